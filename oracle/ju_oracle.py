@@ -1,0 +1,463 @@
+"""CPU oracle for the JoshUpscale per-frame recurrent SR step (numpy, float64).
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  The product path (``joshupscale_amd`` -> libJoshUpscale.so -> HIP kernels)
+never calls into this module and fails loudly when the HIP library is missing.
+
+PARITY UNPINNED.  The reference (itmo153277/JoshUpscale) ships no tests, no
+golden vectors, no weights and no model files, and neither its native path
+(CUDA + TensorRT) nor its Python path (TensorFlow/Keras, onnxruntime) can be
+built or imported in this environment.  This file is therefore a from-source
+restatement of the reference's arithmetic.  It is cross-checked by a second,
+independent restatement built on third-party PyTorch CPU operators
+(``tests/torch_restatement.py``) and by per-primitive known-answer tests, but
+no output of the reference itself anchors it.
+
+Every function cites the reference file:line (relative to the reference root)
+whose behaviour it follows.
+
+Tensor conventions (reference scripts/training/keras_layers.py:208,
+scripts/training/dataset.py:270-289): activations are NHWC without the batch
+dimension here, i.e. ``[H, W, C]``, channel order B,G,R, values in
+[-0.5, 0.5].  Weights are kept in Keras layouts:
+``Conv2D.kernel [kh, kw, cin, cout]``, ``Conv2DTranspose.kernel
+[kh, kw, cout, cin]``.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+SCALE = 4  # reference core/src/tensorrt_backend.cc:27 (kScale)
+
+# reference scripts/training/utils.py:151 (BGR_LUMA)
+BGR_LUMA = np.array([0.114, 0.587, 0.2989], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------
+# model configuration (what the reference bakes into the Keras graph)
+# --------------------------------------------------------------------------
+@dataclass
+class ModelConfig:
+    """Hyper-parameters of ``get_inference_model`` and its two sub-models.
+
+    Defaults are the constructor defaults of the reference
+    (scripts/training/models.py:257-263, 334-339, 365, 484-491, 680-688).
+    """
+
+    frame_height: int = 270
+    frame_width: int = 480
+    num_flow_inputs: int = 4
+    flow_arch: str = "autoencoder"          # or "resnet"
+    flow_filters: Tuple[int, ...] = (32, 64, 128, 256, 128, 64, 32)
+    flow_res_filters: int = 64
+    flow_res_blocks: int = 10
+    flow_pad_factor: int = 8                # 0 = no padding
+    gen_filters: int = 64
+    gen_blocks: int = 24
+    normalize_brightness: bool = False
+    bn_eps: float = 1e-3                    # keras BatchNormalization default
+
+    @property
+    def padded_height(self) -> int:
+        # models.py:735-744
+        f = self.flow_pad_factor
+        if not f:
+            return self.frame_height
+        return (self.frame_height + f - 1) // f * f
+
+    @property
+    def padded_width(self) -> int:
+        f = self.flow_pad_factor
+        if not f:
+            return self.frame_width
+        return (self.frame_width + f - 1) // f * f
+
+
+# --------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------
+def conv2d_same(x: np.ndarray, kernel: np.ndarray,
+                bias: Optional[np.ndarray] = None) -> np.ndarray:
+    """``layers.Conv2D(strides=1, padding="same")`` for odd square kernels.
+
+    Reference call sites: scripts/training/models.py:218-225, 300-306,
+    378-385, 469-475, 531-537.  TF "SAME" padding for stride 1 and kernel k
+    pads (k-1)//2 zeros on every side; the op is a cross-correlation:
+    ``y[h,w,o] = sum_{a,b,c} x[h+a-p, w+b-p, c] * K[a,b,c,o]``.
+    """
+    kh, kw, cin, cout = kernel.shape
+    assert kh == kw and kh % 2 == 1 and x.shape[2] == cin
+    p = (kh - 1) // 2
+    h, w, _ = x.shape
+    xp = np.zeros((h + 2 * p, w + 2 * p, cin), dtype=x.dtype)
+    xp[p:p + h, p:p + w] = x
+    y = np.zeros((h, w, cout), dtype=x.dtype)
+    for a in range(kh):
+        for b in range(kw):
+            y += xp[a:a + h, b:b + w].reshape(-1, cin).dot(
+                kernel[a, b]).reshape(h, w, cout)
+    if bias is not None:
+        y += bias
+    return y
+
+
+def batch_norm(x: np.ndarray, gamma, beta, mean, var, eps: float) -> np.ndarray:
+    """``layers.BatchNormalization`` at inference (models.py:226-228).
+
+    ``y = gamma * (x - mean) / sqrt(var + eps) + beta`` per channel.
+    """
+    return (x - mean) / np.sqrt(var + eps) * gamma + beta
+
+
+def relu(x: np.ndarray) -> np.ndarray:
+    """Default activation of every inference-path model (models.py:261, 337, 489)."""
+    return np.maximum(x, 0)
+
+
+def max_pool_2x2(x: np.ndarray) -> np.ndarray:
+    """``layers.MaxPool2D(pool_size=2)`` (models.py:406-409): stride 2, VALID."""
+    h, w, c = x.shape
+    h2, w2 = h // 2, w // 2
+    return x[:h2 * 2, :w2 * 2].reshape(h2, 2, w2, 2, c).max(axis=(1, 3))
+
+
+def resize_bilinear_tf1(x: np.ndarray, scale: int) -> np.ndarray:
+    """``UpscaleLayer`` (keras_layers.py:46-52).
+
+    ``tf.compat.v1.image.resize_bilinear(align_corners=False,
+    half_pixel_centers=False)``: source coordinate ``s = dst / scale``
+    (asymmetric), ``lo = floor(s)``, ``hi = min(lo + 1, size - 1)``,
+    ``frac = s - lo``; lerp in x inside lerp in y.
+    """
+    h, w, _ = x.shape
+
+    def axis(n_in: int):
+        dst = np.arange(n_in * scale, dtype=np.float64)
+        src = dst / scale
+        lo = np.floor(src).astype(np.int64)
+        hi = np.minimum(lo + 1, n_in - 1)
+        return lo, hi, (src - lo).astype(x.dtype)
+
+    y0, y1, fy = axis(h)
+    x0, x1, fx = axis(w)
+    fx = fx[None, :, None]
+    fy = fy[:, None, None]
+    top = x[y0][:, x0] + (x[y0][:, x1] - x[y0][:, x0]) * fx
+    bot = x[y1][:, x0] + (x[y1][:, x1] - x[y1][:, x0]) * fx
+    return top + (bot - top) * fy
+
+
+def space_to_depth(x: np.ndarray, bs: int) -> np.ndarray:
+    """``tf.nn.space_to_depth`` NHWC (keras_layers.py:129):
+    ``out[h, w, (i*bs + j)*C + c] = x[h*bs + i, w*bs + j, c]``."""
+    h, w, c = x.shape
+    return x.reshape(h // bs, bs, w // bs, bs, c).transpose(0, 2, 1, 3, 4) \
+        .reshape(h // bs, w // bs, bs * bs * c)
+
+
+def depth_to_space(x: np.ndarray, bs: int) -> np.ndarray:
+    """``tf.nn.depth_to_space`` NHWC, "DCR" order (keras_layers.py:175):
+    ``out[h*bs + i, w*bs + j, c] = x[h, w, (i*bs + j)*C' + c]``."""
+    h, w, c = x.shape
+    c2 = c // (bs * bs)
+    return x.reshape(h, w, bs, bs, c2).transpose(0, 2, 1, 3, 4) \
+        .reshape(h * bs, w * bs, c2)
+
+
+def conv2d_transpose_k2s2(x: np.ndarray, kernel: np.ndarray,
+                          bias: Optional[np.ndarray] = None) -> np.ndarray:
+    """``layers.Conv2DTranspose(kernel_size=2, strides=2, padding="same")``
+    (models.py:559-566, 573-579).  Kernel layout ``[kh, kw, cout, cin]``.
+    With k == s there is no overlap:
+    ``y[2h+a, 2w+b, o] = sum_c x[h,w,c] * K[a,b,o,c]``.
+    """
+    kh, kw, cout, cin = kernel.shape
+    assert kh == 2 and kw == 2 and x.shape[2] == cin
+    h, w, _ = x.shape
+    y = np.zeros((h, 2, w, 2, cout), dtype=x.dtype)
+    flat = x.reshape(-1, cin)
+    for a in range(2):
+        for b in range(2):
+            y[:, a, :, b, :] = flat.dot(kernel[a, b].T).reshape(h, w, cout)
+    y = y.reshape(2 * h, 2 * w, cout)
+    if bias is not None:
+        y = y + bias
+    return y
+
+
+def dense_image_warp(image: np.ndarray, flow: np.ndarray) -> np.ndarray:
+    """``DenseWarpLayer`` -> ``dense_image_warp`` -> ``_interpolate_bilinear_impl``
+    (keras_layers.py:79-97; tfa/dense_image_warp.py:182-245, 87-173).
+
+    ``query = (y, x) - flow[y, x, (0, 1)]``; per axis
+    ``floor = min(max(0, floor(q)), size - 2)``, ``alpha = clip(q - floor, 0, 1)``;
+    gather 4 corners; ``top = TL + ax*(TR - TL)``, ``bot = BL + ax*(BR - BL)``,
+    ``out = top + ay*(bot - top)`` (tfa/dense_image_warp.py:169-171).
+    """
+    h, w, _ = image.shape
+    gy, gx = np.meshgrid(np.arange(h, dtype=flow.dtype),
+                         np.arange(w, dtype=flow.dtype), indexing="ij")
+    qy = gy - flow[..., 0]
+    qx = gx - flow[..., 1]
+
+    def axis(q, size):
+        fl = np.minimum(np.maximum(0.0, np.floor(q)), size - 2)
+        alpha = np.clip(q - fl, 0.0, 1.0)
+        return fl.astype(np.int64), alpha
+
+    y0, ay = axis(qy, h)
+    x0, ax = axis(qx, w)
+    y1 = y0 + 1
+    x1 = x0 + 1
+    tl = image[y0, x0]
+    tr = image[y0, x1]
+    bl = image[y1, x0]
+    br = image[y1, x1]
+    ax = ax[..., None].astype(image.dtype)
+    ay = ay[..., None].astype(image.dtype)
+    top = ax * (tr - tl) + tl
+    bot = ax * (br - bl) + bl
+    return ay * (bot - top) + top
+
+
+def preprocess(frame_u8: np.ndarray, dtype=np.float64) -> np.ndarray:
+    """``PreprocessLayer`` (keras_layers.py:192-208): ``x / 255 - 0.5``."""
+    return frame_u8.astype(dtype) / dtype(255) - dtype(0.5)
+
+
+def postprocess(x: np.ndarray) -> np.ndarray:
+    """``PostprocessLayer`` (keras_layers.py:211-230): ``(x + 0.5) * 255`` then a
+    truncating cast to uint8 (``ops.cast``; the deployed graph keeps the value
+    in float and core/src/cuda_convert.cc.cu:76-81 truncates instead).  The
+    input is already clipped to [-0.5, 0.5], so the value is in [0, 255]."""
+    return np.trunc((x + 0.5) * 255).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------
+Weights = Dict[str, np.ndarray]
+
+
+def _conv_bn_act(x, wts: Weights, conv: str, bn: str, eps: float) -> np.ndarray:
+    y = conv2d_same(x, wts[conv + "/kernel"])
+    y = batch_norm(y, wts[bn + "/gamma"], wts[bn + "/beta"],
+                   wts[bn + "/moving_mean"], wts[bn + "/moving_variance"], eps)
+    return relu(y)
+
+
+def res_block(x, wts: Weights, name: str, eps: float) -> np.ndarray:
+    """``res_block`` (models.py:193-254):
+    ``act(BN2(conv2(act(BN1(conv1(x))))) + x)``; FadeIn is the identity at
+    inference once its counter has saturated (keras_layers.py:321-323)."""
+    y = _conv_bn_act(x, wts, name + "/conv_1", name + "/bn_1", eps)
+    y = conv2d_same(y, wts[name + "/conv_2/kernel"])
+    b = name + "/bn_2"
+    y = batch_norm(y, wts[b + "/gamma"], wts[b + "/beta"],
+                   wts[b + "/moving_mean"], wts[b + "/moving_variance"], eps)
+    return relu(y + x)
+
+
+def flow_autoencoder(frames: Sequence[np.ndarray], wts: Weights,
+                     cfg: ModelConfig) -> np.ndarray:
+    """``get_flow_autoencoder`` (models.py:334-481).  Returns the flow field
+    ``[4*PH, 4*PW, 2]`` (channel 0 = dy, 1 = dx, in HR pixels)."""
+    eps = cfg.bn_eps
+    x = np.concatenate(list(frames), axis=2)  # models.py:373-375
+    filters = cfg.flow_filters
+    nblk = len(filters) // 2
+    for i in range(nblk):  # down blocks, models.py:377-410, 450-451
+        n = f"flow/block_{i + 1}"
+        x = _conv_bn_act(x, wts, n + "/conv_1", n + "/bn_1", eps)
+        x = _conv_bn_act(x, wts, n + "/conv_2", n + "/bn_2", eps)
+        x = max_pool_2x2(x)
+    for i in range(nblk, 2 * nblk):  # up blocks, models.py:412-447, 452-453
+        n = f"flow/block_{i + 1}"
+        x = _conv_bn_act(x, wts, n + "/conv_1", n + "/bn_1", eps)
+        x = _conv_bn_act(x, wts, n + "/conv_2", n + "/bn_2", eps)
+        x = resize_bilinear_tf1(x, 2)
+    if len(filters) % 2:  # models.py:454-468
+        x = _conv_bn_act(x, wts, "flow/conv_1", "flow/bn_1", eps)
+    x = conv2d_same(x, wts["flow/conv_2/kernel"], wts["flow/conv_2/bias"])
+    return depth_to_space(x, 4)  # models.py:476-479
+
+
+def flow_resnet(frames: Sequence[np.ndarray], wts: Weights,
+                cfg: ModelConfig) -> np.ndarray:
+    """``get_flow_resnet`` (models.py:257-331)."""
+    eps = cfg.bn_eps
+    x = np.concatenate(list(frames), axis=2)
+    x = _conv_bn_act(x, wts, "flow/conv_1", "flow/bn_1", eps)
+    for i in range(cfg.flow_res_blocks):
+        x = res_block(x, wts, f"flow/block_{i + 1}", eps)
+    x = conv2d_same(x, wts["flow/conv_2/kernel"], wts["flow/conv_2/bias"])
+    return depth_to_space(x, 4)
+
+
+def generator(images: np.ndarray, pre_warp: np.ndarray, wts: Weights,
+              cfg: ModelConfig) -> np.ndarray:
+    """``get_generator_resnet`` (models.py:484-595)."""
+    eps = cfg.bn_eps
+    x = np.concatenate([images, space_to_depth(pre_warp, 4)], axis=2)  # :523-530
+    x = _conv_bn_act(x, wts, "generator/conv_1", "generator/bn_1", eps)
+    for i in range(cfg.gen_blocks):
+        x = res_block(x, wts, f"generator/block_{i + 1}", eps)
+    x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_1/kernel"])
+    b = "generator/bn_2"
+    x = relu(batch_norm(x, wts[b + "/gamma"], wts[b + "/beta"],
+                        wts[b + "/moving_mean"], wts[b + "/moving_variance"],
+                        eps))
+    x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_2/kernel"],
+                              wts["generator/conv_trans_2/bias"])
+    x = np.tanh(x)                                  # models.py:580-583
+    x = resize_bilinear_tf1(images, 4) + x          # models.py:584-590
+    return np.clip(x, -0.5, 0.5)                    # ClipLayer, :591-593
+
+
+# --------------------------------------------------------------------------
+# the recurrent step and the driver loop
+# --------------------------------------------------------------------------
+@dataclass
+class State:
+    """Recurrent state: previous HR output and the LR frame shift register.
+    Zero-initialised (core/include/JoshUpscale/core/cuda.h:69-72,
+    scripts/inference/onnx/inference.py:67-70)."""
+    pre_gen: np.ndarray
+    last_frames: List[np.ndarray]
+
+    @staticmethod
+    def zeros(cfg: ModelConfig, dtype=np.float64) -> "State":
+        return State(
+            np.zeros((cfg.frame_height * SCALE, cfg.frame_width * SCALE, 3),
+                     dtype=dtype),
+            [np.zeros((cfg.padded_height, cfg.padded_width, 3), dtype=dtype)
+             for _ in range(cfg.num_flow_inputs - 1)])
+
+
+@dataclass
+class StepOutputs:
+    output: np.ndarray        # uint8 [4H, 4W, 3]
+    output_raw: np.ndarray
+    pre_warp: np.ndarray
+    flow: np.ndarray          # cropped flow [4H, 4W, 2]
+    state: State = field(repr=False, default=None)
+
+
+def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
+                   cfg: ModelConfig, dtype=np.float64) -> StepOutputs:
+    """One execution of ``get_inference_model`` (models.py:680-829) with
+    ``skip_processing=False``.  ``cur_frame_u8`` is ``[H, W, 3]`` uint8 BGR."""
+    h, w = cfg.frame_height, cfg.frame_width
+    assert cur_frame_u8.shape == (h, w, 3) and cur_frame_u8.dtype == np.uint8
+    cur = preprocess(cur_frame_u8, dtype)                         # :768-770
+    cur_pad = cur
+    brightness = None
+    if cfg.normalize_brightness:                                  # :772-779
+        brightness = np.mean(cur * BGR_LUMA.astype(dtype) * 3)
+        cur_pad = cur_pad - brightness
+    ph, pw = cfg.padded_height, cfg.padded_width
+    if (ph, pw) != (h, w):                                        # :780-789
+        pad_h, pad_w = ph - h, pw - w
+        padded = np.zeros((ph, pw, 3), dtype=dtype)
+        padded[pad_h // 2:pad_h // 2 + h, pad_w // 2:pad_w // 2 + w] = cur_pad
+        cur_pad = padded
+    frames = [cur_pad] + list(state.last_frames)
+    if cfg.flow_arch == "autoencoder":
+        flow = flow_autoencoder(frames, wts, cfg)                 # :790
+    elif cfg.flow_arch == "resnet":
+        flow = flow_resnet(frames, wts, cfg)
+    else:
+        raise ValueError(cfg.flow_arch)
+    if (ph, pw) != (h, w):                                        # :791-798
+        oy = ((ph - h) // 2) * 4
+        ox = ((pw - w) // 2) * 4
+        flow = flow[oy:oy + h * 4, ox:ox + w * 4]
+    pre_warp = dense_image_warp(state.pre_gen, flow)              # :799-801
+    if cfg.normalize_brightness:
+        pre_warp = pre_warp + brightness                          # :802-803
+    output_raw = generator(cur, pre_warp, wts, cfg)               # :804
+    output = postprocess(output_raw)                              # :805-807
+    if cfg.normalize_brightness:
+        output_raw = output_raw - brightness                      # :809-810
+    new_state = State(output_raw,
+                      [cur_pad] + list(state.last_frames[:-1]))  # :821-823
+    return StepOutputs(output, output_raw, pre_warp, flow, new_state)
+
+
+def bgrx_to_bgr(frame_bgrx: np.ndarray) -> np.ndarray:
+    """Stage-in of the plugin boundary: 4 bytes per pixel, B,G,R,X; X ignored
+    (core/include/JoshUpscale/core/tensor.h:18-20, 41-43;
+    core/src/cuda_convert.cc.cu:95-108 copies lanes x,y,z only)."""
+    return np.ascontiguousarray(frame_bgrx[..., :3])
+
+
+def bgr_to_bgrx(frame_bgr: np.ndarray) -> np.ndarray:
+    """Stage-out: the 4th byte is written as 0 (cuda_convert.cc.cu:39-45)."""
+    h, w, _ = frame_bgr.shape
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    out[..., :3] = frame_bgr
+    return out
+
+
+class Session:
+    """Recurrent driver, mirroring ``Session`` of
+    scripts/inference/onnx/inference.py:46-94 (zero state, feed outputs[1:]
+    back into inputs[1:]) on BGRX frames as ``Runtime::processImage`` sees them
+    (core/src/tensorrt_backend.cc:270-278)."""
+
+    def __init__(self, wts: Weights, cfg: ModelConfig, dtype=np.float64):
+        self.wts = {k: np.asarray(v, dtype=dtype) for k, v in wts.items()}
+        self.cfg = cfg
+        self.dtype = dtype
+        self.reset()
+
+    def reset(self) -> None:
+        self.state = State.zeros(self.cfg, self.dtype)
+        self.last: Optional[StepOutputs] = None
+
+    def run(self, frame_bgrx: np.ndarray) -> np.ndarray:
+        out = inference_step(bgrx_to_bgr(frame_bgrx), self.state, self.wts,
+                             self.cfg, self.dtype)
+        self.state = out.state
+        self.last = out
+        return bgr_to_bgrx(out.output)
+
+
+# --------------------------------------------------------------------------
+# algorithmic work (used by bench.py / DESIGN.md for the roofline figures)
+# --------------------------------------------------------------------------
+def macs_per_frame(cfg: ModelConfig) -> Dict[str, int]:
+    """Multiply-accumulates of one frame, by part."""
+    h, w = cfg.frame_height, cfg.frame_width
+    ph, pw = cfg.padded_height, cfg.padded_width
+    nf = cfg.gen_filters
+    gen = h * w * (9 * (3 + 48) * nf + cfg.gen_blocks * 2 * 9 * nf * nf
+                   + 4 * nf * 32) + (2 * h) * (2 * w) * 4 * 32 * 3
+    cin = 3 * cfg.num_flow_inputs
+    flow = 0
+    if cfg.flow_arch == "autoencoder":
+        f = cfg.flow_filters
+        nb = len(f) // 2
+        px = ph * pw
+        for i in range(nb):
+            flow += px * 9 * (cin * f[i] + f[i] * f[i])
+            cin = f[i]
+            px //= 4
+        for i in range(nb, 2 * nb):
+            flow += px * 9 * (cin * f[i] + f[i] * f[i])
+            cin = f[i]
+            px *= 4
+        if len(f) % 2:
+            flow += px * 9 * cin * f[-1]
+            cin = f[-1]
+        flow += px * 9 * cin * 32
+    else:
+        n = cfg.flow_res_filters
+        flow = ph * pw * (9 * cin * n + cfg.flow_res_blocks * 2 * 9 * n * n
+                          + 1 * n * 32)  # conv_2 is 1x1 (models.py:320-325)
+    return {"generator": gen, "flow": flow, "total": gen + flow}
