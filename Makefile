@@ -1,0 +1,36 @@
+# Builds libJoshUpscale.so (C ABI + C++ plugin surface + gfx950 kernels) in-tree.
+# No cmake on purpose: the GPU box runs the prebuilt .so that travels with the
+# snapshot; `python -c "import __graft_entry__ as g; g.build()"` drives this.
+HIPCC      ?= /opt/rocm/bin/hipcc
+ARCH       ?= gfx950
+CSRC       := joshupscale_amd/csrc
+OUT        := joshupscale_amd/lib
+OBJ        := build/obj
+CXXFLAGS   := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wall -Wextra \
+              -Wno-unused-parameter
+HIPFLAGS   := --offload-arch=$(ARCH) $(CXXFLAGS)
+SRCS_CPP   := model.cpp engine.cpp c_api.cpp core_api.cpp log.cpp
+OBJS       := $(addprefix $(OBJ)/,$(SRCS_CPP:.cpp=.o)) $(OBJ)/kernels.o
+
+all: $(OUT)/libJoshUpscale.so
+
+$(OBJ)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJ)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/joshupscale_amd.h include/JoshUpscale/core.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) -x hip $(HIPFLAGS) -c $< -o $@
+
+$(OUT)/libJoshUpscale.so: $(OBJS)
+	@mkdir -p $(OUT)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,--exclude-libs,ALL
+
+harness: $(OUT)/libJoshUpscale.so tools/plugin_harness.cpp
+	g++ -O2 -std=c++17 -Iinclude tools/plugin_harness.cpp -o build/plugin_harness \
+	    -L$(OUT) -lJoshUpscale -Wl,-rpath,'$$ORIGIN/../$(OUT)'
+
+clean:
+	rm -rf build $(OUT)
+
+.PHONY: all clean harness

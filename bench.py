@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of 480x270 -> 1920x1080 recurrent SR on MI355X.
+
+A "step" is one frame through the drop-in boundary (`ju_process`, the C ABI form
+of `Runtime::processImage`, reference core/src/tensorrt_backend.cc:270-278):
+stage-in, one recurrent step (flow net, warp, generator), stage-out,
+synchronise.  Frames are synthetic random BGRX and already resident in HBM when
+the timed region starts (JU_LOC_DEVICE images); weights are seeded random-init of
+the reference's default architecture ("PSP quality", see BASELINE.json).
+
+N GPUs = N independent streams, one process per GPU, one RCCL broadcast of the
+model container at start-up, no per-frame communication ("replicas only").
+
+Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from joshupscale_amd import dist as jdist  # noqa: E402
+from joshupscale_amd import model_file as M  # noqa: E402
+from joshupscale_amd import runtime as R  # noqa: E402
+
+PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(blob: bytes, cfg, frames: np.ndarray, budget_s: float) -> dict:
+    """The C restatement of the reference path (oracle/ju_oracle_c.c), timed on
+    this box's host cores on a bounded sample of the same workload."""
+    from oracle.c_binding import CSession
+    sess = CSession(blob, cfg.frame_height, cfg.frame_width)
+    t0 = time.perf_counter()
+    sess.run(frames[0])
+    first = time.perf_counter() - t0
+    n = int(max(1, min(8, budget_s // max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(n):
+        sess.run(frames[(i + 1) % len(frames)])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": sess.threads, "kind": "port",
+            "sample": f"{n} frame(s) of the same {cfg.frame_width}x{cfg.frame_height} clip "
+                      f"after 1 warm-up frame, C fp32 restatement with OpenMP "
+                      f"({dt / n:.2f} s/frame, host has {os.cpu_count()} logical CPUs)"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--preset", default="psp-quality", choices=sorted(M.PRESETS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--location", default="device", choices=["device", "host"],
+                    help="host = PCIe-inclusive (not the headline value)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-iters", type=int, default=20)
+    args = ap.parse_args()
+
+    rank, local_rank, world = jdist.env_world()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        jdist.init("nccl")  # RCCL
+
+    cfg = M.PRESETS[args.preset]
+    blob = None
+    if rank == 0:
+        blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=42))
+    blob = jdist.broadcast_model(blob, device)
+    dt = R.DTYPE_BF16 if args.dtype == "bf16" else R.DTYPE_F16
+    rt = R.Runtime(blob, device=local_rank, dtype=dt)
+
+    h, w = cfg.frame_height, cfg.frame_width
+    clip = M.synthetic_frames(16, h, w, seed=1234 + rank, kind="noise")
+    out_host = np.empty((4 * h, 4 * w, 4), np.uint8)
+    if args.location == "device":
+        d_in = torch.from_numpy(clip).to(device)
+        d_out = torch.empty((4 * h, 4 * w, 4), dtype=torch.uint8, device=device)
+        ins = [rt.device_image(d_in[i].data_ptr(), w, h) for i in range(len(clip))]
+        outs = [rt.device_image(d_out.data_ptr(), 4 * w, 4 * h)] * len(clip)
+    else:
+        ins = [R.host_image(clip[i]) for i in range(len(clip))]
+        outs = [R.host_image(out_host)] * len(clip)
+    torch.cuda.synchronize()
+
+    def step(i: int) -> None:
+        rt.process(ins[i % len(ins)], outs[i % len(outs)])
+
+    for i in range(args.warmup):
+        step(i)
+    jdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    jdist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = jdist.max_over_ranks(elapsed, device)
+
+    result = None
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        # dominant kernel: the 3x3 64->64 convolution of the residual tower,
+        # timed with HIP events on the engine's own stream
+        ms, launches, flops = rt.time_steps("tower", args.roofline_iters)
+        flops_per_launch = flops / max(launches, 1)
+        achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        total_flops = rt.time_steps("", 0)[2]
+        result = {
+            "metric": "frames/sec 480x270->1920x1080 recurrent SR" if args.preset.startswith("psp")
+                      else f"frames/sec {w}x{h}->{4 * w}x{4 * h} recurrent SR",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": f"{args.preset}: {w}x{h}->{4 * w}x{4 * h} recurrent loop, 1 stream per GPU, "
+                            f"{args.dtype} MFMA operands, fp32 accumulate, frames resident in "
+                            f"{'HBM' if args.location == 'device' else 'host memory (PCIe-inclusive)'}",
+                "weights": "seeded random-init (seed 42), reference default architecture",
+                "streams": world, "parallelism": f"replicas x{world}",
+                "boundary": "ju_process (synchronous processImage)",
+                "gflop_per_frame": total_flops / 1e9,
+                "whole_frame_tflops": total_flops * fps / world / 1e12,
+            },
+            "roofline": {
+                "kernel": "conv_mfma 3x3 64->64 (generator residual tower)",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": None,
+                "launch_ms": ms, "launches_per_frame": launches,
+                "flops_per_launch": flops_per_launch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(blob, cfg, clip, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    jdist.barrier()
+    rt.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

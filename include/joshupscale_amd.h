@@ -1,0 +1,148 @@
+/*
+ * joshupscale_amd.h -- C ABI of the MI355X-native JoshUpscale runtime.
+ *
+ * This is the drop-in boundary for the reference's core/ runtime: plain C,
+ * plain pointers and sizes, no C++ or torch types.  Each entry point states the
+ * reference interface it replaces (paths relative to the reference repository).
+ * The C++ surface the AviSynth/OBS plugins compile against
+ * (include/JoshUpscale/core.h) is a thin shim over these functions; so are the
+ * Python (ctypes) bindings in joshupscale_amd/runtime.py.
+ *
+ * Threading: a ju_runtime is not thread-safe (one internal HIP stream; the
+ * reference declares MT_SERIALIZED, avisynth_plugin/src/main.cc:176-178).
+ * Several runtimes, also on different devices, may coexist.  ju_last_error()
+ * is thread-local.
+ *
+ * Every function returning int returns JU_OK (0) or a JU_ERR_* code; the
+ * message is then available from ju_last_error() on the calling thread.
+ */
+#ifndef JOSHUPSCALE_AMD_H_
+#define JOSHUPSCALE_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define JU_API __attribute__((visibility("default")))
+#else
+#define JU_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ju_runtime ju_runtime;
+
+enum {
+	JU_OK = 0,
+	JU_ERR_INVALID_ARGUMENT = 1, /* std::invalid_argument in the reference */
+	JU_ERR_IO = 2,               /* std::ios_base::failure (model file) */
+	JU_ERR_DEVICE = 3,           /* HIP error (CudaException, core/include/JoshUpscale/core/cuda.h:24-32) */
+	JU_ERR_UNSUPPORTED = 4,
+	JU_ERR_INTERNAL = 5
+};
+
+/* DataLocation of core/public/JoshUpscale/core.h:30.  JU_LOC_DEVICE is the
+ * reference's CUDA location reinterpreted as "HIP device pointer". */
+enum { JU_LOC_CPU = 0, JU_LOC_DEVICE = 1, JU_LOC_GRAPHICS_RESOURCE = 2 };
+
+/* Compute precision of MFMA operands / stored activations. */
+enum { JU_DTYPE_DEFAULT = -1, JU_DTYPE_F16 = 0, JU_DTYPE_BF16 = 1 };
+
+/* LogLevel of core/public/JoshUpscale/core.h:21. */
+enum { JU_LOG_INFO = 0, JU_LOG_WARNING = 1, JU_LOG_ERROR = 2 };
+
+/* Mirrors struct Image (core/public/JoshUpscale/core.h:32-38) field for field:
+ * 4 bytes per pixel, byte order B,G,R,X (X ignored on input, written 0 on
+ * output); stride in bytes, may be negative (bottom-up frames, ptr = first
+ * logical row); width/height in pixels. */
+typedef struct ju_image {
+	void *ptr;
+	uint8_t location;
+	ptrdiff_t stride;
+	size_t width;
+	size_t height;
+} ju_image;
+
+/* Replaces createRuntime(int deviceId, const std::filesystem::path &modelPath)
+ * (core/public/JoshUpscale/core.h:91-92, core/src/core.cc:153-175, 197-199):
+ * reads the whole model file, selects the device for the duration of the call,
+ * builds the engine.  The file is this runtime's .jupw container
+ * (joshupscale_amd/model_file.py), not a TensorRT engine. */
+JU_API int ju_create(int device_id, const char *model_path, ju_runtime **out_runtime);
+
+/* Same, from model bytes already in memory (what TensorRTBackend's constructor
+ * takes: core/src/tensorrt_backend.cc:117).  dtype: JU_DTYPE_*.  Used by the
+ * multi-GPU launcher after the RCCL weight broadcast. */
+JU_API int ju_create_from_memory(int device_id, const void *model_bytes, size_t model_size,
+    int dtype, ju_runtime **out_runtime);
+
+/* Replaces Runtime::~Runtime via delete (core.h:65-66). NULL is a no-op. */
+JU_API void ju_destroy(ju_runtime *runtime);
+
+/* Replaces Runtime::processImage(const Image&, const Image&) (core.h:68-69,
+ * core/src/core.cc:177-189, core/src/tensorrt_backend.cc:270-278): stage-in,
+ * one recurrent step, stage-out, stream synchronise, state ping-pong.
+ * Unlike the reference (assert only, core.cc:179-182) wrong sizes are an
+ * error (JU_ERR_INVALID_ARGUMENT). */
+JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image *output);
+
+/* Asynchronous form for JU_LOC_DEVICE images: enqueues the same work on the
+ * runtime's stream and returns; ju_synchronize() waits.  Frames are still
+ * strictly ordered (the recurrence is carried by stream order). */
+JU_API int ju_enqueue(ju_runtime *runtime, const ju_image *input, const ju_image *output);
+JU_API int ju_synchronize(ju_runtime *runtime);
+
+/* Replaces Runtime::getInputWidth/Height, getOutputWidth/Height (core.h:71-82). */
+JU_API int ju_get_size(const ju_runtime *runtime, size_t *input_width, size_t *input_height,
+    size_t *output_width, size_t *output_height);
+
+/* Zeroes the recurrent state; equivalent to destroying and recreating the
+ * runtime as the OBS filter does on a model switch (obs_plugin/src/filter.cc:146-151). */
+JU_API int ju_reset(ju_runtime *runtime);
+
+/* Replaces getExceptionString() (core.h:94): message of the last failed call on
+ * this thread ("" if none). The pointer stays valid until the next failing
+ * call on the same thread. */
+JU_API const char *ju_last_error(void);
+
+/* Replaces setLogSink(LogSink*) (core.h:23-28). callback NULL restores the
+ * default sink (stderr, warnings and errors only unless JU_VERBOSE=1). */
+typedef void (*ju_log_callback)(const char *tag, int level, const char *message, void *user);
+JU_API void ju_set_log_callback(ju_log_callback callback, void *user);
+
+/* Replaces getGLDeviceIndex() / getGLImage() (core.h:60-62): graphics interop is
+ * not available in this runtime yet; both report JU_ERR_UNSUPPORTED. */
+JU_API int ju_get_gl_device_index(int *out_device);
+JU_API int ju_get_gl_image(uint32_t gl_texture, int type, ju_image *out_image);
+
+/* ---- introspection (tests and bench.py; no reference counterpart) ---------- */
+
+/* Compute dtype actually in use (JU_DTYPE_F16 / JU_DTYPE_BF16). */
+JU_API int ju_get_dtype(const ju_runtime *runtime);
+
+/* Copies a named internal tensor to host memory as float32.  *count receives the
+ * element count; dst may be NULL to query it.  Names: "state" (last output_raw,
+ * f16 [4H][4W][4]), "flow" (f32 [PH][PW][32]), "flow_in", "gen_in", "trunk",
+ * "tail_y", and the per-layer flow activations. */
+JU_API int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, size_t capacity,
+    size_t *count);
+
+/* Average device time in milliseconds of ONE kernel launch among the per-frame
+ * steps tagged `tag` ("tower" = the 3x3 64->64 convolutions of the generator's
+ * residual blocks, "flow", "warp", "gen_head", "tail", "pack", "" = all),
+ * measured with HIP events on the runtime's own stream over `iters`
+ * repetitions.  *launches = kernel launches per repetition, *flops = their
+ * algorithmic FLOPs (2*MAC) per repetition. */
+JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_per_launch,
+    int *launches, double *flops);
+
+/* Library version string, e.g. "joshupscale-amd 0.1 (gfx950)". */
+JU_API const char *ju_version(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* JOSHUPSCALE_AMD_H_ */

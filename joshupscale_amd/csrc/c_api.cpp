@@ -1,0 +1,193 @@
+// extern "C" entry points of libJoshUpscale.so (include/joshupscale_amd.h).
+// Exceptions never cross this boundary: each call is wrapped, the message is
+// kept per thread for ju_last_error().
+
+#include "joshupscale_amd.h"
+
+#include <cstdio>
+#include <fstream>
+#include <ios>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+#include "log.h"
+
+struct ju_runtime {
+	std::unique_ptr<ju::Engine> engine;
+};
+
+namespace {
+
+thread_local std::string g_LastError;
+
+int fail(int code, const std::string &msg) {
+	g_LastError = msg;
+	ju::logMessage(ju::LogLevel::Error, "Core", msg);
+	return code;
+}
+
+template <typename F>
+int guarded(F &&f) {
+	try {
+		f();
+		return JU_OK;
+	} catch (const ju::HipError &e) {
+		return fail(JU_ERR_DEVICE, std::string("HipException: ") + e.what());
+	} catch (const std::invalid_argument &e) {
+		return fail(JU_ERR_INVALID_ARGUMENT, std::string("std::invalid_argument: ") + e.what());
+	} catch (const std::ios_base::failure &e) {
+		return fail(JU_ERR_IO, std::string("std::ios_base::failure: ") + e.what());
+	} catch (const std::bad_alloc &e) {
+		return fail(JU_ERR_INTERNAL, std::string("std::bad_alloc: ") + e.what());
+	} catch (const std::exception &e) {
+		return fail(JU_ERR_INTERNAL, std::string("std::exception: ") + e.what());
+	} catch (...) {
+		return fail(JU_ERR_INTERNAL, "unknown exception");
+	}
+}
+
+ju::Frame toFrame(const ju_image *img) {
+	if (img == nullptr) throw std::invalid_argument("image is NULL");
+	if (img->location > JU_LOC_GRAPHICS_RESOURCE) {
+		throw std::invalid_argument("image has an unknown location");
+	}
+	return ju::Frame{img->ptr, static_cast<ju::Location>(img->location), img->stride, img->width,
+	    img->height};
+}
+
+ju::Engine &engineOf(ju_runtime *rt) {
+	if (rt == nullptr || !rt->engine) throw std::invalid_argument("runtime is NULL");
+	return *rt->engine;
+}
+
+int createFromBytes(int device, const void *bytes, std::size_t size, int dtype, ju_runtime **out) {
+	return guarded([&] {
+		if (out == nullptr) throw std::invalid_argument("out_runtime is NULL");
+		*out = nullptr;
+		int count = 0;
+		JU_HIP(hipGetDeviceCount(&count));
+		if (device < 0 || device >= count) {
+			throw std::invalid_argument("device " + std::to_string(device) + " does not exist (" +
+			                            std::to_string(count) + " HIP devices visible)");
+		}
+		ju::DeviceGuard guard(device);  // like cuda::DeviceContext in core/src/core.cc:168
+		auto rt = std::make_unique<ju_runtime>();
+		rt->engine = std::make_unique<ju::Engine>(device, bytes, size, dtype);
+		*out = rt.release();
+	});
+}
+
+}  // namespace
+
+extern "C" {
+
+int ju_create(int device_id, const char *model_path, ju_runtime **out_runtime) {
+	std::vector<char> bytes;
+	int rc = guarded([&] {
+		if (model_path == nullptr) throw std::invalid_argument("model_path is NULL");
+		// whole-file read with failbit/badbit exceptions, as core/src/core.cc:156-167
+		std::ifstream f(model_path, std::ifstream::in | std::ifstream::binary | std::ifstream::ate);
+		if (!f) throw std::ios_base::failure(std::string("cannot open model file ") + model_path);
+		f.exceptions(std::ifstream::badbit | std::ifstream::failbit);
+		const auto size = static_cast<std::size_t>(f.tellg());
+		bytes.resize(size);
+		f.seekg(0);
+		f.read(bytes.data(), static_cast<std::streamsize>(size));
+	});
+	if (rc != JU_OK) return rc;
+	return createFromBytes(device_id, bytes.data(), bytes.size(), JU_DTYPE_DEFAULT, out_runtime);
+}
+
+int ju_create_from_memory(int device_id, const void *model_bytes, size_t model_size, int dtype,
+    ju_runtime **out_runtime) {
+	return createFromBytes(device_id, model_bytes, model_size, dtype, out_runtime);
+}
+
+void ju_destroy(ju_runtime *runtime) {
+	delete runtime;
+}
+
+int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image *output) {
+	return guarded([&] { engineOf(runtime).process(toFrame(input), toFrame(output)); });
+}
+
+int ju_enqueue(ju_runtime *runtime, const ju_image *input, const ju_image *output) {
+	return guarded([&] {
+		const ju::Frame in = toFrame(input), out = toFrame(output);
+		if (in.location != ju::Location::Device || out.location != ju::Location::Device) {
+			throw std::invalid_argument("ju_enqueue needs JU_LOC_DEVICE images");
+		}
+		engineOf(runtime).enqueue(in, out);
+	});
+}
+
+int ju_synchronize(ju_runtime *runtime) {
+	return guarded([&] { engineOf(runtime).synchronize(); });
+}
+
+int ju_get_size(const ju_runtime *runtime, size_t *input_width, size_t *input_height,
+    size_t *output_width, size_t *output_height) {
+	return guarded([&] {
+		const ju::FrameSize fs = engineOf(const_cast<ju_runtime *>(runtime)).frameSize();
+		if (input_width) *input_width = fs.inputWidth;
+		if (input_height) *input_height = fs.inputHeight;
+		if (output_width) *output_width = fs.outputWidth;
+		if (output_height) *output_height = fs.outputHeight;
+	});
+}
+
+int ju_reset(ju_runtime *runtime) {
+	return guarded([&] { engineOf(runtime).reset(); });
+}
+
+const char *ju_last_error(void) {
+	return g_LastError.c_str();
+}
+
+void ju_set_log_callback(ju_log_callback callback, void *user) {
+	ju::setLogCallback(callback, user);
+}
+
+int ju_get_gl_device_index(int *out_device) {
+	if (out_device) *out_device = -1;
+	return fail(JU_ERR_UNSUPPORTED, "std::runtime_error: OpenGL interop is not supported by the MI355X runtime");
+}
+
+int ju_get_gl_image(uint32_t, int, ju_image *out_image) {
+	if (out_image) *out_image = ju_image{};
+	return fail(JU_ERR_UNSUPPORTED, "std::runtime_error: OpenGL interop is not supported by the MI355X runtime");
+}
+
+int ju_get_dtype(const ju_runtime *runtime) {
+	if (runtime == nullptr || !runtime->engine) return -1;
+	return static_cast<int>(runtime->engine->dtype());
+}
+
+int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, size_t capacity,
+    size_t *count) {
+	return guarded([&] {
+		if (name == nullptr) throw std::invalid_argument("name is NULL");
+		const std::size_t n = engineOf(runtime).readTensor(name, dst, capacity);
+		if (count) *count = n;
+	});
+}
+
+int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_per_launch,
+    int *launches, double *flops) {
+	return guarded([&] {
+		const std::string t = tag ? tag : "";
+		ju::Engine &e = engineOf(runtime);
+		const double ms = e.timeSteps(t, iters, launches);
+		if (ms_per_launch) *ms_per_launch = ms;
+		if (flops) *flops = e.flopsOf(t);
+	});
+}
+
+const char *ju_version(void) {
+	return "joshupscale-amd 0.1 (gfx950)";
+}
+
+}  // extern "C"

@@ -1,0 +1,579 @@
+#include "engine.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+
+#include "log.h"
+
+namespace ju {
+
+namespace {
+
+std::vector<int> identityMap(int cin, int cinP) {
+	std::vector<int> m(cinP, -1);
+	for (int i = 0; i < cin; ++i) m[i] = i;
+	return m;
+}
+
+int roundUp(int v, int m) { return (v + m - 1) / m * m; }
+
+// Packed channel order of the generator input record written by warp_pack_kernel:
+// ch = i*16 + j*3 + c  <- reference channel 3 + (i*4+j)*3 + c   (space_to_depth,
+// keras_layers.py:129, concatenated after the 3 LR channels, models.py:523-530)
+// ch 12,13,14          <- reference channels 0,1,2 (the LR frame)
+std::vector<int> generatorInputMap() {
+	std::vector<int> m(64, -1);
+	for (int i = 0; i < 4; ++i) {
+		for (int j = 0; j < 4; ++j) {
+			for (int c = 0; c < 3; ++c) m[i * 16 + j * 3 + c] = 3 + (i * 4 + j) * 3 + c;
+		}
+	}
+	m[12] = 0;
+	m[13] = 1;
+	m[14] = 2;
+	return m;
+}
+
+}  // namespace
+
+Engine::Tensor &Engine::addTensor(
+    const std::string &name, std::size_t count, bool f32, bool state) {
+	Tensor t;
+	t.buf = DeviceBuffer(count * (f32 ? 4 : 2));
+	t.count = count;
+	t.isF32 = f32;
+	t.isState = state;
+	auto res = m_Tensors.emplace(name, std::move(t));
+	if (!res.second) throw std::logic_error("duplicate tensor " + name);
+	return res.first->second;
+}
+
+Engine::ConvWeights &Engine::addConv(
+    const std::string &name, const FoldedConv &f, const std::vector<int> &cinMap) {
+	ConvWeights cw;
+	const auto packed = packConvWeights(f, cinMap, m_DType);
+	cw.w = DeviceBuffer(packed.size() * 2);
+	cw.w.upload(packed.data(), packed.size() * 2);
+	cw.bias = DeviceBuffer(f.bias.size() * 4);
+	cw.bias.upload(f.bias.data(), f.bias.size() * 4);
+	cw.cinP = static_cast<int>(cinMap.size());
+	cw.cout = f.cout;
+	cw.taps = f.taps;
+	cw.cinReal = f.cin;
+	auto res = m_Convs.emplace(name, std::move(cw));
+	if (!res.second) throw std::logic_error("duplicate conv " + name);
+	return res.first->second;
+}
+
+void Engine::buildWeights(const ModelFile &model) {
+	const ModelConfig &c = m_Config;
+	auto plain = [&](const std::string &conv, const std::string &bn, bool bias) {
+		FoldedConv f = foldConv(model, conv, bn, bias);
+		addConv(conv, f, identityMap(f.cin, roundUp(f.cin, 16)));
+		return f.cout;
+	};
+	// ---- flow ----
+	const int flowCin = 3 * c.numFlowInputs;
+	if (c.flowArch == 0) {
+		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+		int cin = flowCin;
+		for (int i = 0; i < 2 * nb; ++i) {
+			const std::string n = "flow/block_" + std::to_string(i + 1);
+			const TensorView &k = model.tensor(n + "/conv_1/kernel");
+			if (k.dims.size() != 4 || k.dims[2] != cin || k.dims[3] != c.flowFilters[i]) {
+				throw std::invalid_argument("Invalid model: flow filter mismatch at " + n);
+			}
+			plain(n + "/conv_1", n + "/bn_1", false);
+			cin = plain(n + "/conv_2", n + "/bn_2", false);
+		}
+		if (c.flowFilters.size() % 2) plain("flow/conv_1", "flow/bn_1", false);
+		if (plain("flow/conv_2", "", true) != 32) {
+			throw std::invalid_argument("Invalid model: flow head must have 32 channels");
+		}
+	} else {
+		plain("flow/conv_1", "flow/bn_1", false);
+		for (int i = 0; i < c.flowResBlocks; ++i) {
+			const std::string n = "flow/block_" + std::to_string(i + 1);
+			plain(n + "/conv_1", n + "/bn_1", false);
+			plain(n + "/conv_2", n + "/bn_2", false);
+		}
+		if (plain("flow/conv_2", "", true) != 32) {
+			throw std::invalid_argument("Invalid model: flow head must have 32 channels");
+		}
+	}
+	// ---- generator ----
+	{
+		FoldedConv f = foldConv(model, "generator/conv_1", "generator/bn_1", false);
+		if (f.cin != 51 || f.cout != c.genFilters) {
+			throw std::invalid_argument("Invalid model: generator/conv_1 must be 51 -> gen_filters");
+		}
+		addConv("generator/conv_1", f, generatorInputMap());
+	}
+	for (int i = 0; i < c.genBlocks; ++i) {
+		const std::string n = "generator/block_" + std::to_string(i + 1);
+		plain(n + "/conv_1", n + "/bn_1", false);
+		plain(n + "/conv_2", n + "/bn_2", false);
+	}
+	{
+		FoldedConv f = foldConvTranspose2x2(model, "generator/conv_trans_1", "generator/bn_2");
+		if (f.cout != 128 || f.cin != c.genFilters) {
+			throw std::invalid_argument("Invalid model: conv_trans_1 must be gen_filters -> 32");
+		}
+		addConv("generator/conv_trans_1", f, identityMap(f.cin, roundUp(f.cin, 16)));
+		const TensorView &k2 = model.tensor("generator/conv_trans_2/kernel", {2, 2, 3, 32});
+		const TensorView &b2 = model.tensor("generator/conv_trans_2/bias", {3});
+		m_TailW2 = DeviceBuffer(k2.count * 4);
+		m_TailW2.upload(k2.data, k2.count * 4);
+		m_TailB2 = DeviceBuffer(16);
+		m_TailB2.upload(b2.data, 12);
+	}
+}
+
+void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
+    const std::string &wname, const void *in, const void *res, void *out, int H, int W,
+    bool relu, bool outF32, bool tower) {
+	auto it = m_Convs.find(wname);
+	if (it == m_Convs.end()) throw std::logic_error("missing conv weights " + wname);
+	const ConvWeights &cw = it->second;
+	ConvParams p{};
+	p.in = in;
+	p.wgt = cw.w.get();
+	p.bias = cw.bias.as<float>();
+	p.res = res;
+	p.out = out;
+	p.H = H;
+	p.W = W;
+	p.cin = cw.cinP;
+	p.cout = cw.cout;
+	p.taps = cw.taps;
+	p.relu = relu ? 1 : 0;
+	p.outF32 = outF32 ? 1 : 0;
+	const DType dt = m_DType;
+	Step s;
+	s.tag = tag;
+	s.flops = 2.0 * H * W * cw.taps * cw.cinReal * cw.cout;
+	if (tower) {
+		s.run = [dt, p](hipStream_t st) { launchConvTower(dt, p, st); };
+	} else {
+		s.run = [dt, p](hipStream_t st) { launchConv(dt, p, st); };
+	}
+	prog->push_back(std::move(s));
+}
+
+void Engine::buildProgram(int set) {
+	const ModelConfig &c = m_Config;
+	const DType dt = m_DType;
+	std::vector<Step> &prog = m_Program[set];
+	prog.clear();
+	const int H = c.frameHeight, W = c.frameWidth;
+	const int PH = c.paddedHeight(), PW = c.paddedWidth();
+	const int padTop = (PH - H) / 2, padLeft = (PW - W) / 2;  // models.py:783-787
+	const auto *frame = m_InStage.as<std::uint8_t>();
+	const std::ptrdiff_t fstride = static_cast<std::ptrdiff_t>(W) * 4;
+	const void *packedIn = m_Packed[set].get();
+	void *packedOut = m_Packed[set ^ 1].get();
+	const void *stateIn = m_State[set].get();
+	void *stateOut = m_State[set ^ 1].get();
+	const int nIn = c.numFlowInputs;
+	auto T = [&](const std::string &n) -> void * { return m_Tensors.at(n).buf.get(); };
+
+	prog.push_back({"pack", 0.0, [=](hipStream_t s) {
+		                launchPackFrames(dt, frame, fstride, packedIn, packedOut, H, W, PH, PW,
+		                    padTop, padLeft, nIn, s);
+	                }});
+	// ---- flow net ----
+	const void *cur = packedOut;
+	int h = PH, w = PW;
+	if (c.flowArch == 0) {
+		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+		for (int i = 0; i < 2 * nb; ++i) {
+			const std::string n = "flow/block_" + std::to_string(i + 1);
+			const int f = c.flowFilters[i];
+			addConvStep(&prog, "flow", n + "/conv_1", cur, nullptr, T(n + "/a_1"), h, w, true, false);
+			addConvStep(&prog, "flow", n + "/conv_2", T(n + "/a_1"), nullptr, T(n + "/a_2"), h, w,
+			    true, false);
+			const void *src = T(n + "/a_2");
+			void *dst = T(n + "/resample");
+			if (i < nb) {
+				prog.push_back({"flow", 0.0,
+				    [=](hipStream_t s) { launchMaxPool2(dt, src, dst, h, w, f, s); }});
+				h /= 2;
+				w /= 2;
+			} else {
+				prog.push_back({"flow", 0.0,
+				    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
+				h *= 2;
+				w *= 2;
+			}
+			cur = dst;
+		}
+		if (c.flowFilters.size() % 2) {
+			addConvStep(&prog, "flow", "flow/conv_1", cur, nullptr, T("flow/a_1"), h, w, true, false);
+			cur = T("flow/a_1");
+		}
+	} else {
+		addConvStep(&prog, "flow", "flow/conv_1", cur, nullptr, T("flow/x0"), h, w, true, false);
+		const char *xs[2] = {"flow/x0", "flow/x1"};
+		int a = 0;
+		for (int i = 0; i < c.flowResBlocks; ++i) {
+			const std::string n = "flow/block_" + std::to_string(i + 1);
+			addConvStep(&prog, "flow", n + "/conv_1", T(xs[a]), nullptr, T("flow/t"), h, w, true, false);
+			addConvStep(&prog, "flow", n + "/conv_2", T("flow/t"), T(xs[a]), T(xs[a ^ 1]), h, w, true,
+			    false);
+			a ^= 1;
+		}
+		cur = T(xs[a]);
+	}
+	addConvStep(&prog, "flow", "flow/conv_2", cur, nullptr, T("flow"), h, w, false, true);
+	// ---- warp + space-to-depth + concat ----
+	{
+		const float *flow = static_cast<const float *>(T("flow"));
+		void *genIn = T("gen_in");
+		prog.push_back({"warp", 0.0, [=](hipStream_t s) {
+			                launchWarpPack(dt, stateIn, flow, frame, fstride, genIn, H, W, PW, padTop,
+			                    padLeft, s);
+		                }});
+	}
+	// ---- generator ----
+	addConvStep(&prog, "gen_head", "generator/conv_1", T("gen_in"), nullptr, T("trunk_a"), H, W,
+	    true, false);
+	const char *xs[2] = {"trunk_a", "trunk_b"};
+	int a = 0;
+	for (int i = 0; i < c.genBlocks; ++i) {
+		const std::string n = "generator/block_" + std::to_string(i + 1);
+		addConvStep(&prog, "tower", n + "/conv_1", T(xs[a]), nullptr, T("trunk_t"), H, W, true,
+		    false, true);
+		addConvStep(&prog, "tower", n + "/conv_2", T("trunk_t"), T(xs[a]), T(xs[a ^ 1]), H, W, true,
+		    false, true);
+		a ^= 1;
+	}
+	m_TrunkOut = xs[a];
+	addConvStep(&prog, "tail", "generator/conv_trans_1", T(xs[a]), nullptr, T("tail_y"), H, W, true,
+	    false);
+	{
+		const void *y = T("tail_y");
+		const float *w2 = m_TailW2.as<float>();
+		const float *b2 = m_TailB2.as<float>();
+		auto *outU8 = m_OutStage.as<std::uint8_t>();
+		prog.push_back({"tail", 2.0 * (2 * H) * (2 * W) * 4 * 32 * 3, [=](hipStream_t s) {
+			                launchTail(dt, y, w2, b2, frame, fstride, stateOut, outU8, H, W, s);
+		                }});
+	}
+}
+
+Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride)
+    : m_Device(device) {
+	// Like TensorRTBackend (tensorrt_backend.cc:118), the engine is built on the
+	// CURRENT device; the caller (c_api.cpp) selects it for the call.
+	int current = -1;
+	JU_HIP(hipGetDevice(&current));
+	if (current != device) throw std::logic_error("Engine must be created with its device current");
+	ModelFile model(blob, size);
+	m_Config = model.config();
+	const ModelConfig &c = m_Config;
+	int dt = dtypeOverride >= 0 ? dtypeOverride : c.computeDtype;
+	if (dt != kF16 && dt != kBF16) throw std::invalid_argument("Unsupported compute dtype");
+	m_DType = static_cast<DType>(dt);
+	if (c.normalizeBrightness) {
+		throw std::invalid_argument(
+		    "Unsupported model: normalize_brightness is not implemented by this runtime yet");
+	}
+	if (c.genFilters % 32 != 0 || c.genFilters <= 0 || c.genBlocks < 0) {
+		throw std::invalid_argument("Unsupported model: gen_filters must be a multiple of 32");
+	}
+	const int H = c.frameHeight, W = c.frameWidth;
+	const int PH = c.paddedHeight(), PW = c.paddedWidth();
+	if (c.flowArch == 0) {
+		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+		if (nb < 1 || PH % (1 << nb) != 0 || PW % (1 << nb) != 0) {
+			throw std::invalid_argument(
+			    "Unsupported model: padded frame size must be divisible by 2^(flow depth)");
+		}
+		for (int f : c.flowFilters) {
+			if (f % 32 != 0 || f <= 0) {
+				throw std::invalid_argument("Unsupported model: flow filters must be multiples of 32");
+			}
+		}
+	} else if (c.flowResFilters % 32 != 0) {
+		throw std::invalid_argument("Unsupported model: flow filters must be multiples of 32");
+	}
+
+	buildWeights(model);
+
+	// ---- buffers (all zero-initialised) ----
+	const std::size_t lr = static_cast<std::size_t>(H) * W;
+	const std::size_t plr = static_cast<std::size_t>(PH) * PW;
+	m_InStage = DeviceBuffer(lr * 4);
+	m_OutStage = DeviceBuffer(lr * 16 * 4);
+	m_RawStage = DeviceBuffer(lr * 16 * 4);
+	for (int i = 0; i < 2; ++i) {
+		m_State[i] = DeviceBuffer(lr * 16 * 4 * 2);  // f16 [4H][4W][4]
+		m_Packed[i] = DeviceBuffer(plr * 16 * 2);     // [PH][PW][16]
+	}
+	if (c.flowArch == 0) {
+		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+		std::size_t px = plr;
+		for (int i = 0; i < 2 * nb; ++i) {
+			const std::string n = "flow/block_" + std::to_string(i + 1);
+			const std::size_t f = c.flowFilters[i];
+			addTensor(n + "/a_1", px * f);
+			addTensor(n + "/a_2", px * f);
+			px = i < nb ? px / 4 : px * 4;
+			addTensor(n + "/resample", px * f);
+		}
+		if (c.flowFilters.size() % 2) addTensor("flow/a_1", px * c.flowFilters.back());
+	} else {
+		addTensor("flow/x0", plr * c.flowResFilters);
+		addTensor("flow/x1", plr * c.flowResFilters);
+		addTensor("flow/t", plr * c.flowResFilters);
+	}
+	addTensor("flow", plr * 32, true);
+	addTensor("gen_in", lr * 64);
+	addTensor("trunk_a", lr * c.genFilters);
+	addTensor("trunk_b", lr * c.genFilters);
+	addTensor("trunk_t", lr * c.genFilters);
+	addTensor("tail_y", lr * 128);
+
+	buildProgram(0);
+	buildProgram(1);
+
+	// One eager pass per binding set: sets the kernels' dynamic-LDS attributes
+	// and surfaces launch errors before anything is captured.
+	for (int s = 0; s < 2; ++s) {
+		for (const Step &st : m_Program[s]) st.run(m_Stream);
+	}
+	m_Stream.synchronize();
+	reset();
+
+	const char *noGraph = std::getenv("JU_NO_GRAPH");
+	m_UseGraph = !(noGraph && noGraph[0] == '1');
+	if (m_UseGraph) {
+		for (int s = 0; s < 2; ++s) {
+			m_Graph[s] = GraphExec::capture(m_Stream, [&] {
+				for (const Step &st : m_Program[s]) st.run(m_Stream);
+			});
+		}
+		m_Stream.synchronize();
+	}
+	std::ostringstream ss;
+	ss << "engine ready: " << W << "x" << H << " -> " << 4 * W << "x" << 4 * H << ", "
+	   << (m_DType == kF16 ? "fp16" : "bf16") << ", " << m_Program[0].size()
+	   << " kernels/frame, graph=" << (m_UseGraph ? "on" : "off");
+	logMessage(LogLevel::Info, "Engine", ss.str());
+}
+
+Engine::~Engine() {
+	try {
+		DeviceGuard g(m_Device);
+		(void)hipStreamSynchronize(m_Stream);
+	} catch (...) {
+	}
+}
+
+void Engine::reset() {
+	DeviceGuard g(m_Device);
+	for (int i = 0; i < 2; ++i) {
+		m_State[i].zeroAsync(m_Stream);
+		m_Packed[i].zeroAsync(m_Stream);
+	}
+	m_Stream.synchronize();
+	m_Idx = 0;
+}
+
+FrameSize Engine::frameSize() const {
+	const auto w = static_cast<std::size_t>(m_Config.frameWidth);
+	const auto h = static_cast<std::size_t>(m_Config.frameHeight);
+	return {w, h, w * 4, h * 4};
+}
+
+void Engine::stageIn(const Frame &in) {
+	const FrameSize fs = frameSize();
+	if (in.ptr == nullptr || in.width != fs.inputWidth || in.height != fs.inputHeight) {
+		throw std::invalid_argument("processImage: input image must be exactly " +
+		                            std::to_string(fs.inputWidth) + "x" +
+		                            std::to_string(fs.inputHeight));
+	}
+	const std::size_t rowBytes = fs.inputWidth * 4;
+	const std::size_t rows = fs.inputHeight;
+	const auto plain = static_cast<std::ptrdiff_t>(rowBytes);
+	auto *dst = m_InStage.as<std::uint8_t>();
+	auto *src = static_cast<std::uint8_t *>(in.ptr);
+	if (in.stride > -plain && in.stride < plain) {
+		throw std::invalid_argument("processImage: |stride| smaller than a row");
+	}
+	switch (in.location) {
+	case Location::Host:
+		if (in.stride == plain) {
+			JU_HIP(hipMemcpyAsync(dst, src, rowBytes * rows, hipMemcpyHostToDevice, m_Stream));
+		} else if (in.stride > 0) {
+			JU_HIP(hipMemcpy2DAsync(dst, rowBytes, src, static_cast<std::size_t>(in.stride),
+			    rowBytes, rows, hipMemcpyHostToDevice, m_Stream));
+		} else {
+			// bottom-up frame (AviSynth RGB32, avisynth_plugin/src/main.cc:125-142): upload
+			// the rows in memory order, then flip on the device.
+			auto *raw = m_RawStage.as<std::uint8_t>();
+			const std::uint8_t *lowest = src + static_cast<std::ptrdiff_t>(rows - 1) * in.stride;
+			JU_HIP(hipMemcpy2DAsync(raw, rowBytes, lowest, static_cast<std::size_t>(-in.stride),
+			    rowBytes, rows, hipMemcpyHostToDevice, m_Stream));
+			launchCopyRows(raw + (rows - 1) * rowBytes, -plain, dst, plain, rowBytes, rows, m_Stream);
+		}
+		break;
+	case Location::Device:
+		if (in.stride == plain) {
+			JU_HIP(hipMemcpyAsync(dst, src, rowBytes * rows, hipMemcpyDeviceToDevice, m_Stream));
+		} else {
+			launchCopyRows(src, in.stride, dst, plain, rowBytes, rows, m_Stream);
+		}
+		break;
+	default:
+		throw std::invalid_argument(
+		    "processImage: GRAPHICS_RESOURCE images are not supported by this runtime");
+	}
+}
+
+void Engine::stageOut(const Frame &out) {
+	const FrameSize fs = frameSize();
+	if (out.ptr == nullptr || out.width != fs.outputWidth || out.height != fs.outputHeight) {
+		throw std::invalid_argument("processImage: output image must be exactly " +
+		                            std::to_string(fs.outputWidth) + "x" +
+		                            std::to_string(fs.outputHeight));
+	}
+	const std::size_t rowBytes = fs.outputWidth * 4;
+	const std::size_t rows = fs.outputHeight;
+	const auto plain = static_cast<std::ptrdiff_t>(rowBytes);
+	const auto *src = m_OutStage.as<std::uint8_t>();
+	auto *dst = static_cast<std::uint8_t *>(out.ptr);
+	if (out.stride > -plain && out.stride < plain) {
+		throw std::invalid_argument("processImage: |stride| smaller than a row");
+	}
+	switch (out.location) {
+	case Location::Host:
+		if (out.stride == plain) {
+			JU_HIP(hipMemcpyAsync(dst, src, rowBytes * rows, hipMemcpyDeviceToHost, m_Stream));
+		} else if (out.stride > 0) {
+			JU_HIP(hipMemcpy2DAsync(dst, static_cast<std::size_t>(out.stride), src, rowBytes,
+			    rowBytes, rows, hipMemcpyDeviceToHost, m_Stream));
+		} else {
+			auto *raw = m_RawStage.as<std::uint8_t>();
+			launchCopyRows(src, plain, raw + (rows - 1) * rowBytes, -plain, rowBytes, rows, m_Stream);
+			std::uint8_t *lowest = dst + static_cast<std::ptrdiff_t>(rows - 1) * out.stride;
+			JU_HIP(hipMemcpy2DAsync(lowest, static_cast<std::size_t>(-out.stride), raw, rowBytes,
+			    rowBytes, rows, hipMemcpyDeviceToHost, m_Stream));
+		}
+		break;
+	case Location::Device:
+		if (out.stride == plain) {
+			JU_HIP(hipMemcpyAsync(dst, src, rowBytes * rows, hipMemcpyDeviceToDevice, m_Stream));
+		} else {
+			launchCopyRows(src, plain, dst, out.stride, rowBytes, rows, m_Stream);
+		}
+		break;
+	default:
+		throw std::invalid_argument(
+		    "processImage: GRAPHICS_RESOURCE images are not supported by this runtime");
+	}
+}
+
+void Engine::runProgram() {
+	if (m_UseGraph && m_Graph[m_Idx].valid()) {
+		m_Graph[m_Idx].launch(m_Stream);
+	} else {
+		for (const Step &st : m_Program[m_Idx]) st.run(m_Stream);
+	}
+}
+
+void Engine::enqueue(const Frame &in, const Frame &out) {
+	DeviceGuard g(m_Device);
+	stageIn(in);
+	runProgram();
+	stageOut(out);
+	m_Idx ^= 1;  // state ping-pong (tensorrt_backend.cc:277)
+}
+
+void Engine::process(const Frame &in, const Frame &out) {
+	DeviceGuard g(m_Device);
+	stageIn(in);
+	runProgram();
+	stageOut(out);
+	m_Stream.synchronize();
+	m_Idx ^= 1;
+}
+
+void Engine::synchronize() {
+	DeviceGuard g(m_Device);
+	m_Stream.synchronize();
+}
+
+std::vector<std::string> Engine::tensorNames() const {
+	std::vector<std::string> names = {"state", "flow_in", "trunk"};
+	for (const auto &kv : m_Tensors) names.push_back(kv.first);
+	return names;
+}
+
+std::size_t Engine::readTensor(const std::string &name, float *dst, std::size_t capacity) {
+	DeviceGuard g(m_Device);
+	const void *src = nullptr;
+	std::size_t count = 0;
+	bool f32 = false;
+	DType dt = m_DType;
+	const std::size_t lr = static_cast<std::size_t>(m_Config.frameHeight) * m_Config.frameWidth;
+	if (name == "state") {  // the state the NEXT frame will read = last output_raw
+		src = m_State[m_Idx].get();
+		count = lr * 16 * 4;
+		dt = kF16;
+	} else if (name == "flow_in") {
+		src = m_Packed[m_Idx].get();
+		count = static_cast<std::size_t>(m_Config.paddedHeight()) * m_Config.paddedWidth() * 16;
+	} else {
+		const std::string key = name == "trunk" ? m_TrunkOut : name;
+		auto it = m_Tensors.find(key);
+		if (it == m_Tensors.end()) throw std::invalid_argument("unknown tensor " + name);
+		src = it->second.buf.get();
+		count = it->second.count;
+		f32 = it->second.isF32;
+	}
+	if (dst == nullptr) return count;
+	if (capacity < count) throw std::invalid_argument("readTensor: buffer too small");
+	m_Stream.synchronize();
+	if (f32) {
+		JU_HIP(hipMemcpy(dst, src, count * 4, hipMemcpyDeviceToHost));
+	} else {
+		DeviceBuffer tmp(count * 4);
+		launchToFloat(dt, src, tmp.as<float>(), count, m_Stream);
+		m_Stream.synchronize();
+		JU_HIP(hipMemcpy(dst, tmp.get(), count * 4, hipMemcpyDeviceToHost));
+	}
+	return count;
+}
+
+double Engine::flopsOf(const std::string &tag) const {
+	double f = 0.0;
+	for (const Step &s : m_Program[0]) {
+		if (tag.empty() || s.tag == tag) f += s.flops;
+	}
+	return f;
+}
+
+double Engine::timeSteps(const std::string &tag, int iters, int *launches) {
+	DeviceGuard g(m_Device);
+	std::vector<const Step *> steps;
+	for (const Step &s : m_Program[m_Idx]) {
+		if (tag.empty() || s.tag == tag) steps.push_back(&s);
+	}
+	if (launches) *launches = static_cast<int>(steps.size());
+	if (steps.empty() || iters <= 0) return 0.0;
+	for (const Step *s : steps) s->run(m_Stream);  // warm
+	Event t0, t1;
+	t0.record(m_Stream);
+	for (int i = 0; i < iters; ++i) {
+		for (const Step *s : steps) s->run(m_Stream);
+	}
+	t1.record(m_Stream);
+	t1.synchronize();
+	return static_cast<double>(Event::elapsedMs(t0, t1)) / (static_cast<double>(iters) * steps.size());
+}
+
+}  // namespace ju

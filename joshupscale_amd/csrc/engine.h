@@ -1,0 +1,127 @@
+// The per-frame recurrent super-resolution engine (MI355X / gfx950).
+//
+// Replaces the reference's TensorRTBackend (reference
+// core/include/JoshUpscale/core/tensorrt_backend.h:20-53,
+// core/src/tensorrt_backend.cc:117-288): same contract — construct from model
+// bytes on the current device, `process(in, out)` = stage-in, one execution of
+// the inference graph against binding set `idx`, stage-out, synchronise, flip
+// `idx` — but the graph is this engine's own schedule of hand-written HIP
+// kernels (kernels.hip) captured into two hipGraphs instead of a TensorRT
+// execution context.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "hip_util.h"
+#include "kernels.h"
+#include "model.h"
+
+namespace ju {
+
+// Frame descriptor of the boundary (reference core/public/JoshUpscale/core.h:30-38):
+// 4 bytes per pixel B,G,R,X; `stride` in bytes, may be negative (bottom-up);
+// `ptr` addresses the first logical row.
+enum class Location : std::uint8_t { Host = 0, Device = 1, GraphicsResource = 2 };
+
+struct Frame {
+	void *ptr;
+	Location location;
+	std::ptrdiff_t stride;
+	std::size_t width;
+	std::size_t height;
+};
+
+struct FrameSize {
+	std::size_t inputWidth, inputHeight, outputWidth, outputHeight;
+};
+
+class Engine {
+public:
+	// dtypeOverride: -1 = the container's hint, else kF16 / kBF16.
+	Engine(int device, const void *blob, std::size_t size, int dtypeOverride);
+	~Engine();
+	Engine(const Engine &) = delete;
+	Engine &operator=(const Engine &) = delete;
+
+	// Synchronous, like Runtime::processImage (tensorrt_backend.cc:270-278).
+	void process(const Frame &in, const Frame &out);
+	// Asynchronous variant for device-resident frames: enqueue only.
+	void enqueue(const Frame &in, const Frame &out);
+	void synchronize();
+	// Zero the recurrent state (what destroying and recreating the runtime does
+	// in the reference: obs_plugin/src/filter.cc:146-151).
+	void reset();
+
+	FrameSize frameSize() const;
+	int device() const { return m_Device; }
+	DType dtype() const { return m_DType; }
+	const ModelConfig &config() const { return m_Config; }
+	void setUseGraph(bool on) { m_UseGraph = on; }
+
+	// ---- introspection (tests, bench) ----
+	// Copies a named internal tensor to host as f32; returns its element count
+	// (call with dst == nullptr to query).  Names: see Engine::tensorNames().
+	std::size_t readTensor(const std::string &name, float *dst, std::size_t capacity);
+	std::vector<std::string> tensorNames() const;
+	// Average device time (ms) of one launch of the steps carrying `tag`, measured
+	// with HIP events on the engine's own stream over `iters` repetitions of that
+	// group; *launches receives the number of kernel launches per repetition.
+	double timeSteps(const std::string &tag, int iters, int *launches);
+	// FLOPs (2*MAC) of the steps carrying `tag` (one repetition).
+	double flopsOf(const std::string &tag) const;
+
+private:
+	struct Tensor {
+		DeviceBuffer buf;
+		std::size_t count = 0;
+		bool isF32 = false;
+		bool isState = false;  // f16 regardless of the compute dtype
+	};
+	struct Step {
+		std::string tag;
+		double flops;
+		std::function<void(hipStream_t)> run;
+	};
+	struct ConvWeights {
+		DeviceBuffer w;
+		DeviceBuffer bias;
+		int cinP = 0, cout = 0, taps = 9, cinReal = 0;
+	};
+
+	Tensor &addTensor(const std::string &name, std::size_t count, bool f32 = false,
+	    bool state = false);
+	ConvWeights &addConv(const std::string &name, const FoldedConv &f,
+	    const std::vector<int> &cinMap);
+	void addConvStep(std::vector<Step> *prog, const std::string &tag, const std::string &wname,
+	    const void *in, const void *res, void *out, int H, int W, bool relu, bool outF32,
+	    bool tower = false);
+	void buildWeights(const ModelFile &model);
+	void buildProgram(int set);
+	void stageIn(const Frame &in);
+	void stageOut(const Frame &out);
+	void runProgram();
+
+	int m_Device;
+	ModelConfig m_Config;
+	DType m_DType;
+	Stream m_Stream;
+	bool m_UseGraph = true;
+	int m_Idx = 0;
+	std::string m_TrunkOut = "trunk_a";
+
+	std::map<std::string, Tensor> m_Tensors;
+	std::map<std::string, ConvWeights> m_Convs;
+	DeviceBuffer m_TailW2, m_TailB2;
+	DeviceBuffer m_InStage, m_OutStage, m_RawStage;
+	DeviceBuffer m_State[2], m_Packed[2];
+	std::vector<Step> m_Program[2];
+	GraphExec m_Graph[2];
+};
+
+}  // namespace ju

@@ -1,0 +1,92 @@
+// Host-side launch interface of the gfx950 kernels (kernels.hip).
+//
+// Every launcher enqueues on the given stream and returns immediately; none of
+// them allocates, synchronises or touches the host heap, so the whole per-frame
+// sequence can be captured into a hipGraph (engine.cpp), mirroring the
+// reference's one captured graph per binding set
+// (reference core/src/tensorrt_backend.cc:257-263).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ju {
+
+enum DType : int { kF16 = 0, kBF16 = 1 };
+
+inline std::size_t dtypeSize(DType) { return 2; }
+
+// ---- implicit-GEMM convolution on MFMA -----------------------------------
+// in   : NHWC [H][W][cin]   16-bit, cin a multiple of 16
+// wgt  : kernel-ready weights from packConvWeights() (model.cpp)
+// bias : f32 [cout] (BN-folded bias or the layer's own bias)
+// res  : optional NHWC [H][W][cout] 16-bit tensor added before the activation
+// out  : NHWC [H][W][cout], 16-bit or f32 (outF32)
+struct ConvParams {
+	const void *in;
+	const void *wgt;
+	const float *bias;
+	const void *res;
+	void *out;
+	int H, W;
+	int cin, cout;
+	int taps;    // 9 (3x3 "same") or 1 (1x1)
+	int relu;    // apply max(x, 0)
+	int outF32;  // store f32 instead of the 16-bit type
+};
+
+// Channel chunk / cout-block choice shared by the launcher and the packer.
+inline int convCK(int cin) { return cin % 64 == 0 ? 64 : (cin % 32 == 0 ? 32 : 16); }
+inline int convNB(int cout) { return cout % 64 == 0 ? 2 : 1; }
+
+void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
+
+// Specialised 64->64 3x3 kernel of the generator tower (falls back to
+// launchConv when the shape does not match).
+void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream);
+
+// ---- flow-net helpers -------------------------------------------------------
+// cur frame (u8 BGRX, signed row stride) + previous packed history ->
+// packed [PH][PW][16]: ch 0-2 current frame (x/255-0.5, zero in the pad border),
+// ch 3-11 = previous ch 0-8, ch 12-15 zero.
+void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
+    const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
+    int padLeft, int numInputs, hipStream_t stream);
+
+void launchMaxPool2(DType dt, const void *in, void *out, int H, int W, int C,
+    hipStream_t stream);  // in [H][W][C] -> out [H/2][W/2][C]
+
+void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C,
+    hipStream_t stream);  // TF1 asymmetric bilinear, in [H][W][C] -> out [2H][2W][C]
+
+// ---- warp + space-to-depth + concat ----------------------------------------
+// state : previous HR output, f16 [4H][4W][4] (B,G,R,0)
+// flow  : f32 [PH][PW][32], channel (i*4+j)*2 + {dy,dx} (depth-to-space is free)
+// frame : current LR frame, u8 BGRX
+// out   : generator input NHWC [H][W][64] in the packed channel order
+//         ch = i*16 + j*3 + c for the warped HR pixel (4h+i, 4w+j, c),
+//         ch 12,13,14 = current LR frame B,G,R, other spare slots zero.
+void launchWarpPack(DType dt, const void *state, const float *flow,
+    const std::uint8_t *frame, std::ptrdiff_t frameStride, void *out, int H, int W, int PW,
+    int padTop, int padLeft, hipStream_t stream);
+
+// ---- generator tail ---------------------------------------------------------
+// y     : [H][W][128] 16-bit = relu(BN(convT1)) with channel (a*2+b)*32 + o
+// w2    : f32 [2][2][3][32] (convT2 kernel, keras layout), b2 f32 [3]
+// frame : current LR frame u8 BGRX (bilinear x4 skip)
+// stateOut : f16 [4H][4W][4]; outU8 : BGRX [4H][4W][4], X = 0
+void launchTail(DType dt, const void *y, const float *w2, const float *b2,
+    const std::uint8_t *frame, std::ptrdiff_t frameStride, void *stateOut,
+    std::uint8_t *outU8, int H, int W, hipStream_t stream);
+
+// ---- staging ----------------------------------------------------------------
+// Row-wise device copy with signed strides (bottom-up frames).
+void launchCopyRows(const std::uint8_t *src, std::ptrdiff_t srcStride, std::uint8_t *dst,
+    std::ptrdiff_t dstStride, std::size_t rowBytes, std::size_t rows, hipStream_t stream);
+
+// 16-bit tensor -> f32 (debug read-back).
+void launchToFloat(DType dt, const void *in, float *out, std::size_t n, hipStream_t stream);
+
+}  // namespace ju

@@ -1,0 +1,658 @@
+// gfx950 (CDNA4, MI355X) kernels of the per-frame recurrent super-resolution
+// step.  What each one computes follows the reference's Keras graph
+// (scripts/training/models.py:680-829 and the layers it uses); how it is
+// computed is MI355X-first:
+//
+//  * conv_mfma_kernel   implicit-GEMM 3x3 / 1x1 convolution on
+//                       v_mfma_f32_32x32x16_{f16,bf16}: weights are the MFMA A
+//                       operand (M = cout), activations the B operand
+//                       (N = 32 consecutive pixels of one image row), so each
+//                       lane's accumulator registers hold 4 consecutive output
+//                       channels of ONE pixel and the NHWC store is 8 B/lane.
+//                       Input tile (+halo) and the weight chunk are staged in
+//                       LDS; the input image is XOR-swizzled per 16-B chunk so
+//                       the ds_read_b128 fragment reads are bank-conflict free.
+//  * pack_frames        u8 BGRX frame + frame history -> 16-channel flow input
+//  * maxpool2/upsample2 flow auto-encoder resampling (TF1 asymmetric bilinear)
+//  * warp_pack          dense bilinear warp of the previous HR output fused with
+//                       space-to-depth(4), the concat with the LR frame and the
+//                       16-bit pack (reference models.py:799-801, 523-530)
+//  * tail               ConvT(2x2,s2,32->3)+bias, tanh, bilinear x4 skip, clip,
+//                       HR state write and truncating BGRX u8 pack in one pass
+//                       (reference models.py:573-593, keras_layers.py:211-230,
+//                       core/src/cuda_convert.cc.cu:95-108)
+//
+// Wavefront = 64 lanes everywhere; no CUDA-isms, no portability layer.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "kernels.h"
+
+namespace ju {
+
+namespace {
+
+using f16 = _Float16;
+using bf16 = __bf16;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+using Vec8 = T __attribute__((ext_vector_type(8)));
+template <typename T>
+using Vec4 = T __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma32(Vec8<f16> a, Vec8<f16> b, f32x16 c) {
+	return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(Vec8<bf16> a, Vec8<bf16> b, f32x16 c) {
+	return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+inline void hipCheckLaunch(const char *what) {
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		throw std::runtime_error(std::string("HIP launch failed (") + what +
+		                         "): " + hipGetErrorString(e));
+	}
+}
+
+// ---------------------------------------------------------------------------
+// implicit-GEMM convolution
+// ---------------------------------------------------------------------------
+constexpr int kTW = 32;       // tile width in pixels = MFMA N
+constexpr int kConvThreads = 256;
+
+// XOR swizzle of the 16-byte chunk index inside a pixel's CK channels.  P =
+// chunks per pixel.  16 lanes of one ds_read_b128 group read the same logical
+// chunk of 16 pixels whose LDS pixel indices are distinct mod 16; after the
+// swizzle they fall on 16 distinct 16-byte slots of the 256-byte bank row.
+template <int P>
+__device__ __forceinline__ int swz(int q) {
+	if constexpr (P == 8) return (q >> 1) & 7;
+	else if constexpr (P == 4) return (q >> 2) & 3;
+	else return (q >> 3) & 1;
+}
+
+template <typename T, int TAPS, int CK, int NB, int RW>
+__global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
+	constexpr int HALO = (TAPS == 9) ? 1 : 0;
+	constexpr int TH = 4 * RW;            // tile rows: 4 waves x RW rows each
+	constexpr int IW = kTW + 2 * HALO;    // staged tile incl. halo
+	constexpr int IH = TH + 2 * HALO;
+	constexpr int P = CK / 8;             // 16-B chunks per pixel
+	constexpr int KS = CK / 16;           // MFMA k-steps per tap
+	constexpr int COG = 32 * NB;          // couts per workgroup
+	constexpr int W_BYTES = TAPS * CK * COG * 2;
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	unsigned char *smW = smem;
+	unsigned char *smI = smem + W_BYTES;
+
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6;
+	const int lane = tid & 63;
+	const int px = lane & 31;
+	const int hh = lane >> 5;
+	const int tx0 = blockIdx.x * kTW;
+	const int ty0 = blockIdx.y * TH;
+	const int cog = blockIdx.z;
+	const int nCC = p.cin / CK;
+	const T *__restrict__ in = static_cast<const T *>(p.in);
+	const T *__restrict__ wgt = static_cast<const T *>(p.wgt);
+
+	// accumulators start at the (BN-folded) bias: rows of D are output channels
+	f32x16 acc[NB][RW];
+#pragma unroll
+	for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			const f32x4 b = *reinterpret_cast<const f32x4 *>(
+			    p.bias + cog * COG + nb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+			for (int rw = 0; rw < RW; ++rw) {
+				acc[nb][rw][4 * g + 0] = b[0];
+				acc[nb][rw][4 * g + 1] = b[1];
+				acc[nb][rw][4 * g + 2] = b[2];
+				acc[nb][rw][4 * g + 3] = b[3];
+			}
+		}
+	}
+
+	for (int cc = 0; cc < nCC; ++cc) {
+		if (cc > 0) __syncthreads();
+		// ---- stage the weight chunk (already in fragment order) ----
+		{
+			const uint4 *src = reinterpret_cast<const uint4 *>(
+			    wgt + (size_t)(cog * nCC + cc) * (TAPS * CK * COG));
+			uint4 *dst = reinterpret_cast<uint4 *>(smW);
+#pragma unroll 4
+			for (int i = tid; i < W_BYTES / 16; i += kConvThreads) dst[i] = src[i];
+		}
+		// ---- stage the input tile (+halo), zero outside the image ----
+		for (int i = tid; i < IH * IW * P; i += kConvThreads) {
+			const int q = i / P;
+			const int c = i % P;
+			const int r = q / IW;
+			const int x = q - r * IW;
+			const int gy = ty0 - HALO + r;
+			const int gx = tx0 - HALO + x;
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+				v = *reinterpret_cast<const uint4 *>(
+				    in + ((size_t)gy * p.W + gx) * p.cin + cc * CK + c * 8);
+			}
+			*reinterpret_cast<uint4 *>(smI + q * (CK * 2) + ((c ^ swz<P>(q)) << 4)) = v;
+		}
+		__syncthreads();
+		// ---- MFMA over taps x k-steps ----
+#pragma unroll
+		for (int tap = 0; tap < TAPS; ++tap) {
+			const int dy = (TAPS == 9) ? tap / 3 : 0;
+			const int dx = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+			for (int ks = 0; ks < KS; ++ks) {
+				Vec8<T> a[NB];
+#pragma unroll
+				for (int nb = 0; nb < NB; ++nb) {
+					a[nb] = *reinterpret_cast<const Vec8<T> *>(
+					    smW + ((((tap * KS + ks) * 2 + hh) * COG + nb * 32 + px) << 4));
+				}
+#pragma unroll
+				for (int rw = 0; rw < RW; ++rw) {
+					const int q = (wave * RW + rw + dy) * IW + px + dx;
+					const int c = ks * 2 + hh;
+					const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(
+					    smI + q * (CK * 2) + ((c ^ swz<P>(q)) << 4));
+#pragma unroll
+					for (int nb = 0; nb < NB; ++nb) acc[nb][rw] = mfma32(a[nb], b, acc[nb][rw]);
+				}
+			}
+		}
+	}
+
+	// ---- epilogue: residual, activation, NHWC store (4 channels per lane) ----
+	const int gx = tx0 + px;
+#pragma unroll
+	for (int rw = 0; rw < RW; ++rw) {
+		const int gy = ty0 + wave * RW + rw;
+		if (gy >= p.H || gx >= p.W) continue;
+		const size_t pixOff = ((size_t)gy * p.W + gx) * p.cout + cog * COG;
+#pragma unroll
+		for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const size_t off = pixOff + nb * 32 + 8 * g + 4 * hh;
+				float v[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) v[i] = acc[nb][rw][4 * g + i];
+				if (p.res != nullptr) {
+					const Vec4<T> r =
+					    *reinterpret_cast<const Vec4<T> *>(static_cast<const T *>(p.res) + off);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(r[i]);
+				}
+				if (p.relu) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+				}
+				if (p.outF32) {
+					f32x4 o = {v[0], v[1], v[2], v[3]};
+					*reinterpret_cast<f32x4 *>(static_cast<float *>(p.out) + off) = o;
+				} else {
+					Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
+					    static_cast<T>(v[3])};
+					*reinterpret_cast<Vec4<T> *>(static_cast<T *>(p.out) + off) = o;
+				}
+			}
+		}
+	}
+}
+
+template <int TAPS, int CK, int NB, int RW>
+constexpr int convLdsBytes() {
+	constexpr int HALO = (TAPS == 9) ? 1 : 0;
+	return TAPS * CK * 32 * NB * 2 + (4 * RW + 2 * HALO) * (kTW + 2 * HALO) * CK * 2;
+}
+
+template <typename T, int TAPS, int CK, int NB, int RW>
+void launchConvInst(const ConvParams &p, hipStream_t stream) {
+	constexpr int lds = convLdsBytes<TAPS, CK, NB, RW>();
+	auto kern = conv_mfma_kernel<T, TAPS, CK, NB, RW>;
+	static bool attrSet = false;  // first launch happens before any graph capture
+	if (!attrSet) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+		    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		if (e != hipSuccess) {
+			throw std::runtime_error(
+			    std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(e));
+		}
+		attrSet = true;
+	}
+	dim3 grid((p.W + kTW - 1) / kTW, (p.H + 4 * RW - 1) / (4 * RW), p.cout / (32 * NB));
+	hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, p);
+	hipCheckLaunch("conv_mfma");
+}
+
+template <typename T>
+void launchConvT(const ConvParams &p, hipStream_t stream) {
+	const int ck = convCK(p.cin);
+	const int nb = convNB(p.cout);
+	if (p.cin % 16 != 0 || p.cout % 32 != 0) {
+		throw std::invalid_argument("conv: cin must be a multiple of 16, cout of 32");
+	}
+#define JU_CONV_CASE(TAPS_, CK_, NB_)                                          \
+	if (p.taps == TAPS_ && ck == CK_ && nb == NB_) {                           \
+		launchConvInst<T, TAPS_, CK_, NB_, 2>(p, stream);                      \
+		return;                                                                \
+	}
+	JU_CONV_CASE(9, 64, 2)
+	JU_CONV_CASE(9, 64, 1)
+	JU_CONV_CASE(9, 32, 2)
+	JU_CONV_CASE(9, 32, 1)
+	JU_CONV_CASE(9, 16, 2)
+	JU_CONV_CASE(9, 16, 1)
+	JU_CONV_CASE(1, 64, 2)
+	JU_CONV_CASE(1, 64, 1)
+	JU_CONV_CASE(1, 32, 2)
+	JU_CONV_CASE(1, 32, 1)
+#undef JU_CONV_CASE
+	throw std::invalid_argument("conv: unsupported shape");
+}
+
+// ---------------------------------------------------------------------------
+// flow input packing
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float preprocessU8(unsigned v) {
+	// PreprocessLayer: x / 255 - 0.5 (reference keras_layers.py:208)
+	return static_cast<float>(v) / 255.0f - 0.5f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_frames_kernel(const std::uint8_t *__restrict__ frame,
+    std::ptrdiff_t frameStride, const T *__restrict__ prev, T *__restrict__ cur, int H, int W,
+    int PH, int PW, int padTop, int padLeft, int numInputs) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= PH * PW) return;
+	const int py = idx / PW;
+	const int pxx = idx - py * PW;
+	const int y = py - padTop;
+	const int x = pxx - padLeft;
+	float c0 = 0.f, c1 = 0.f, c2 = 0.f;  // ZeroPadding2D after preprocess: 0.0 in the border
+	if (y >= 0 && y < H && x >= 0 && x < W) {
+		const unsigned v = *reinterpret_cast<const unsigned *>(frame + y * frameStride + x * 4);
+		c0 = preprocessU8(v & 0xff);
+		c1 = preprocessU8((v >> 8) & 0xff);
+		c2 = preprocessU8((v >> 16) & 0xff);
+	}
+	const Vec8<T> p0 = *reinterpret_cast<const Vec8<T> *>(prev + (size_t)idx * 16);
+	const Vec8<T> p1 = *reinterpret_cast<const Vec8<T> *>(prev + (size_t)idx * 16 + 8);
+	T pv[16];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		pv[i] = p0[i];
+		pv[8 + i] = p1[i];
+	}
+	const int nch = 3 * numInputs;
+	T o[16];
+	o[0] = static_cast<T>(c0);
+	o[1] = static_cast<T>(c1);
+	o[2] = static_cast<T>(c2);
+#pragma unroll
+	for (int k = 3; k < 16; ++k) o[k] = (k < nch) ? pv[k - 3] : static_cast<T>(0.f);
+	Vec8<T> o0, o1;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		o0[i] = o[i];
+		o1[i] = o[8 + i];
+	}
+	*reinterpret_cast<Vec8<T> *>(cur + (size_t)idx * 16) = o0;
+	*reinterpret_cast<Vec8<T> *>(cur + (size_t)idx * 16 + 8) = o1;
+}
+
+// ---------------------------------------------------------------------------
+// 2x2 max-pool and TF1 bilinear x2 (8 channels = 16 B per thread)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_kernel(
+    const T *__restrict__ in, T *__restrict__ out, int H, int W, int C) {
+	const int OH = H / 2, OW = W / 2, CC = C / 8;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= OH * OW * CC) return;
+	const int c = idx % CC;
+	const int pix = idx / CC;
+	const int ox = pix % OW;
+	const int oy = pix / OW;
+	const T *base = in + ((size_t)(2 * oy) * W + 2 * ox) * C + c * 8;
+	const Vec8<T> a = *reinterpret_cast<const Vec8<T> *>(base);
+	const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(base + C);
+	const Vec8<T> d = *reinterpret_cast<const Vec8<T> *>(base + (size_t)W * C);
+	const Vec8<T> e = *reinterpret_cast<const Vec8<T> *>(base + (size_t)W * C + C);
+	Vec8<T> o;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const float m = fmaxf(fmaxf(static_cast<float>(a[i]), static_cast<float>(b[i])),
+		    fmaxf(static_cast<float>(d[i]), static_cast<float>(e[i])));
+		o[i] = static_cast<T>(m);
+	}
+	*reinterpret_cast<Vec8<T> *>(out + (size_t)pix * C + c * 8) = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_kernel(
+    const T *__restrict__ in, T *__restrict__ out, int H, int W, int C) {
+	// tf.compat.v1.image.resize_bilinear(align_corners=False,
+	// half_pixel_centers=False): src = dst / 2 (reference keras_layers.py:46-52)
+	const int OH = H * 2, OW = W * 2, CC = C / 8;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= OH * OW * CC) return;
+	const int c = idx % CC;
+	const int pix = idx / CC;
+	const int ox = pix % OW;
+	const int oy = pix / OW;
+	const int y0 = oy >> 1, x0 = ox >> 1;
+	const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+	const float fy = (oy & 1) * 0.5f, fx = (ox & 1) * 0.5f;
+	const Vec8<T> tl = *reinterpret_cast<const Vec8<T> *>(in + ((size_t)y0 * W + x0) * C + c * 8);
+	const Vec8<T> tr = *reinterpret_cast<const Vec8<T> *>(in + ((size_t)y0 * W + x1) * C + c * 8);
+	const Vec8<T> bl = *reinterpret_cast<const Vec8<T> *>(in + ((size_t)y1 * W + x0) * C + c * 8);
+	const Vec8<T> br = *reinterpret_cast<const Vec8<T> *>(in + ((size_t)y1 * W + x1) * C + c * 8);
+	Vec8<T> o;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const float a = static_cast<float>(tl[i]), b = static_cast<float>(tr[i]);
+		const float d = static_cast<float>(bl[i]), e = static_cast<float>(br[i]);
+		const float top = a + (b - a) * fx;
+		const float bot = d + (e - d) * fx;
+		o[i] = static_cast<T>(top + (bot - top) * fy);
+	}
+	*reinterpret_cast<Vec8<T> *>(out + (size_t)pix * C + c * 8) = o;
+}
+
+// ---------------------------------------------------------------------------
+// dense warp + space-to-depth + concat + pack
+// ---------------------------------------------------------------------------
+// One thread per (LR pixel, HR row i of its 4x4 block): 4 warped HR pixels x 3
+// channels plus 4 spare slots = one 32-byte quarter of the pixel's 128-byte
+// generator-input record.  Four consecutive lanes fill one record, a wavefront
+// writes 2 KiB contiguously.
+template <typename T>
+__global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ state,
+    const float *__restrict__ flow, const std::uint8_t *__restrict__ frame,
+    std::ptrdiff_t frameStride, T *__restrict__ out, int H, int W, int PW, int padTop,
+    int padLeft) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= H * W * 4) return;
+	const int i = idx & 3;
+	const int pix = idx >> 2;
+	const int w = pix % W;
+	const int h = pix / W;
+	const int HH = H * 4, WW = W * 4;
+	// depth-to-space(4) of the flow head is just this channel addressing:
+	// flow[4h+i, 4w+j, k] = head[h, w, (i*4+j)*2 + k]  (keras_layers.py:175)
+	const float *fp = flow + ((size_t)(h + padTop) * PW + (w + padLeft)) * 32 + i * 8;
+	const f32x4 f0 = *reinterpret_cast<const f32x4 *>(fp);
+	const f32x4 f1 = *reinterpret_cast<const f32x4 *>(fp + 4);
+	const float fl[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+	T o[16];
+	const int Y = 4 * h + i;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int X = 4 * w + j;
+		// tfa/dense_image_warp.py:232-245, 116-171
+		const float qy = static_cast<float>(Y) - fl[2 * j];
+		const float qx = static_cast<float>(X) - fl[2 * j + 1];
+		const float fy = fminf(fmaxf(0.0f, floorf(qy)), static_cast<float>(HH - 2));
+		const float fx = fminf(fmaxf(0.0f, floorf(qx)), static_cast<float>(WW - 2));
+		const float ay = fminf(fmaxf(0.0f, qy - fy), 1.0f);
+		const float ax = fminf(fmaxf(0.0f, qx - fx), 1.0f);
+		const int y0 = static_cast<int>(fy), x0 = static_cast<int>(fx);
+		const f16 *s0 = state + ((size_t)y0 * WW + x0) * 4;
+		const f16 *s1 = s0 + (size_t)WW * 4;
+		const Vec4<f16> tl = *reinterpret_cast<const Vec4<f16> *>(s0);
+		const Vec4<f16> tr = *reinterpret_cast<const Vec4<f16> *>(s0 + 4);
+		const Vec4<f16> bl = *reinterpret_cast<const Vec4<f16> *>(s1);
+		const Vec4<f16> br = *reinterpret_cast<const Vec4<f16> *>(s1 + 4);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const float a = static_cast<float>(tl[c]), b = static_cast<float>(tr[c]);
+			const float d = static_cast<float>(bl[c]), e = static_cast<float>(br[c]);
+			const float top = ax * (b - a) + a;
+			const float bot = ax * (e - d) + d;
+			o[j * 3 + c] = static_cast<T>(ay * (bot - top) + top);
+		}
+	}
+	float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+	if (i == 0) {
+		const unsigned v = *reinterpret_cast<const unsigned *>(frame + h * frameStride + w * 4);
+		l0 = preprocessU8(v & 0xff);
+		l1 = preprocessU8((v >> 8) & 0xff);
+		l2 = preprocessU8((v >> 16) & 0xff);
+	}
+	// spare slots: the LR frame rides in quarter 0, zeros elsewhere (x/255-0.5 of
+	// a real pixel is never needed for i != 0, and 0.0 weights nothing)
+	o[12] = static_cast<T>(l0);
+	o[13] = static_cast<T>(l1);
+	o[14] = static_cast<T>(l2);
+	o[15] = static_cast<T>(0.f);
+	Vec8<T> o0, o1;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		o0[k] = o[k];
+		o1[k] = o[8 + k];
+	}
+	T *dst = out + (size_t)pix * 64 + i * 16;
+	*reinterpret_cast<Vec8<T> *>(dst) = o0;
+	*reinterpret_cast<Vec8<T> *>(dst + 8) = o1;
+}
+
+// ---------------------------------------------------------------------------
+// generator tail
+// ---------------------------------------------------------------------------
+// One thread per mid-resolution pixel (2h+a, 2w+b): 32 channels in, 2x2 HR
+// pixels x 3 channels out.
+template <typename T>
+__global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
+    const float *__restrict__ w2, const float *__restrict__ b2,
+    const std::uint8_t *__restrict__ frame, std::ptrdiff_t frameStride,
+    f16 *__restrict__ stateOut, std::uint8_t *__restrict__ outU8, int H, int W) {
+	const int MW = 2 * W, MH = 2 * H;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= MW * MH) return;
+	const int mx = idx % MW;
+	const int my = idx / MW;
+	const int h = my >> 1, a = my & 1;
+	const int w = mx >> 1, b = mx & 1;
+	const T *src = y + ((size_t)h * W + w) * 128 + (a * 2 + b) * 32;
+	float in[32];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const Vec8<T> v = *reinterpret_cast<const Vec8<T> *>(src + k * 8);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) in[k * 8 + i] = static_cast<float>(v[i]);
+	}
+	// LR neighbourhood for the bilinear x4 skip (UpscaleLayer, keras_layers.py:46-52)
+	const int h1 = min(h + 1, H - 1), w1 = min(w + 1, W - 1);
+	float lr[2][2][3];
+#pragma unroll
+	for (int yy = 0; yy < 2; ++yy) {
+#pragma unroll
+		for (int xx = 0; xx < 2; ++xx) {
+			const unsigned v = *reinterpret_cast<const unsigned *>(
+			    frame + (yy ? h1 : h) * frameStride + (xx ? w1 : w) * 4);
+			lr[yy][xx][0] = preprocessU8(v & 0xff);
+			lr[yy][xx][1] = preprocessU8((v >> 8) & 0xff);
+			lr[yy][xx][2] = preprocessU8((v >> 16) & 0xff);
+		}
+	}
+	const int WW = 4 * W;
+#pragma unroll
+	for (int a2 = 0; a2 < 2; ++a2) {
+		const int Y = 2 * my + a2;
+		const float fy = static_cast<float>(Y & 3) * 0.25f;
+		Vec8<f16> st;
+		unsigned pk[2];
+#pragma unroll
+		for (int b2i = 0; b2i < 2; ++b2i) {
+			const int X = 2 * mx + b2i;
+			const float fx = static_cast<float>(X & 3) * 0.25f;
+			unsigned packed = 0;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				// ConvT 2x2 s2: y[2h+a,2w+b,o] = sum_c x[h,w,c] K[a,b,o,c] (+bias)
+				float acc = b2[c];
+				const float *wk = w2 + ((a2 * 2 + b2i) * 3 + c) * 32;
+#pragma unroll
+				for (int k = 0; k < 32; ++k) acc = fmaf(in[k], wk[k], acc);
+				const float top = lr[0][0][c] + (lr[0][1][c] - lr[0][0][c]) * fx;
+				const float bot = lr[1][0][c] + (lr[1][1][c] - lr[1][0][c]) * fx;
+				const float skip = top + (bot - top) * fy;
+				float r = tanhf(acc) + skip;
+				r = fminf(fmaxf(r, -0.5f), 0.5f);  // ClipLayer
+				st[b2i * 4 + c] = static_cast<f16>(r);
+				// PostprocessLayer + truncating cast (cuda_convert.cc.cu:76-81)
+				const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);
+				packed |= (u & 0xff) << (8 * c);
+			}
+			st[b2i * 4 + 3] = static_cast<f16>(0.f);
+			pk[b2i] = packed;  // X byte = 0
+		}
+		*reinterpret_cast<Vec8<f16> *>(stateOut + ((size_t)Y * WW + 2 * mx) * 4) = st;
+		*reinterpret_cast<uint2 *>(outU8 + ((size_t)Y * WW + 2 * mx) * 4) = make_uint2(pk[0], pk[1]);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// staging helpers
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_rows_kernel(const std::uint8_t *__restrict__ src,
+    std::ptrdiff_t srcStride, std::uint8_t *__restrict__ dst, std::ptrdiff_t dstStride,
+    unsigned wordsPerRow, unsigned rows) {
+	const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= wordsPerRow * rows) return;
+	const unsigned r = idx / wordsPerRow;
+	const unsigned c = idx - r * wordsPerRow;
+	const unsigned v = *reinterpret_cast<const unsigned *>(
+	    src + static_cast<std::ptrdiff_t>(r) * srcStride + c * 4);
+	*reinterpret_cast<unsigned *>(dst + static_cast<std::ptrdiff_t>(r) * dstStride + c * 4) = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_float_kernel(
+    const T *__restrict__ in, float *__restrict__ out, size_t n) {
+	const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (idx < n) out[idx] = static_cast<float>(in[idx]);
+}
+
+inline unsigned blocksFor(size_t n) { return static_cast<unsigned>((n + 255) / 256); }
+
+}  // namespace
+
+// ===========================================================================
+// launchers
+// ===========================================================================
+void launchConv(DType dt, const ConvParams &p, hipStream_t stream) {
+	if (dt == kF16) launchConvT<f16>(p, stream);
+	else launchConvT<bf16>(p, stream);
+}
+
+void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
+	launchConv(dt, p, stream);
+}
+
+void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
+    const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
+    int padLeft, int numInputs, hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)PH * PW);
+	if (dt == kF16) {
+		hipLaunchKernelGGL(pack_frames_kernel<f16>, dim3(nb), dim3(256), 0, stream, frame,
+		    frameStride, static_cast<const f16 *>(prevPacked), static_cast<f16 *>(curPacked), H, W,
+		    PH, PW, padTop, padLeft, numInputs);
+	} else {
+		hipLaunchKernelGGL(pack_frames_kernel<bf16>, dim3(nb), dim3(256), 0, stream, frame,
+		    frameStride, static_cast<const bf16 *>(prevPacked), static_cast<bf16 *>(curPacked), H,
+		    W, PH, PW, padTop, padLeft, numInputs);
+	}
+	hipCheckLaunch("pack_frames");
+}
+
+void launchMaxPool2(DType dt, const void *in, void *out, int H, int W, int C, hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)(H / 2) * (W / 2) * (C / 8));
+	if (dt == kF16) {
+		hipLaunchKernelGGL(maxpool2_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(in), static_cast<f16 *>(out), H, W, C);
+	} else {
+		hipLaunchKernelGGL(maxpool2_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(in), static_cast<bf16 *>(out), H, W, C);
+	}
+	hipCheckLaunch("maxpool2");
+}
+
+void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)(H * 2) * (W * 2) * (C / 8));
+	if (dt == kF16) {
+		hipLaunchKernelGGL(upsample2_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(in), static_cast<f16 *>(out), H, W, C);
+	} else {
+		hipLaunchKernelGGL(upsample2_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(in), static_cast<bf16 *>(out), H, W, C);
+	}
+	hipCheckLaunch("upsample2");
+}
+
+void launchWarpPack(DType dt, const void *state, const float *flow, const std::uint8_t *frame,
+    std::ptrdiff_t frameStride, void *out, int H, int W, int PW, int padTop, int padLeft,
+    hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)H * W * 4);
+	if (dt == kF16) {
+		hipLaunchKernelGGL(warp_pack_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<f16 *>(out), H,
+		    W, PW, padTop, padLeft);
+	} else {
+		hipLaunchKernelGGL(warp_pack_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<bf16 *>(out), H,
+		    W, PW, padTop, padLeft);
+	}
+	hipCheckLaunch("warp_pack");
+}
+
+void launchTail(DType dt, const void *y, const float *w2, const float *b2,
+    const std::uint8_t *frame, std::ptrdiff_t frameStride, void *stateOut, std::uint8_t *outU8,
+    int H, int W, hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)4 * H * W);
+	if (dt == kF16) {
+		hipLaunchKernelGGL(tail_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(y), w2, b2, frame, frameStride, static_cast<f16 *>(stateOut),
+		    outU8, H, W);
+	} else {
+		hipLaunchKernelGGL(tail_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(y), w2, b2, frame, frameStride, static_cast<f16 *>(stateOut),
+		    outU8, H, W);
+	}
+	hipCheckLaunch("tail");
+}
+
+void launchCopyRows(const std::uint8_t *src, std::ptrdiff_t srcStride, std::uint8_t *dst,
+    std::ptrdiff_t dstStride, std::size_t rowBytes, std::size_t rows, hipStream_t stream) {
+	const unsigned words = static_cast<unsigned>(rowBytes / 4);
+	hipLaunchKernelGGL(copy_rows_kernel, dim3(blocksFor((size_t)words * rows)), dim3(256), 0,
+	    stream, src, srcStride, dst, dstStride, words, static_cast<unsigned>(rows));
+	hipCheckLaunch("copy_rows");
+}
+
+void launchToFloat(DType dt, const void *in, float *out, std::size_t n, hipStream_t stream) {
+	if (dt == kF16) {
+		hipLaunchKernelGGL(to_float_kernel<f16>, dim3(blocksFor(n)), dim3(256), 0, stream,
+		    static_cast<const f16 *>(in), out, n);
+	} else {
+		hipLaunchKernelGGL(to_float_kernel<bf16>, dim3(blocksFor(n)), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(in), out, n);
+	}
+	hipCheckLaunch("to_float");
+}
+
+}  // namespace ju

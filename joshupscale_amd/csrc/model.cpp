@@ -1,0 +1,267 @@
+#include "model.h"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace ju {
+
+namespace {
+
+constexpr char kMagic[8] = {'J', 'U', 'P', 'W', 'G', 'T', '\0', '\1'};
+constexpr std::size_t kHeaderBytes = 128;
+constexpr std::size_t kEntryBytes = 128;
+
+template <typename T>
+T readLE(const unsigned char *p) {
+	T v;
+	std::memcpy(&v, p, sizeof(T));  // x86-64 / little endian host
+	return v;
+}
+
+}  // namespace
+
+ModelFile::ModelFile(const void *blob, std::size_t size) {
+	if (blob == nullptr || size < kHeaderBytes) {
+		throw std::invalid_argument("Invalid model: too small");
+	}
+	m_Bytes.assign(static_cast<const unsigned char *>(blob),
+	    static_cast<const unsigned char *>(blob) + size);
+	const unsigned char *b = m_Bytes.data();
+	if (std::memcmp(b, kMagic, 8) != 0) {
+		// The reference's .trt engines (core/src/tensorrt_backend.cc:129-143) are
+		// rejected here with a clear message rather than mis-parsed.
+		throw std::invalid_argument(
+		    "Invalid model: not a JoshUpscale-AMD .jupw container (TensorRT engines are not "
+		    "supported by this runtime)");
+	}
+	const auto version = readLE<std::uint32_t>(b + 8);
+	const auto headerBytes = readLE<std::uint32_t>(b + 12);
+	if (version != 1 || headerBytes < kHeaderBytes || headerBytes > size) {
+		throw std::invalid_argument("Invalid model: unsupported container version");
+	}
+	auto u32 = [&](std::size_t off) { return static_cast<int>(readLE<std::uint32_t>(b + off)); };
+	ModelConfig &c = m_Config;
+	c.frameHeight = u32(16);
+	c.frameWidth = u32(20);
+	const int scale = u32(24);
+	c.numFlowInputs = u32(28);
+	c.flowArch = u32(32);
+	c.flowPadFactor = u32(36);
+	c.normalizeBrightness = u32(40) != 0;
+	c.genFilters = u32(44);
+	c.genBlocks = u32(48);
+	c.flowResFilters = u32(52);
+	c.flowResBlocks = u32(56);
+	const int nFlowFilters = u32(60);
+	if (nFlowFilters < 0 || nFlowFilters > 8) {
+		throw std::invalid_argument("Invalid model: bad flow filter count");
+	}
+	for (int i = 0; i < nFlowFilters; ++i) c.flowFilters.push_back(u32(64 + 4 * i));
+	c.bnEps = readLE<float>(b + 96);
+	c.computeDtype = u32(100);
+	const int nTensors = u32(104);
+	if (scale != 4) throw std::invalid_argument("Invalid model: scale must be 4");
+	if (c.frameHeight < 2 || c.frameWidth < 2 || c.frameHeight > 8192 || c.frameWidth > 8192) {
+		throw std::invalid_argument("Invalid model: unsupported frame size");
+	}
+	if (c.numFlowInputs < 1 || c.numFlowInputs > 5) {
+		throw std::invalid_argument("Invalid model: 1..5 flow inputs supported");
+	}
+	if (c.flowArch != 0 && c.flowArch != 1) {
+		throw std::invalid_argument("Invalid model: unknown flow architecture");
+	}
+	if (c.computeDtype != kF16 && c.computeDtype != kBF16) {
+		throw std::invalid_argument("Invalid model: unknown compute dtype");
+	}
+	if (nTensors < 0 || headerBytes + static_cast<std::size_t>(nTensors) * kEntryBytes > size) {
+		throw std::invalid_argument("Invalid model: truncated tensor table");
+	}
+	for (int i = 0; i < nTensors; ++i) {
+		const unsigned char *e = b + headerBytes + static_cast<std::size_t>(i) * kEntryBytes;
+		char name[93];
+		std::memcpy(name, e, 92);
+		name[92] = '\0';
+		const auto ndim = readLE<std::uint32_t>(e + 92);
+		if (ndim > 4) throw std::invalid_argument("Invalid model: tensor rank > 4");
+		TensorView t;
+		std::size_t count = 1;
+		for (std::uint32_t d = 0; d < ndim; ++d) {
+			const auto dim = readLE<std::uint32_t>(e + 96 + 4 * d);
+			t.dims.push_back(static_cast<int>(dim));
+			count *= dim;
+		}
+		const auto off = readLE<std::uint64_t>(e + 112);
+		const auto cnt = readLE<std::uint64_t>(e + 120);
+		if (cnt != count || off % 4 != 0 || off > size || cnt > (size - off) / 4) {
+			throw std::invalid_argument(std::string("Invalid model: bad tensor entry ") + name);
+		}
+		t.count = count;
+		t.data = reinterpret_cast<const float *>(b + off);
+		m_Tensors.emplace(name, std::move(t));
+	}
+}
+
+const TensorView &ModelFile::tensor(const std::string &name) const {
+	auto it = m_Tensors.find(name);
+	if (it == m_Tensors.end()) {
+		throw std::invalid_argument("Invalid model: missing tensor " + name);
+	}
+	return it->second;
+}
+
+const TensorView &ModelFile::tensor(const std::string &name, const std::vector<int> &dims) const {
+	const TensorView &t = tensor(name);
+	if (t.dims != dims) {
+		throw std::invalid_argument("Invalid model: unexpected shape for " + name);
+	}
+	return t;
+}
+
+namespace {
+
+// per-channel BN scale/shift in double
+void bnScaleShift(const ModelFile &m, const std::string &bn, int c, std::vector<double> *scale,
+    std::vector<double> *shift) {
+	scale->assign(c, 1.0);
+	shift->assign(c, 0.0);
+	if (bn.empty()) return;
+	const float *g = m.tensor(bn + "/gamma", {c}).data;
+	const float *be = m.tensor(bn + "/beta", {c}).data;
+	const float *mu = m.tensor(bn + "/moving_mean", {c}).data;
+	const float *var = m.tensor(bn + "/moving_variance", {c}).data;
+	const double eps = m.config().bnEps;
+	for (int i = 0; i < c; ++i) {
+		const double s = static_cast<double>(g[i]) / std::sqrt(static_cast<double>(var[i]) + eps);
+		(*scale)[i] = s;
+		(*shift)[i] = static_cast<double>(be[i]) - static_cast<double>(mu[i]) * s;
+	}
+}
+
+}  // namespace
+
+FoldedConv foldConv(const ModelFile &m, const std::string &convName,
+    const std::string &bnPrefix, bool hasBias) {
+	const TensorView &k = m.tensor(convName + "/kernel");
+	if (k.dims.size() != 4 || k.dims[0] != k.dims[1] || (k.dims[0] != 3 && k.dims[0] != 1)) {
+		throw std::invalid_argument("Invalid model: " + convName + " must be a 3x3 or 1x1 conv");
+	}
+	FoldedConv f;
+	f.taps = k.dims[0] * k.dims[1];
+	f.cin = k.dims[2];
+	f.cout = k.dims[3];
+	std::vector<double> scale, shift;
+	bnScaleShift(m, bnPrefix, f.cout, &scale, &shift);
+	f.w.resize(static_cast<std::size_t>(f.taps) * f.cin * f.cout);
+	for (std::size_t i = 0; i < f.w.size(); ++i) {
+		f.w[i] = static_cast<float>(static_cast<double>(k.data[i]) * scale[i % f.cout]);
+	}
+	f.bias.resize(f.cout);
+	const float *b = hasBias ? m.tensor(convName + "/bias", {f.cout}).data : nullptr;
+	for (int o = 0; o < f.cout; ++o) {
+		f.bias[o] = static_cast<float>((b ? static_cast<double>(b[o]) * scale[o] : 0.0) + shift[o]);
+	}
+	return f;
+}
+
+FoldedConv foldConvTranspose2x2(
+    const ModelFile &m, const std::string &convName, const std::string &bnPrefix) {
+	const TensorView &k = m.tensor(convName + "/kernel");
+	if (k.dims.size() != 4 || k.dims[0] != 2 || k.dims[1] != 2) {
+		throw std::invalid_argument("Invalid model: " + convName + " must be a 2x2 conv-transpose");
+	}
+	const int co = k.dims[2], ci = k.dims[3];
+	std::vector<double> scale, shift;
+	bnScaleShift(m, bnPrefix, co, &scale, &shift);
+	FoldedConv f;
+	f.taps = 1;
+	f.cin = ci;
+	f.cout = 4 * co;
+	f.w.resize(static_cast<std::size_t>(ci) * 4 * co);
+	f.bias.resize(4 * co);
+	for (int ab = 0; ab < 4; ++ab) {
+		for (int o = 0; o < co; ++o) {
+			for (int c = 0; c < ci; ++c) {
+				// y[2h+a,2w+b,o] = sum_c x[h,w,c] K[a,b,o,c]   
+				f.w[static_cast<std::size_t>(c) * 4 * co + ab * co + o] = static_cast<float>(
+				    static_cast<double>(k.data[(static_cast<std::size_t>(ab) * co + o) * ci + c]) *
+				    scale[o]);
+			}
+			f.bias[ab * co + o] = static_cast<float>(shift[o]);
+		}
+	}
+	return f;
+}
+
+std::uint16_t floatToF16(float f) {
+	std::uint32_t x;
+	std::memcpy(&x, &f, 4);
+	const std::uint16_t sign = static_cast<std::uint16_t>((x >> 16) & 0x8000u);
+	x &= 0x7fffffffu;
+	if (x >= 0x7f800000u) return sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u);
+	if (x >= 0x477ff000u) return sign | 0x7c00u;  // rounds to >= 65520 -> inf
+	if (x < 0x38800000u) {                         // below 2^-14: half subnormal
+		float af;
+		std::memcpy(&af, &x, 4);
+		const float scaled = af * 16777216.0f;  // * 2^24, exact
+		const auto r = static_cast<std::uint32_t>(std::nearbyint(scaled));  // RNE
+		return sign | static_cast<std::uint16_t>(r);
+	}
+	const std::uint32_t mant = x & 0x7fffffu;
+	const std::uint32_t exp = (x >> 23) - 112u;
+	std::uint32_t h = (exp << 10) | (mant >> 13);
+	const std::uint32_t rem = mant & 0x1fffu;
+	if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+	return sign | static_cast<std::uint16_t>(h);
+}
+
+std::uint16_t floatToBF16(float f) {
+	std::uint32_t x;
+	std::memcpy(&x, &f, 4);
+	if ((x & 0x7fffffffu) > 0x7f800000u) return static_cast<std::uint16_t>((x >> 16) | 0x40u);
+	x += 0x7fffu + ((x >> 16) & 1u);
+	return static_cast<std::uint16_t>(x >> 16);
+}
+
+std::vector<std::uint16_t> packConvWeights(
+    const FoldedConv &c, const std::vector<int> &cinMap, DType dt) {
+	const int cinP = static_cast<int>(cinMap.size());
+	if (cinP % 16 != 0 || c.cout % 32 != 0) {
+		throw std::invalid_argument("packConvWeights: cin must pad to 16, cout to 32");
+	}
+	const int CK = convCK(cinP);
+	const int COG = 32 * convNB(c.cout);
+	const int KS = CK / 16;
+	const int nCC = cinP / CK;
+	const int nCOG = c.cout / COG;
+	std::vector<std::uint16_t> out(static_cast<std::size_t>(c.taps) * cinP * c.cout);
+	std::size_t idx = 0;
+	for (int cog = 0; cog < nCOG; ++cog) {
+		for (int cc = 0; cc < nCC; ++cc) {
+			for (int tap = 0; tap < c.taps; ++tap) {
+				for (int ks = 0; ks < KS; ++ks) {
+					for (int h = 0; h < 2; ++h) {
+						for (int n = 0; n < COG; ++n) {
+							for (int j = 0; j < 8; ++j) {
+								const int kp = cc * CK + ks * 16 + h * 8 + j;
+								const int src = cinMap[kp];
+								float v = 0.f;
+								if (src >= 0) {
+									if (src >= c.cin) {
+										throw std::out_of_range("packConvWeights: cinMap");
+									}
+									v = c.w[(static_cast<std::size_t>(tap) * c.cin + src) * c.cout +
+									        cog * COG + n];
+								}
+								out[idx++] = dt == kF16 ? floatToF16(v) : floatToBF16(v);
+							}
+						}
+					}
+				}
+			}
+		}
+	}
+	return out;
+}
+
+}  // namespace ju

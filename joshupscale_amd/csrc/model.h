@@ -1,0 +1,97 @@
+// Model container (.jupw) reader, BatchNorm folding and kernel-ready weight
+// packing.  The container is this engine's replacement for the serialized
+// TensorRT engine the reference loads (reference core/src/core.cc:156-167,
+// core/src/tensorrt_backend.cc:117-148); its Python twin is
+// joshupscale_amd/model_file.py.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace ju {
+
+struct ModelConfig {
+	int frameHeight = 0;
+	int frameWidth = 0;
+	int numFlowInputs = 4;
+	int flowArch = 0;  // 0 = autoencoder, 1 = resnet
+	int flowPadFactor = 0;
+	bool normalizeBrightness = false;
+	int genFilters = 64;
+	int genBlocks = 24;
+	int flowResFilters = 64;
+	int flowResBlocks = 10;
+	std::vector<int> flowFilters;
+	float bnEps = 1e-3f;
+	int computeDtype = kBF16;
+
+	// reference scripts/training/models.py:735-744
+	int paddedHeight() const {
+		return flowPadFactor ? (frameHeight + flowPadFactor - 1) / flowPadFactor * flowPadFactor
+		                     : frameHeight;
+	}
+	int paddedWidth() const {
+		return flowPadFactor ? (frameWidth + flowPadFactor - 1) / flowPadFactor * flowPadFactor
+		                     : frameWidth;
+	}
+};
+
+struct TensorView {
+	std::vector<int> dims;
+	const float *data = nullptr;
+	std::size_t count = 0;
+};
+
+class ModelFile {
+public:
+	// Parses and validates; keeps its own copy of the bytes.
+	ModelFile(const void *blob, std::size_t size);
+
+	const ModelConfig &config() const { return m_Config; }
+	bool has(const std::string &name) const { return m_Tensors.count(name) != 0; }
+	const TensorView &tensor(const std::string &name) const;  // throws if missing
+	// Tensor that must have exactly these dims.
+	const TensorView &tensor(const std::string &name, const std::vector<int> &dims) const;
+
+private:
+	std::vector<unsigned char> m_Bytes;
+	ModelConfig m_Config;
+	std::map<std::string, TensorView> m_Tensors;
+};
+
+// A convolution with BatchNorm folded in: y = sum_k x[k] * w[tap][k][cout] + bias.
+struct FoldedConv {
+	int taps = 9;
+	int cin = 0;
+	int cout = 0;
+	std::vector<float> w;     // [taps][cin][cout]
+	std::vector<float> bias;  // [cout]
+};
+
+// Conv2D (keras kernel [k][k][cin][cout]) followed by an optional BatchNorm
+// (folded: W' = W*g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps))
+// and/or the layer's own bias.  `bnPrefix` empty = no BN.
+FoldedConv foldConv(const ModelFile &m, const std::string &convName,
+    const std::string &bnPrefix, bool hasBias);
+
+// Conv2DTranspose k2 s2 (keras kernel [2][2][cout][cin]) + BN, expressed as a
+// 1x1 convolution cin -> 4*cout with output channel (a*2+b)*cout + o.
+FoldedConv foldConvTranspose2x2(
+    const ModelFile &m, const std::string &convName, const std::string &bnPrefix);
+
+// Kernel-ready 16-bit weights for conv_mfma_kernel:
+// [cout/COG][cinP/CK][tap][CK/16][2][COG][8] with COG = 32*convNB(cout),
+// CK = convCK(cinP).  `cinMap[k]` = source input channel of packed channel k, or
+// -1 for a zero channel (cinMap.size() == cinP, a multiple of 16).
+std::vector<std::uint16_t> packConvWeights(
+    const FoldedConv &c, const std::vector<int> &cinMap, DType dt);
+
+std::uint16_t floatToF16(float f);
+std::uint16_t floatToBF16(float f);
+
+}  // namespace ju

@@ -26,7 +26,7 @@ Layout (all little endian):
     100 u32      compute_dtype hint (0 fp16, 1 bf16)
     104 u32      n_tensors
     108 u32      reserved[5]                        -> header_bytes = 128
-    table: n_tensors x { char name[96]; u32 ndim; u32 dims[4]; u64 offset;
+    table: n_tensors x { char name[92]; u32 ndim; u32 dims[4]; u64 offset;
                          u64 count }                (128 bytes each)
     data:  float32, each tensor 64-byte aligned, offsets from file start
 """
@@ -192,10 +192,10 @@ def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray]) -> bytes:
     blobs = []
     for n in names:
         a = np.ascontiguousarray(weights[n], dtype="<f4")
-        if a.ndim > 4 or len(n.encode()) >= 96:
+        if a.ndim > 4 or len(n.encode()) >= 92:
             raise ValueError(n)
         dims = list(a.shape) + [1] * (4 - a.ndim)
-        table += struct.pack("<96sI4IQQ", n.encode(), a.ndim, *dims, off, a.size)
+        table += struct.pack("<92sI4IQQ", n.encode(), a.ndim, *dims, off, a.size)
         blobs.append((off, a.tobytes()))
         off = (off + a.nbytes + 63) // 64 * 64
     out = bytearray(off)
@@ -224,7 +224,7 @@ def deserialize(blob: bytes) -> Tuple[ModelConfig, Dict[str, np.ndarray]]:
     w = {}
     for i in range(nt):
         name, ndim, d0, d1, d2, d3, off, cnt = struct.unpack_from(
-            "<96sI4IQQ", blob, header_bytes + i * ENTRY_BYTES)
+            "<92sI4IQQ", blob, header_bytes + i * ENTRY_BYTES)
         name = name.split(b"\0", 1)[0].decode()
         shape = (d0, d1, d2, d3)[:ndim]
         w[name] = np.frombuffer(blob, dtype="<f4", count=cnt,

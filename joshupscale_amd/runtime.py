@@ -1,0 +1,230 @@
+"""ctypes binding of libJoshUpscale.so (the C ABI in include/joshupscale_amd.h).
+
+Host-side mirror, in Python, of what the reference exposes to its callers:
+
+* :class:`Runtime` <-> ``JoshUpscale::core::Runtime`` / ``createRuntime``
+  (reference core/public/JoshUpscale/core.h:64-92): ``process_image`` is
+  ``processImage`` on BGRX frames.
+* :class:`Session` <-> the recurrent drivers of the reference's Python scripts
+  (scripts/inference/onnx/inference.py:46-94,
+  scripts/inference/tensorrt/inference.py:60-193): ``run(image)`` takes one
+  ``[H, W, 3|4]`` uint8 BGR(X) frame and returns the upscaled frame, the state
+  living inside the runtime.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible the
+constructors raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_LIB_NAME = "libJoshUpscale.so"
+_LIB: Optional[C.CDLL] = None
+
+LOC_CPU, LOC_DEVICE, LOC_GRAPHICS_RESOURCE = 0, 1, 2
+DTYPE_DEFAULT, DTYPE_F16, DTYPE_BF16 = -1, 0, 1
+DTYPE_NAMES = {DTYPE_F16: "fp16", DTYPE_BF16: "bf16"}
+
+
+class JuImage(C.Structure):
+    """``ju_image`` == ``JoshUpscale::core::Image`` (core.h:32-38)."""
+    _fields_ = [("ptr", C.c_void_p), ("location", C.c_uint8),
+                ("stride", C.c_ssize_t), ("width", C.c_size_t),
+                ("height", C.c_size_t)]
+
+
+LOG_CALLBACK = C.CFUNCTYPE(None, C.c_char_p, C.c_int, C.c_char_p, C.c_void_p)
+
+
+class JoshUpscaleError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
+
+
+def load_library() -> C.CDLL:
+    """Load the HIP library; fails loudly (no fallback) when it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `make` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`). "
+            "joshupscale_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    P = C.POINTER
+    sigs = {
+        "ju_create": (C.c_int, [C.c_int, C.c_char_p, P(C.c_void_p)]),
+        "ju_create_from_memory": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int,
+                                            P(C.c_void_p)]),
+        "ju_destroy": (None, [C.c_void_p]),
+        "ju_process": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage)]),
+        "ju_enqueue": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage)]),
+        "ju_synchronize": (C.c_int, [C.c_void_p]),
+        "ju_get_size": (C.c_int, [C.c_void_p] + [P(C.c_size_t)] * 4),
+        "ju_reset": (C.c_int, [C.c_void_p]),
+        "ju_last_error": (C.c_char_p, []),
+        "ju_set_log_callback": (None, [LOG_CALLBACK, C.c_void_p]),
+        "ju_get_gl_device_index": (C.c_int, [P(C.c_int)]),
+        "ju_get_gl_image": (C.c_int, [C.c_uint32, C.c_int, P(JuImage)]),
+        "ju_get_dtype": (C.c_int, [C.c_void_p]),
+        "ju_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
+                                     P(C.c_size_t)]),
+        "ju_time_steps": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, P(C.c_double),
+                                    P(C.c_int), P(C.c_double)]),
+        "ju_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _check(lib: C.CDLL, rc: int) -> None:
+    if rc != 0:
+        raise JoshUpscaleError(rc, lib.ju_last_error().decode(errors="replace"))
+
+
+class Runtime:
+    """One recurrent SR stream on one GPU (``JoshUpscale::core::Runtime``)."""
+
+    def __init__(self, model, device: int = 0, dtype: int = DTYPE_DEFAULT):
+        """``model``: path of a .jupw file, or its bytes."""
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        if isinstance(model, (bytes, bytearray, memoryview)):
+            buf = bytes(model)
+            _check(self._lib, self._lib.ju_create_from_memory(
+                device, buf, len(buf), dtype, C.byref(self._h)))
+        else:
+            if dtype != DTYPE_DEFAULT:
+                with open(model, "rb") as f:
+                    buf = f.read()
+                _check(self._lib, self._lib.ju_create_from_memory(
+                    device, buf, len(buf), dtype, C.byref(self._h)))
+            else:
+                _check(self._lib, self._lib.ju_create(
+                    device, os.fsencode(model), C.byref(self._h)))
+        w = [C.c_size_t() for _ in range(4)]
+        _check(self._lib, self._lib.ju_get_size(self._h, *[C.byref(x) for x in w]))
+        self.input_width, self.input_height, self.output_width, self.output_height = (
+            x.value for x in w)
+        self.device = device
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.ju_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the boundary ------------------------------------------------------
+    @property
+    def dtype(self) -> int:
+        return self._lib.ju_get_dtype(self._h)
+
+    def process(self, inp: JuImage, out: JuImage) -> None:
+        """Raw ``processImage`` on two image descriptors (synchronous)."""
+        _check(self._lib, self._lib.ju_process(self._h, C.byref(inp), C.byref(out)))
+
+    def enqueue(self, inp: JuImage, out: JuImage) -> None:
+        _check(self._lib, self._lib.ju_enqueue(self._h, C.byref(inp), C.byref(out)))
+
+    def synchronize(self) -> None:
+        _check(self._lib, self._lib.ju_synchronize(self._h))
+
+    def reset(self) -> None:
+        _check(self._lib, self._lib.ju_reset(self._h))
+
+    def process_image(self, frame_bgrx: np.ndarray,
+                      out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Host frames: ``[H, W, 4]`` uint8 in, ``[4H, 4W, 4]`` uint8 out.  Any
+        row stride (also negative, i.e. a ``[::-1]`` view) is passed through."""
+        if frame_bgrx.dtype != np.uint8 or frame_bgrx.ndim != 3 or frame_bgrx.shape[2] != 4:
+            raise ValueError("expected a [H, W, 4] uint8 BGRX frame")
+        if frame_bgrx.strides[2] != 1 or frame_bgrx.strides[1] != 4:
+            frame_bgrx = np.ascontiguousarray(frame_bgrx)
+        if out is None:
+            out = np.empty((self.output_height, self.output_width, 4), np.uint8)
+        if out.strides[2] != 1 or out.strides[1] != 4:
+            raise ValueError("output must have contiguous pixels")
+        self.process(host_image(frame_bgrx), host_image(out))
+        return out
+
+    def device_image(self, ptr: int, width: int, height: int,
+                     stride: Optional[int] = None) -> JuImage:
+        return JuImage(ptr, LOC_DEVICE, width * 4 if stride is None else stride,
+                       width, height)
+
+    # -- introspection -------------------------------------------------------
+    def read_tensor(self, name: str) -> np.ndarray:
+        n = C.c_size_t()
+        _check(self._lib, self._lib.ju_read_tensor(self._h, name.encode(), None, 0,
+                                                   C.byref(n)))
+        arr = np.empty(n.value, np.float32)
+        _check(self._lib, self._lib.ju_read_tensor(
+            self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.size, C.byref(n)))
+        return arr
+
+    def time_steps(self, tag: str, iters: int) -> Tuple[float, int, float]:
+        """(ms per launch, launches per repetition, FLOPs per repetition)."""
+        ms, n, fl = C.c_double(), C.c_int(), C.c_double()
+        _check(self._lib, self._lib.ju_time_steps(
+            self._h, tag.encode(), iters, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+
+def host_image(arr: np.ndarray) -> JuImage:
+    """Describe a ``[H, W, 4]`` uint8 numpy array (any row stride) as an image."""
+    return JuImage(arr.ctypes.data, LOC_CPU, arr.strides[0], arr.shape[1], arr.shape[0])
+
+
+class Session:
+    """Recurrent driver with the reference scripts' call shape
+    (scripts/inference/onnx/inference.py:46-94): ``Session(model).run(image)``.
+    Accepts ``[H, W, 3]`` BGR (as ``cv2.imread`` yields) or ``[H, W, 4]`` BGRX and
+    returns the same number of channels."""
+
+    def __init__(self, model, device: int = 0, dtype: int = DTYPE_DEFAULT):
+        self.runtime = Runtime(model, device, dtype)
+
+    def run(self, image: np.ndarray) -> np.ndarray:
+        if image.ndim == 4 and image.shape[0] == 1:
+            image = image[0]
+        ch = image.shape[2]
+        if ch == 3:
+            frame = np.empty(image.shape[:2] + (4,), np.uint8)
+            frame[..., :3] = image
+            frame[..., 3] = 255
+        else:
+            frame = image
+        out = self.runtime.process_image(np.ascontiguousarray(frame, dtype=np.uint8))
+        return out[..., :3].copy() if ch == 3 else out
+
+    def reset(self) -> None:
+        self.runtime.reset()

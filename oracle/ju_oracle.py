@@ -244,6 +244,12 @@ def postprocess(x: np.ndarray) -> np.ndarray:
 Weights = Dict[str, np.ndarray]
 
 
+def _rec(trace: Optional[dict], name: str, value: np.ndarray) -> None:
+    """Record an intermediate tensor for layer-by-layer parity diagnostics."""
+    if trace is not None:
+        trace[name] = value
+
+
 def _conv_bn_act(x, wts: Weights, conv: str, bn: str, eps: float) -> np.ndarray:
     y = conv2d_same(x, wts[conv + "/kernel"])
     y = batch_norm(y, wts[bn + "/gamma"], wts[bn + "/beta"],
@@ -264,7 +270,7 @@ def res_block(x, wts: Weights, name: str, eps: float) -> np.ndarray:
 
 
 def flow_autoencoder(frames: Sequence[np.ndarray], wts: Weights,
-                     cfg: ModelConfig) -> np.ndarray:
+                     cfg: ModelConfig, trace: Optional[dict] = None) -> np.ndarray:
     """``get_flow_autoencoder`` (models.py:334-481).  Returns the flow field
     ``[4*PH, 4*PW, 2]`` (channel 0 = dy, 1 = dx, in HR pixels)."""
     eps = cfg.bn_eps
@@ -274,21 +280,29 @@ def flow_autoencoder(frames: Sequence[np.ndarray], wts: Weights,
     for i in range(nblk):  # down blocks, models.py:377-410, 450-451
         n = f"flow/block_{i + 1}"
         x = _conv_bn_act(x, wts, n + "/conv_1", n + "/bn_1", eps)
+        _rec(trace, n + "/a_1", x)
         x = _conv_bn_act(x, wts, n + "/conv_2", n + "/bn_2", eps)
+        _rec(trace, n + "/a_2", x)
         x = max_pool_2x2(x)
+        _rec(trace, n + "/resample", x)
     for i in range(nblk, 2 * nblk):  # up blocks, models.py:412-447, 452-453
         n = f"flow/block_{i + 1}"
         x = _conv_bn_act(x, wts, n + "/conv_1", n + "/bn_1", eps)
+        _rec(trace, n + "/a_1", x)
         x = _conv_bn_act(x, wts, n + "/conv_2", n + "/bn_2", eps)
+        _rec(trace, n + "/a_2", x)
         x = resize_bilinear_tf1(x, 2)
+        _rec(trace, n + "/resample", x)
     if len(filters) % 2:  # models.py:454-468
         x = _conv_bn_act(x, wts, "flow/conv_1", "flow/bn_1", eps)
+        _rec(trace, "flow/a_1", x)
     x = conv2d_same(x, wts["flow/conv_2/kernel"], wts["flow/conv_2/bias"])
+    _rec(trace, "flow", x)  # head before depth-to-space: [PH, PW, 32]
     return depth_to_space(x, 4)  # models.py:476-479
 
 
 def flow_resnet(frames: Sequence[np.ndarray], wts: Weights,
-                cfg: ModelConfig) -> np.ndarray:
+                cfg: ModelConfig, trace: Optional[dict] = None) -> np.ndarray:
     """``get_flow_resnet`` (models.py:257-331)."""
     eps = cfg.bn_eps
     x = np.concatenate(list(frames), axis=2)
@@ -296,22 +310,27 @@ def flow_resnet(frames: Sequence[np.ndarray], wts: Weights,
     for i in range(cfg.flow_res_blocks):
         x = res_block(x, wts, f"flow/block_{i + 1}", eps)
     x = conv2d_same(x, wts["flow/conv_2/kernel"], wts["flow/conv_2/bias"])
+    _rec(trace, "flow", x)
     return depth_to_space(x, 4)
 
 
 def generator(images: np.ndarray, pre_warp: np.ndarray, wts: Weights,
-              cfg: ModelConfig) -> np.ndarray:
+              cfg: ModelConfig, trace: Optional[dict] = None) -> np.ndarray:
     """``get_generator_resnet`` (models.py:484-595)."""
     eps = cfg.bn_eps
     x = np.concatenate([images, space_to_depth(pre_warp, 4)], axis=2)  # :523-530
+    _rec(trace, "gen_in_ref", x)  # reference channel order, 51 channels
     x = _conv_bn_act(x, wts, "generator/conv_1", "generator/bn_1", eps)
+    _rec(trace, "gen_head", x)
     for i in range(cfg.gen_blocks):
         x = res_block(x, wts, f"generator/block_{i + 1}", eps)
+    _rec(trace, "trunk", x)
     x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_1/kernel"])
     b = "generator/bn_2"
     x = relu(batch_norm(x, wts[b + "/gamma"], wts[b + "/beta"],
                         wts[b + "/moving_mean"], wts[b + "/moving_variance"],
                         eps))
+    _rec(trace, "tail_mid", x)  # [2H, 2W, 32]
     x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_2/kernel"],
                               wts["generator/conv_trans_2/bias"])
     x = np.tanh(x)                                  # models.py:580-583
@@ -349,7 +368,8 @@ class StepOutputs:
 
 
 def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
-                   cfg: ModelConfig, dtype=np.float64) -> StepOutputs:
+                   cfg: ModelConfig, dtype=np.float64,
+                   trace: Optional[dict] = None) -> StepOutputs:
     """One execution of ``get_inference_model`` (models.py:680-829) with
     ``skip_processing=False``.  ``cur_frame_u8`` is ``[H, W, 3]`` uint8 BGR."""
     h, w = cfg.frame_height, cfg.frame_width
@@ -368,9 +388,9 @@ def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
         cur_pad = padded
     frames = [cur_pad] + list(state.last_frames)
     if cfg.flow_arch == "autoencoder":
-        flow = flow_autoencoder(frames, wts, cfg)                 # :790
+        flow = flow_autoencoder(frames, wts, cfg, trace)          # :790
     elif cfg.flow_arch == "resnet":
-        flow = flow_resnet(frames, wts, cfg)
+        flow = flow_resnet(frames, wts, cfg, trace)
     else:
         raise ValueError(cfg.flow_arch)
     if (ph, pw) != (h, w):                                        # :791-798
@@ -380,7 +400,8 @@ def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
     pre_warp = dense_image_warp(state.pre_gen, flow)              # :799-801
     if cfg.normalize_brightness:
         pre_warp = pre_warp + brightness                          # :802-803
-    output_raw = generator(cur, pre_warp, wts, cfg)               # :804
+    _rec(trace, "flow_in", np.concatenate(frames, axis=2))
+    output_raw = generator(cur, pre_warp, wts, cfg, trace)        # :804
     output = postprocess(output_raw)                              # :805-807
     if cfg.normalize_brightness:
         output_raw = output_raw - brightness                      # :809-810
@@ -420,9 +441,9 @@ class Session:
         self.state = State.zeros(self.cfg, self.dtype)
         self.last: Optional[StepOutputs] = None
 
-    def run(self, frame_bgrx: np.ndarray) -> np.ndarray:
+    def run(self, frame_bgrx: np.ndarray, trace: Optional[dict] = None) -> np.ndarray:
         out = inference_step(bgrx_to_bgr(frame_bgrx), self.state, self.wts,
-                             self.cfg, self.dtype)
+                             self.cfg, self.dtype, trace)
         self.state = out.state
         self.last = out
         return bgr_to_bgrx(out.output)
