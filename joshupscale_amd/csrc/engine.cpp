@@ -391,6 +391,10 @@ FrameSize Engine::frameSize() const {
 
 void Engine::stageIn(const Frame &in) {
 	const FrameSize fs = frameSize();
+	if (in.location == Location::GraphicsResource) {
+		throw std::invalid_argument(
+		    "processImage: GRAPHICS_RESOURCE images are not supported by this runtime");
+	}
 	if (in.ptr == nullptr || in.width != fs.inputWidth || in.height != fs.inputHeight) {
 		throw std::invalid_argument("processImage: input image must be exactly " +
 		                            std::to_string(fs.inputWidth) + "x" +
@@ -436,6 +440,10 @@ void Engine::stageIn(const Frame &in) {
 
 void Engine::stageOut(const Frame &out) {
 	const FrameSize fs = frameSize();
+	if (out.location == Location::GraphicsResource) {
+		throw std::invalid_argument(
+		    "processImage: GRAPHICS_RESOURCE images are not supported by this runtime");
+	}
 	if (out.ptr == nullptr || out.width != fs.outputWidth || out.height != fs.outputHeight) {
 		throw std::invalid_argument("processImage: output image must be exactly " +
 		                            std::to_string(fs.outputWidth) + "x" +

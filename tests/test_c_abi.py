@@ -1,0 +1,72 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares (CPU).
+No compute call is made here: there is no GPU in the CPU test environment."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import M, ROOT
+from joshupscale_amd import runtime as R
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "joshupscale_amd.h")).read()
+    return sorted(set(re.findall(r"JU_API\s+[\w\s\*]+?\b(ju_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ["ju_create", "ju_create_from_memory", "ju_destroy", "ju_process", "ju_get_size",
+                 "ju_reset", "ju_last_error", "ju_set_log_callback"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(hip_library):
+    for name in declared_functions():
+        assert hasattr(hip_library, name), name
+
+
+def test_cxx_plugin_surface_is_exported():
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", R.library_path()]).decode()
+    for sym in ["createRuntime", "getExceptionString", "setLogSink", "getGLImage",
+                "getGLDeviceIndex"]:
+        assert re.search(r"_ZN11JoshUpscale4core\d+" + sym, out), sym
+
+
+def test_image_struct_matches_core_h_layout():
+    # struct Image {void*; uint8; ptrdiff_t; size_t; size_t} (reference core.h:32-38)
+    assert C.sizeof(R.JuImage) == 40
+    assert R.JuImage.stride.offset == 16 and R.JuImage.width.offset == 24
+
+
+def test_version_and_error_paths_without_gpu(hip_library, tmp_path):
+    assert hip_library.ju_version().decode().startswith("joshupscale-amd")
+    h = C.c_void_p()
+    rc = hip_library.ju_create(0, str(tmp_path / "missing.jupw").encode(), C.byref(h))
+    assert rc == 2 and not h.value                      # JU_ERR_IO
+    assert b"cannot open model file" in hip_library.ju_last_error()
+    assert hip_library.ju_process(None, None, None) == 1  # JU_ERR_INVALID_ARGUMENT
+    assert hip_library.ju_get_gl_device_index(None) == 4  # JU_ERR_UNSUPPORTED
+    hip_library.ju_destroy(None)                          # no-op
+
+
+def test_log_callback_receives_errors(hip_library):
+    seen = []
+    cb = R.LOG_CALLBACK(lambda tag, lvl, msg, user: seen.append((tag, lvl, msg)))
+    hip_library.ju_set_log_callback(cb, None)
+    try:
+        hip_library.ju_reset(None)
+    finally:
+        hip_library.ju_set_log_callback(R.LOG_CALLBACK(0), None)
+    assert seen and seen[0][1] == 2 and b"runtime is NULL" in seen[0][2]
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(R, "_LIB", None)
+    monkeypatch.setattr(R, "_LIB_NAME", "libDoesNotExist.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        R.load_library()

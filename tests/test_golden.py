@@ -1,0 +1,69 @@
+"""The restatements reproduce the committed golden vectors (CPU)."""
+
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from helpers import M, O, ROOT, oracle_config, small_config
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SMALL = {
+    "small_autoencoder": small_config(),
+    "small_resnet": small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2,
+                                 frame_height=34, frame_width=50),
+    "small_noise": small_config(gen_blocks=2),
+}
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_numpy_oracle_reproduces_small_goldens(name):
+    g = load(name)
+    cfg = SMALL[name]
+    wts = M.make_seeded_weights(cfg, seed=42)
+    assert hashlib.sha256(M.serialize(cfg, wts)).hexdigest() == str(g["model_sha256"]), \
+        "seeded weights changed: regenerate with tests/golden/make_golden.py"
+    sess = O.Session(wts, oracle_config(cfg))
+    for t, frame in enumerate(g["frames"]):
+        out = sess.run(frame)
+        assert np.array_equal(out, g["outputs"][t]), (name, t)
+    assert np.abs(sess.last.output_raw - g["output_raw_last"]).max() < 1e-6
+    assert np.abs(sess.last.flow - g["flow_last"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_c_restatement_matches_small_goldens(name):
+    from oracle.c_binding import CSession
+    g = load(name)
+    cfg = SMALL[name]
+    cs = CSession(M.serialize(cfg, M.make_seeded_weights(cfg, seed=42)), cfg.frame_height,
+                  cfg.frame_width)
+    for t, frame in enumerate(g["frames"]):
+        out = cs.run(frame)
+        d = np.abs(out.astype(int) - g["outputs"][t].astype(int))
+        assert d.max() <= 1 and np.mean(d > 0) < 0.01, (name, t)   # fp32 vs fp64 truncation
+    assert np.abs(cs.output_raw() - g["output_raw_last"]).max() < 5e-5
+
+
+def test_c_restatement_matches_full_size_golden_first_frame():
+    """One 480x270 frame of the BASELINE.json configuration (a few seconds)."""
+    from oracle.c_binding import CSession
+    g = load("full_psp_quality")
+    cfg = M.PRESETS["psp-quality"]
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=42))
+    assert hashlib.sha256(blob).hexdigest() == str(g["model_sha256"])
+    frames = M.synthetic_frames(int(g["n_frames"]), 270, 480, seed=int(g["seed"]), kind="smooth")
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
+    cs = CSession(blob, 270, 480)
+    out = cs.run(frames[0])
+    raw = cs.output_raw()
+    for k, (y, x) in enumerate(g["crops"]):
+        d = np.abs(out[y:y + 64, x:x + 64, :3].astype(int) - g["crops_u8"][0, k].astype(int))
+        assert d.max() <= 1
+        assert np.abs(raw[y:y + 64, x:x + 64] - g["crops_raw"][0, k]).max() < 1e-4
+    assert np.abs(out[..., :3].reshape(-1, 3).mean(0) - g["means"][0]).max() < 0.01

@@ -1,0 +1,63 @@
+"""Model container round trip and header layout (CPU)."""
+
+import struct
+
+import numpy as np
+import pytest
+
+from helpers import M
+
+
+def test_roundtrip_all_presets():
+    for name, cfg in M.PRESETS.items():
+        small = M.ModelConfig(**{**cfg.__dict__, "gen_blocks": 1, "flow_res_blocks": 1})
+        w = M.make_seeded_weights(small)
+        cfg2, w2 = M.deserialize(M.serialize(small, w))
+        assert cfg2.__dict__ | {"bn_eps": 0} == small.__dict__ | {"bn_eps": 0}, name
+        assert cfg2.bn_eps == pytest.approx(small.bn_eps)
+        assert list(w) == list(w2)
+        assert all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+def test_header_layout_and_alignment():
+    cfg = M.ModelConfig(gen_blocks=1)
+    w = M.make_seeded_weights(cfg)
+    blob = M.serialize(cfg, w)
+    assert blob[:8] == b"JUPWGT\x00\x01"
+    version, header = struct.unpack_from("<2I", blob, 8)
+    assert (version, header) == (1, 128)
+    assert struct.unpack_from("<4I", blob, 16) == (270, 480, 4, 4)
+    n = struct.unpack_from("<I", blob, 104)[0]
+    assert n == len(w)
+    assert struct.calcsize("<92sI4IQQ") == M.ENTRY_BYTES
+    for i in range(n):
+        off = struct.unpack_from("<Q", blob, 128 + i * 128 + 112)[0]
+        assert off % 64 == 0
+
+
+def test_rejects_foreign_files():
+    with pytest.raises(ValueError):
+        M.deserialize(b"\x00" * 256)          # e.g. a TensorRT engine
+    with pytest.raises(ValueError):
+        M.deserialize(b"JUPWGT")
+
+
+def test_seeded_weights_are_deterministic_and_named_like_keras():
+    cfg = M.ModelConfig(gen_blocks=2)
+    a = M.make_seeded_weights(cfg, seed=42)
+    b = M.make_seeded_weights(cfg, seed=42)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert a["generator/conv_1/kernel"].shape == (3, 3, 51, 64)
+    assert a["generator/conv_trans_1/kernel"].shape == (2, 2, 32, 64)
+    assert a["generator/conv_trans_2/kernel"].shape == (2, 2, 3, 32)
+    assert a["flow/block_1/conv_1/kernel"].shape == (3, 3, 12, 32)
+    assert a["flow/conv_2/kernel"].shape == (3, 3, 32, 32)
+    assert "generator/block_2/bn_2/moving_variance" in a
+
+
+def test_synthetic_frames_contract():
+    f = M.synthetic_frames(2, 30, 48, seed=1234)
+    assert f.shape == (2, 30, 48, 4) and f.dtype == np.uint8 and (f[..., 3] == 255).all()
+    assert np.array_equal(f, M.synthetic_frames(2, 30, 48, seed=1234))
+    s = M.synthetic_frames(3, 30, 48, kind="smooth")
+    assert np.array_equal(s[0, :, 1:, :3], s[1, :, :-1, :3])  # translates 1 px / frame

@@ -1,0 +1,52 @@
+"""The three restatements agree with each other (CPU)."""
+
+import numpy as np
+import pytest
+
+from helpers import M, O, err, oracle_config, small_config, u8_stats
+from torch_restatement import TorchSession
+
+
+@pytest.mark.parametrize("arch,pad,h,w", [("autoencoder", 8, 30, 48), ("resnet", 0, 20, 24),
+                                          ("autoencoder", 8, 17, 33)])
+def test_numpy_oracle_vs_torch_restatement(arch, pad, h, w):
+    cfg = small_config(frame_height=h, frame_width=w, flow_arch=arch, flow_pad_factor=pad,
+                       flow_res_blocks=2)
+    wts = M.make_seeded_weights(cfg)
+    s = O.Session(wts, oracle_config(cfg))
+    ts = TorchSession(wts, oracle_config(cfg))
+    frames = M.synthetic_frames(3, h, w, kind="smooth")
+    for t in range(3):
+        a = s.run(frames[t])
+        b = ts.run(frames[t])
+        raw = ts.output_raw[0].permute(1, 2, 0).numpy()
+        assert np.abs(raw - s.last.output_raw).max() <= 1e-9   # float64 both sides
+        assert np.abs(a.astype(int) - b.astype(int)).max() <= 1  # truncation boundary only
+        assert (a[..., 3] == 0).all()
+
+
+@pytest.mark.parametrize("arch,pad", [("autoencoder", 8), ("resnet", 0)])
+def test_c_restatement_vs_numpy_oracle(arch, pad):
+    from oracle.c_binding import CSession
+    cfg = small_config(flow_arch=arch, flow_pad_factor=pad, flow_res_blocks=2)
+    wts = M.make_seeded_weights(cfg)
+    s = O.Session(wts, oracle_config(cfg))
+    cs = CSession(M.serialize(cfg, wts), cfg.frame_height, cfg.frame_width)
+    frames = M.synthetic_frames(4, cfg.frame_height, cfg.frame_width, kind="smooth")
+    for t in range(4):
+        a = s.run(frames[t])
+        b = cs.run(frames[t])
+        assert err(cs.output_raw(), s.last.output_raw)["max_abs"] < 2e-5  # fp32 vs fp64
+        st = u8_stats(b, a)
+        assert st["max"] <= 1 and (b[..., 3] == 0).all()
+
+
+def test_x_byte_is_ignored_by_the_oracle():
+    cfg = small_config(gen_blocks=1)
+    wts = M.make_seeded_weights(cfg)
+    f = M.synthetic_frames(1, 30, 48)[0]
+    g = f.copy()
+    g[..., 3] = 0
+    a = O.Session(wts, oracle_config(cfg)).run(f)
+    b = O.Session(wts, oracle_config(cfg)).run(g)
+    assert np.array_equal(a, b)

@@ -1,0 +1,145 @@
+"""Known-answer tests of the oracle's primitives (CPU).
+
+The reference has no tests, so every primitive of the
+restatement is pinned by a property the reference's own definition implies."""
+
+import numpy as np
+import pytest
+
+from helpers import O
+
+
+def test_preprocess_postprocess_roundtrip_all_256_values():
+    # keras_layers.py:208, 227-230 + truncating cast: document the exact behaviour
+    v = np.arange(256, dtype=np.uint8).reshape(1, 256, 1).repeat(3, axis=2)
+    back64 = O.postprocess(O.preprocess(v, np.float64))
+    back32 = np.trunc((O.preprocess(v, np.float32) + np.float32(0.5)) * np.float32(255)).astype(np.uint8)
+    # float64: (v/255 - 0.5 + 0.5) * 255 can land just below v and truncate to v-1
+    assert np.abs(back64.astype(int) - v.astype(int)).max() <= 1
+    assert np.abs(back32.astype(int) - v.astype(int)).max() <= 1
+    assert (back64 <= v).all()
+
+
+def test_space_to_depth_channel_order_and_inverse():
+    x = np.arange(8 * 12 * 3, dtype=np.float64).reshape(8, 12, 3)
+    y = O.space_to_depth(x, 4)
+    assert y.shape == (2, 3, 48)
+    for i in range(4):
+        for j in range(4):
+            for c in range(3):
+                assert y[1, 2, (i * 4 + j) * 3 + c] == x[4 + i, 8 + j, c]
+    assert np.array_equal(O.depth_to_space(y, 4), x)
+
+
+def test_depth_to_space_dcr_order():
+    x = np.arange(2 * 3 * 32, dtype=np.float64).reshape(2, 3, 32)
+    y = O.depth_to_space(x, 4)
+    assert y.shape == (8, 12, 2)
+    for i in range(4):
+        for j in range(4):
+            for c in range(2):
+                assert y[4 + i, 8 + j, c] == x[1, 2, (i * 4 + j) * 2 + c]
+
+
+def test_resize_bilinear_tf1_ramp_and_edge_clamp():
+    # asymmetric mapping src = dst/scale: a linear ramp stays linear until the
+    # last `scale-1` outputs, which clamp to the last input sample
+    x = np.arange(6, dtype=np.float64).reshape(1, 6, 1).repeat(2, axis=0)
+    y = O.resize_bilinear_tf1(x, 4)
+    assert y.shape == (8, 24, 1)
+    expect = np.minimum(np.arange(24) / 4.0, 5.0)
+    assert np.allclose(y[0, :, 0], expect)
+    assert np.allclose(y[7, :, 0], expect)  # rows identical -> vertical lerp is a no-op
+    assert np.array_equal(y[::4, ::4], x)   # phase 0 reproduces the input
+
+
+def test_warp_zero_flow_is_identity():
+    rng = np.random.default_rng(0)
+    img = rng.normal(size=(9, 11, 3))
+    out = O.dense_image_warp(img, np.zeros((9, 11, 2)))
+    # interior: alpha == 0, exact.  Last row/column: floor is clamped to size-2 and
+    # alpha == 1, so the reference formula gives (b - a) + a, equal only to rounding.
+    assert np.array_equal(out[:-1, :-1], img[:-1, :-1])
+    assert np.allclose(out, img, rtol=0, atol=1e-15)
+
+
+def test_warp_integer_shift_with_border_clamp():
+    rng = np.random.default_rng(1)
+    img = rng.normal(size=(8, 10, 3))
+    flow = np.zeros((8, 10, 2))
+    flow[..., 0] = 2.0   # out[y, x] = img[y - 2, x + 3], clamped to the border
+    flow[..., 1] = -3.0
+    out = O.dense_image_warp(img, flow)
+    ys = np.clip(np.arange(8) - 2, 0, 7)
+    xs = np.clip(np.arange(10) + 3, 0, 9)
+    assert np.allclose(out, img[ys][:, xs])
+
+
+def test_warp_fractional_matches_manual_bilinear():
+    img = np.arange(5 * 6, dtype=np.float64).reshape(5, 6, 1)
+    flow = np.zeros((5, 6, 2))
+    flow[..., 0] = 0.25
+    flow[..., 1] = -0.5
+    out = O.dense_image_warp(img, flow)
+    y, x = 2, 3  # query (1.75, 3.5)
+    manual = (img[1, 3, 0] * 0.5 + img[1, 4, 0] * 0.5) * 0.25 + (img[2, 3, 0] * 0.5 + img[2, 4, 0] * 0.5) * 0.75
+    assert np.isclose(out[y, x, 0], manual)
+
+
+def test_conv2d_same_against_direct_loops():
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(5, 7, 3))
+    k = rng.normal(size=(3, 3, 3, 4))
+    y = O.conv2d_same(x, k)
+    xp = np.pad(x, ((1, 1), (1, 1), (0, 0)))
+    ref = np.zeros((5, 7, 4))
+    for h in range(5):
+        for w in range(7):
+            for o in range(4):
+                ref[h, w, o] = np.sum(xp[h:h + 3, w:w + 3, :] * k[:, :, :, o])
+    assert np.allclose(y, ref)
+
+
+def test_conv_transpose_no_overlap_definition():
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(3, 4, 5))
+    k = rng.normal(size=(2, 2, 6, 5))
+    b = rng.normal(size=6)
+    y = O.conv2d_transpose_k2s2(x, k, b)
+    assert y.shape == (6, 8, 6)
+    for a in range(2):
+        for bb in range(2):
+            assert np.allclose(y[2 * 1 + a, 2 * 2 + bb], k[a, bb] @ x[1, 2] + b)
+
+
+def test_max_pool_and_batch_norm():
+    x = np.arange(4 * 6 * 2, dtype=np.float64).reshape(4, 6, 2)
+    p = O.max_pool_2x2(x)
+    assert p.shape == (2, 3, 2)
+    assert p[0, 0, 0] == x[1, 1, 0] and p[1, 2, 1] == x[3, 5, 1]
+    y = O.batch_norm(np.ones((1, 1, 2)), np.array([2.0, 3.0]), np.array([0.5, -0.5]),
+                     np.array([0.0, 1.0]), np.array([1.0, 4.0]), 0.0)
+    assert np.allclose(y[0, 0], [2.5, -0.5])
+
+
+def test_state_shift_register_and_padding():
+    from helpers import M, oracle_config, small_config
+    cfg = small_config(gen_blocks=1)
+    oc = oracle_config(cfg)
+    assert (oc.padded_height, oc.padded_width) == (32, 48)
+    sess = O.Session(M.make_seeded_weights(cfg), oc)
+    frames = M.synthetic_frames(3, 30, 48, kind="noise")
+    for t in range(3):
+        sess.run(frames[t])
+    # last_frames[0] is the most recent padded frame; pad rows are exactly zero
+    lf = sess.state.last_frames
+    assert np.array_equal(lf[0][1:31], O.preprocess(frames[2][..., :3]))
+    assert np.array_equal(lf[1][1:31], O.preprocess(frames[1][..., :3]))
+    assert np.array_equal(lf[2][1:31], O.preprocess(frames[0][..., :3]))
+    assert not lf[0][0].any() and not lf[0][31].any()
+    assert np.array_equal(sess.state.pre_gen, sess.last.output_raw)
+
+
+def test_macs_match_survey():
+    m = O.macs_per_frame(O.ModelConfig())
+    assert m["generator"] == 234391449600 and m["flow"] == 17898209280
