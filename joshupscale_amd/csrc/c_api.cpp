@@ -186,6 +186,14 @@ int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_pe
 	});
 }
 
+int ju_debug_set(const char *key, int value) {
+	return guarded([&] {
+		const std::string k = key ? key : "";
+		if (k == "tower_variant") ju::setTowerVariant(value);
+		else throw std::invalid_argument("unknown debug key " + k);
+	});
+}
+
 const char *ju_version(void) {
 	return "joshupscale-amd 0.1 (gfx950)";
 }

@@ -51,6 +51,25 @@ Engine::Tensor &Engine::addTensor(
 	return res.first->second;
 }
 
+Engine::Tensor &Engine::addTowerTensor(const std::string &name, int H, int W, int C) {
+	Tensor &t = addTensor(name, towerPixels(H, W) * C);
+	t.towerH = H;
+	t.towerW = W;
+	t.towerC = C;
+	return t;
+}
+
+Engine::Operand Engine::operand(const std::string &name) {
+	Tensor &t = m_Tensors.at(name);
+	Operand o;
+	o.ptr = t.buf.get();
+	if (t.towerC) {
+		o.pitch = towerPitch(t.towerW);
+		o.ptr = t.buf.as<unsigned char>() + towerOrigin(t.towerW) * t.towerC * 2;
+	}
+	return o;
+}
+
 Engine::ConvWeights &Engine::addConv(
     const std::string &name, const FoldedConv &f, const std::vector<int> &cinMap) {
 	ConvWeights cw;
@@ -133,17 +152,20 @@ void Engine::buildWeights(const ModelFile &model) {
 }
 
 void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
-    const std::string &wname, const void *in, const void *res, void *out, int H, int W,
+    const std::string &wname, Operand in, Operand res, Operand out, int H, int W,
     bool relu, bool outF32, bool tower) {
 	auto it = m_Convs.find(wname);
 	if (it == m_Convs.end()) throw std::logic_error("missing conv weights " + wname);
 	const ConvWeights &cw = it->second;
 	ConvParams p{};
-	p.in = in;
+	p.in = in.ptr;
 	p.wgt = cw.w.get();
 	p.bias = cw.bias.as<float>();
-	p.res = res;
-	p.out = out;
+	p.res = res.ptr;
+	p.out = out.ptr;
+	p.inPitch = in.pitch;
+	p.resPitch = res.pitch;
+	p.outPitch = out.pitch;
 	p.H = H;
 	p.W = W;
 	p.cin = cw.cinP;
@@ -179,23 +201,25 @@ void Engine::buildProgram(int set) {
 	void *stateOut = m_State[set ^ 1].get();
 	const int nIn = c.numFlowInputs;
 	auto T = [&](const std::string &n) -> void * { return m_Tensors.at(n).buf.get(); };
+	auto Op = [&](const std::string &n) { return operand(n); };
+	const Operand none{};
 
 	prog.push_back({"pack", 0.0, [=](hipStream_t s) {
 		                launchPackFrames(dt, frame, fstride, packedIn, packedOut, H, W, PH, PW,
 		                    padTop, padLeft, nIn, s);
 	                }});
 	// ---- flow net ----
-	const void *cur = packedOut;
+	Operand cur{packedOut, 0};
 	int h = PH, w = PW;
 	if (c.flowArch == 0) {
 		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
 		for (int i = 0; i < 2 * nb; ++i) {
 			const std::string n = "flow/block_" + std::to_string(i + 1);
 			const int f = c.flowFilters[i];
-			addConvStep(&prog, "flow", n + "/conv_1", cur, nullptr, T(n + "/a_1"), h, w, true, false);
-			addConvStep(&prog, "flow", n + "/conv_2", T(n + "/a_1"), nullptr, T(n + "/a_2"), h, w,
+			addConvStep(&prog, "flow", n + "/conv_1", cur, none, Op(n + "/a_1"), h, w, true, false);
+			addConvStep(&prog, "flow", n + "/conv_2", Op(n + "/a_1"), none, Op(n + "/a_2"), h, w,
 			    true, false);
-			const void *src = T(n + "/a_2");
+			const void *src = T(n + "/a_2");  // dense tensors
 			void *dst = T(n + "/resample");
 			if (i < nb) {
 				prog.push_back({"flow", 0.0,
@@ -208,26 +232,26 @@ void Engine::buildProgram(int set) {
 				h *= 2;
 				w *= 2;
 			}
-			cur = dst;
+			cur = Operand{dst, 0};
 		}
 		if (c.flowFilters.size() % 2) {
-			addConvStep(&prog, "flow", "flow/conv_1", cur, nullptr, T("flow/a_1"), h, w, true, false);
-			cur = T("flow/a_1");
+			addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/a_1"), h, w, true, false);
+			cur = Op("flow/a_1");
 		}
 	} else {
-		addConvStep(&prog, "flow", "flow/conv_1", cur, nullptr, T("flow/x0"), h, w, true, false);
+		addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/x0"), h, w, true, false);
 		const char *xs[2] = {"flow/x0", "flow/x1"};
 		int a = 0;
 		for (int i = 0; i < c.flowResBlocks; ++i) {
 			const std::string n = "flow/block_" + std::to_string(i + 1);
-			addConvStep(&prog, "flow", n + "/conv_1", T(xs[a]), nullptr, T("flow/t"), h, w, true, false);
-			addConvStep(&prog, "flow", n + "/conv_2", T("flow/t"), T(xs[a]), T(xs[a ^ 1]), h, w, true,
-			    false);
+			addConvStep(&prog, "flow", n + "/conv_1", Op(xs[a]), none, Op("flow/t"), h, w, true, false);
+			addConvStep(&prog, "flow", n + "/conv_2", Op("flow/t"), Op(xs[a]), Op(xs[a ^ 1]), h, w,
+			    true, false);
 			a ^= 1;
 		}
-		cur = T(xs[a]);
+		cur = Op(xs[a]);
 	}
-	addConvStep(&prog, "flow", "flow/conv_2", cur, nullptr, T("flow"), h, w, false, true);
+	addConvStep(&prog, "flow", "flow/conv_2", cur, none, Op("flow"), h, w, false, true);
 	// ---- warp + space-to-depth + concat ----
 	{
 		const float *flow = static_cast<const float *>(T("flow"));
@@ -238,20 +262,20 @@ void Engine::buildProgram(int set) {
 		                }});
 	}
 	// ---- generator ----
-	addConvStep(&prog, "gen_head", "generator/conv_1", T("gen_in"), nullptr, T("trunk_a"), H, W,
+	addConvStep(&prog, "gen_head", "generator/conv_1", Op("gen_in"), none, Op("trunk_a"), H, W,
 	    true, false);
 	const char *xs[2] = {"trunk_a", "trunk_b"};
 	int a = 0;
 	for (int i = 0; i < c.genBlocks; ++i) {
 		const std::string n = "generator/block_" + std::to_string(i + 1);
-		addConvStep(&prog, "tower", n + "/conv_1", T(xs[a]), nullptr, T("trunk_t"), H, W, true,
+		addConvStep(&prog, "tower", n + "/conv_1", Op(xs[a]), none, Op("trunk_t"), H, W, true,
 		    false, true);
-		addConvStep(&prog, "tower", n + "/conv_2", T("trunk_t"), T(xs[a]), T(xs[a ^ 1]), H, W, true,
-		    false, true);
+		addConvStep(&prog, "tower", n + "/conv_2", Op("trunk_t"), Op(xs[a]), Op(xs[a ^ 1]), H, W,
+		    true, false, true);
 		a ^= 1;
 	}
 	m_TrunkOut = xs[a];
-	addConvStep(&prog, "tail", "generator/conv_trans_1", T(xs[a]), nullptr, T("tail_y"), H, W, true,
+	addConvStep(&prog, "tail", "generator/conv_trans_1", Op(xs[a]), none, Op("tail_y"), H, W, true,
 	    false);
 	{
 		const void *y = T("tail_y");
@@ -332,9 +356,9 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	}
 	addTensor("flow", plr * 32, true);
 	addTensor("gen_in", lr * 64);
-	addTensor("trunk_a", lr * c.genFilters);
-	addTensor("trunk_b", lr * c.genFilters);
-	addTensor("trunk_t", lr * c.genFilters);
+	addTowerTensor("trunk_a", H, W, c.genFilters);
+	addTowerTensor("trunk_b", H, W, c.genFilters);
+	addTowerTensor("trunk_t", H, W, c.genFilters);
 	addTensor("tail_y", lr * 128);
 
 	buildProgram(0);
@@ -526,6 +550,7 @@ std::size_t Engine::readTensor(const std::string &name, float *dst, std::size_t 
 	const void *src = nullptr;
 	std::size_t count = 0;
 	bool f32 = false;
+	const Tensor *tw = nullptr;
 	DType dt = m_DType;
 	const std::size_t lr = static_cast<std::size_t>(m_Config.frameHeight) * m_Config.frameWidth;
 	if (name == "state") {  // the state the NEXT frame will read = last output_raw
@@ -542,9 +567,12 @@ std::size_t Engine::readTensor(const std::string &name, float *dst, std::size_t 
 		src = it->second.buf.get();
 		count = it->second.count;
 		f32 = it->second.isF32;
+		if (it->second.towerC) tw = &it->second;
 	}
-	if (dst == nullptr) return count;
-	if (capacity < count) throw std::invalid_argument("readTensor: buffer too small");
+	const std::size_t outCount =
+	    tw ? static_cast<std::size_t>(tw->towerH) * tw->towerW * tw->towerC : count;
+	if (dst == nullptr) return outCount;
+	if (capacity < outCount) throw std::invalid_argument("readTensor: buffer too small");
 	m_Stream.synchronize();
 	if (f32) {
 		JU_HIP(hipMemcpy(dst, src, count * 4, hipMemcpyDeviceToHost));
@@ -552,9 +580,17 @@ std::size_t Engine::readTensor(const std::string &name, float *dst, std::size_t 
 		DeviceBuffer tmp(count * 4);
 		launchToFloat(dt, src, tmp.as<float>(), count, m_Stream);
 		m_Stream.synchronize();
-		JU_HIP(hipMemcpy(dst, tmp.get(), count * 4, hipMemcpyDeviceToHost));
+		if (tw) {  // strip the zero border of the tower layout: dense [H][W][C] out
+			const std::size_t rowElems = static_cast<std::size_t>(tw->towerW) * tw->towerC;
+			JU_HIP(hipMemcpy2D(dst, rowElems * 4,
+			    tmp.as<float>() + towerOrigin(tw->towerW) * tw->towerC,
+			    static_cast<std::size_t>(towerPitch(tw->towerW)) * tw->towerC * 4, rowElems * 4,
+			    tw->towerH, hipMemcpyDeviceToHost));
+		} else {
+			JU_HIP(hipMemcpy(dst, tmp.get(), count * 4, hipMemcpyDeviceToHost));
+		}
 	}
-	return count;
+	return outCount;
 }
 
 double Engine::flopsOf(const std::string &tag) const {

@@ -82,6 +82,13 @@ private:
 		std::size_t count = 0;
 		bool isF32 = false;
 		bool isState = false;  // f16 regardless of the compute dtype
+		int towerH = 0, towerW = 0, towerC = 0;  // != 0: zero-bordered tower layout
+	};
+	// A tensor as a conv operand: pointer to image pixel (0,0) + row pitch in pixels
+	// (0 = dense).
+	struct Operand {
+		void *ptr = nullptr;
+		int pitch = 0;
 	};
 	struct Step {
 		std::string tag;
@@ -99,8 +106,10 @@ private:
 	ConvWeights &addConv(const std::string &name, const FoldedConv &f,
 	    const std::vector<int> &cinMap);
 	void addConvStep(std::vector<Step> *prog, const std::string &tag, const std::string &wname,
-	    const void *in, const void *res, void *out, int H, int W, bool relu, bool outF32,
+	    Operand in, Operand res, Operand out, int H, int W, bool relu, bool outF32,
 	    bool tower = false);
+	Operand operand(const std::string &name);
+	Tensor &addTowerTensor(const std::string &name, int H, int W, int C);
 	void buildWeights(const ModelFile &model);
 	void buildProgram(int set);
 	void stageIn(const Frame &in);

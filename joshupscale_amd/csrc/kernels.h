@@ -35,7 +35,23 @@ struct ConvParams {
 	int taps;    // 9 (3x3 "same") or 1 (1x1)
 	int relu;    // apply max(x, 0)
 	int outF32;  // store f32 instead of the 16-bit type
+	// Row pitches in pixels (0 = dense, i.e. W).  The pointers address image
+	// pixel (0,0); a tensor kept in the zero-bordered tower layout (below) is
+	// passed as its interior origin plus its pitch.
+	int inPitch, outPitch, resPitch;
 };
+
+// Zero-bordered activation layout of the generator trunk ("tower layout"):
+// [towerRows(H)][towerPitch(W)][C] with the image at row/column offset 1.  The
+// one-pixel border and the rows/columns beyond the image are zero and are never
+// written, so the persistent tower kernel stages tiles with no bounds checks and
+// gets the convolution's zero padding for free.
+inline int towerPitch(int W) { return (W + 31) / 32 * 32 + 2; }
+inline int towerRows(int H) { return (H + 7) / 8 * 8 + 2; }
+inline std::size_t towerPixels(int H, int W) {
+	return static_cast<std::size_t>(towerRows(H)) * towerPitch(W);
+}
+inline std::size_t towerOrigin(int W) { return static_cast<std::size_t>(towerPitch(W)) + 1; }
 
 // Channel chunk / cout-block choice shared by the launcher and the packer.
 inline int convCK(int cin) { return cin % 64 == 0 ? 64 : (cin % 32 == 0 ? 32 : 16); }
@@ -43,9 +59,13 @@ inline int convNB(int cout) { return cout % 64 == 0 ? 2 : 1; }
 
 void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
 
-// Specialised 64->64 3x3 kernel of the generator tower (falls back to
-// launchConv when the shape does not match).
+// Persistent 3x3 64->64 kernel of the generator tower.  in/res/out must be
+// tower-layout tensors addressed at their interior origin with
+// pitch == towerPitch(W); other shapes fall back to launchConv.
 void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream);
+
+// Timing-only ablation switch of the tower kernel (0 = product kernel).
+void setTowerVariant(int variant);
 
 // ---- flow-net helpers -------------------------------------------------------
 // cur frame (u8 BGRX, signed row stride) + previous packed history ->

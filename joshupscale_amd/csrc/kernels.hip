@@ -102,6 +102,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 	const int ty0 = blockIdx.y * TH;
 	const int cog = blockIdx.z;
 	const int nCC = p.cin / CK;
+	const int inPitch = p.inPitch ? p.inPitch : p.W;
+	const int outPitch = p.outPitch ? p.outPitch : p.W;
+	const int resPitch = p.resPitch ? p.resPitch : p.W;
 	const T *__restrict__ in = static_cast<const T *>(p.in);
 	const T *__restrict__ wgt = static_cast<const T *>(p.wgt);
 
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 			uint4 v = make_uint4(0, 0, 0, 0);
 			if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
 				v = *reinterpret_cast<const uint4 *>(
-				    in + ((size_t)gy * p.W + gx) * p.cin + cc * CK + c * 8);
+				    in + ((size_t)gy * inPitch + gx) * p.cin + cc * CK + c * 8);
 			}
 			*reinterpret_cast<uint4 *>(smI + q * (CK * 2) + ((c ^ swz<P>(q)) << 4)) = v;
 		}
@@ -181,18 +184,20 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 	for (int rw = 0; rw < RW; ++rw) {
 		const int gy = ty0 + wave * RW + rw;
 		if (gy >= p.H || gx >= p.W) continue;
-		const size_t pixOff = ((size_t)gy * p.W + gx) * p.cout + cog * COG;
+		const size_t pixOff = ((size_t)gy * outPitch + gx) * p.cout + cog * COG;
+		const size_t resOff = ((size_t)gy * resPitch + gx) * p.cout + cog * COG;
 #pragma unroll
 		for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
 				const size_t off = pixOff + nb * 32 + 8 * g + 4 * hh;
+				const size_t roff = resOff + nb * 32 + 8 * g + 4 * hh;
 				float v[4];
 #pragma unroll
 				for (int i = 0; i < 4; ++i) v[i] = acc[nb][rw][4 * g + i];
 				if (p.res != nullptr) {
 					const Vec4<T> r =
-					    *reinterpret_cast<const Vec4<T> *>(static_cast<const T *>(p.res) + off);
+					    *reinterpret_cast<const Vec4<T> *>(static_cast<const T *>(p.res) + roff);
 #pragma unroll
 					for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(r[i]);
 				}
@@ -262,6 +267,338 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 	JU_CONV_CASE(1, 32, 1)
 #undef JU_CONV_CASE
 	throw std::invalid_argument("conv: unsupported shape");
+}
+
+
+// ---------------------------------------------------------------------------
+// persistent 3x3 64->64 convolution of the generator's residual tower
+// ---------------------------------------------------------------------------
+// One workgroup per CU (grid = min(#tiles, 256)), 4 waves, one per SIMD.  The
+// 72 KiB of kernel-ready weights are DMA'd into LDS once per workgroup; input
+// tiles (8 rows x 32 px + halo = 10 x 34 px x 128 B) are double-buffered and
+// fetched with global_load_lds (no VGPR round trip) while the previous tile is on
+// the matrix cores.  Activations live in the zero-bordered tower layout, so tile
+// staging has no bounds checks.  LDS: 73728 + 2 * 43520 = 160768 B of 163840.
+//
+// LDS-DMA writes lane-linear (base + lane*16), so the bank-conflict swizzle is
+// applied to each lane's SOURCE chunk and again on the fragment read.
+constexpr int kTowerThreads = 256;
+constexpr int kTowerWBytes = 9 * 64 * 64 * 2;
+constexpr int kTowerTileBytes = 10 * 34 * 128;
+constexpr int kTowerLds = kTowerWBytes + 2 * kTowerTileBytes;
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+	    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+struct TowerParams {
+	const void *in;    // tower-layout allocation start (row -1, col -1 of the image)
+	const void *wgt;
+	const float *bias;
+	const void *res;   // allocation start or nullptr
+	void *out;         // allocation start
+	int H, W, pitch;   // pitch in pixels
+	int tilesX, numTiles;
+	int relu;
+};
+
+// VARIANT is a timing-only ablation switch (tools/tower_ablation.py); 0 is the
+// product kernel.  1: no MFMA loop, 2: no epilogue loads/stores, 3: no tile
+// staging, 4: no weight staging.  Variants != 0 compute garbage by design.
+template <typename T, int VARIANT>
+__global__ __launch_bounds__(kTowerThreads, 1) void conv_tower_kernel(TowerParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	unsigned char *smW = smem;
+	unsigned char *smT = smem + kTowerWBytes;
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6;
+	const int lane = tid & 63;
+	const int px = lane & 31;
+	const int hh = lane >> 5;
+	const T *__restrict__ in = static_cast<const T *>(p.in);
+
+	// XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2);
+	// give each XCD a contiguous run of tiles so vertically adjacent tiles find
+	// their shared halo rows in L2.
+	const int nwg = gridDim.x;
+	const int bid = blockIdx.x;
+	const int perX = (nwg + 7) >> 3;
+	const int slot = (bid & 7) * perX + (bid >> 3);  // may exceed nwg-1 when nwg % 8 != 0
+
+	auto stageTile = [&](int tile, int buf) {
+		const int ty = tile / p.tilesX;
+		const int tx = tile - ty * p.tilesX;
+		const T *base = in + ((size_t)(ty * 8) * p.pitch + tx * 32) * 64;
+		unsigned char *dst = smT + buf * kTowerTileBytes;
+#pragma unroll
+		for (int k = 0; k < (VARIANT == 3 ? 0 : 11); ++k) {
+			const int i = wave + 4 * k;          // wave-instruction index: 8 pixels each
+			const int q = i * 8 + (lane >> 3);   // pixel index inside the 10 x 34 tile
+			if (i < 43 && q < 340) {
+				const int r = q / 34;
+				const int x = q - r * 34;
+				const int c = (lane & 7) ^ ((q >> 1) & 7);
+				glds16(base + ((size_t)r * p.pitch + x) * 64 + c * 8, dst + i * 1024);
+			}
+		}
+	};
+
+	// ---- prologue: weights + first tile in flight together ----
+	{
+		const unsigned char *wsrc = static_cast<const unsigned char *>(p.wgt);
+#pragma unroll
+		for (int k = 0; k < (VARIANT == 4 ? 0 : 18); ++k) {
+			const int i = wave + 4 * k;
+			glds16(wsrc + (size_t)i * 1024 + lane * 16, smW + i * 1024);
+		}
+	}
+	int tile = slot;
+	if (tile < p.numTiles) stageTile(tile, 0);
+
+	f32x4 biasv[2][4];
+#pragma unroll
+	for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			biasv[nb][g] = *reinterpret_cast<const f32x4 *>(p.bias + nb * 32 + 8 * g + 4 * hh);
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+
+	// LDS byte addresses for the hand-issued fragment reads
+	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (__attribute__((address_space(3))) unsigned char *)smem));
+	const unsigned wAddr = ldsBase + hh * 1024 + px * 16;
+	const unsigned wAddrHi = wAddr + 40960;
+	const int q0 = (wave * 2) * 34 + px;
+
+	int buf = 0;
+	const int stride = perX * 8;
+	for (; tile < p.numTiles; tile += stride, buf ^= 1) {
+		const int next = tile + stride;
+		if (next < p.numTiles) stageTile(next, buf ^ 1);  // async, lands during the MFMAs
+
+		const int ty = tile / p.tilesX;
+		const int tx = tile - ty * p.tilesX;
+		f32x16 acc[2][2];
+#pragma unroll
+		for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+#pragma unroll
+				for (int rw = 0; rw < 2; ++rw) {
+					acc[nb][rw][4 * g + 0] = biasv[nb][g][0];
+					acc[nb][rw][4 * g + 1] = biasv[nb][g][1];
+					acc[nb][rw][4 * g + 2] = biasv[nb][g][2];
+					acc[nb][rw][4 * g + 3] = biasv[nb][g][3];
+				}
+			}
+		}
+		// residual prefetch (second conv of a block): issued now, consumed after the
+		// K loop, so its latency hides behind the MFMAs
+		Vec4<T> resv[2][2][4];
+		if (VARIANT != 2 && p.res != nullptr) {
+			const int gxr = tx * 32 + px;
+#pragma unroll
+			for (int rw = 0; rw < 2; ++rw) {
+				const int gyr = ty * 8 + wave * 2 + rw;  // rows beyond H read the zero border
+				const T *rp = static_cast<const T *>(p.res) +
+				              ((size_t)(gyr + 1) * p.pitch + gxr + 1) * 64 + 4 * hh;
+#pragma unroll
+				for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						resv[rw][nb][g] = *reinterpret_cast<const Vec4<T> *>(rp + nb * 32 + 8 * g);
+					}
+				}
+			}
+		}
+
+		// K loop as 12 macro-steps m = (dx, ks): the 3 vertical taps x 2 cout blocks
+		// of weights (6 fragments) and the wave's 4 input rows (4 fragments) feed
+		// 12 MFMAs.  With one wave per SIMD nothing but this wave's own instruction
+		// stream can hide LDS latency, and hipcc schedules fragment reads just in
+		// time (ds_read; s_waitcnt lgkmcnt(0); mfma), so the loop is hand-scheduled:
+		// the 10 fragment reads of step m+1 are issued, one behind each of the first
+		// 10 MFMAs of step m, IN THE ORDER step m+1 consumes them; each MFMA waits
+		// with a counted lgkmcnt for exactly the reads it needs (LDS reads return in
+		// order).  Reads are asm (hipcc must not count or move them); each wait is
+		// followed by sched_barrier(0) so no MFMA is hoisted above it.
+		//
+		// consumption order of a step's reads:   a00 b0 a01 b1 a10 a11 b2 a20 a21 b3
+		// MFMA k = (dy, rw, nb) = (k>>2, (k>>1)&1, k&1) uses a[dy][nb], b[rw+dy]
+		Vec8<T> fa[2][3][2], fb[2][4];
+		const unsigned tileAddr = ldsBase + kTowerWBytes + buf * kTowerTileBytes;
+		auto issueRead = [&](int m, int set, int idx) {
+			// idx = position in the consumption order above
+			const int dx = m >> 2, ks = m & 3;
+			constexpr int kind[10] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1};   // 0 = weight, 1 = activation
+			constexpr int sub[10] = {0, 0, 1, 1, 2, 3, 2, 4, 5, 3};    // a: dy*2+nb ; b: row
+			if (kind[idx] == 0) {
+				const int dy = sub[idx] >> 1, nb = sub[idx] & 1;
+				const int widx = (dy * 3 + dx) * 4 + ks;
+				const int off = widx * 2048 + nb * 512;
+				if (off < 65536 - 512) {
+					asm volatile("ds_read_b128 %0, %1 offset:%2"
+					             : "=v"(fa[set][dy][nb]) : "v"(wAddr), "n"(off));
+				} else {
+					asm volatile("ds_read_b128 %0, %1 offset:%2"
+					             : "=v"(fa[set][dy][nb]) : "v"(wAddrHi), "n"(off - 40960));
+				}
+			} else {
+				const int r = sub[idx];
+				const int q = q0 + r * 34 + dx;
+				const unsigned a = tileAddr + q * 128 + (((ks * 2 + hh) ^ ((q >> 1) & 7)) << 4);
+				asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][r]) : "v"(a));
+			}
+		};
+		// reads that must have landed before MFMA k of a step: index of the last one
+		// it needs in the consumption order (-1: nothing new)
+		constexpr int needs[12] = {1, 2, 3, -1, 4, 5, 6, -1, 7, 8, 9, -1};
+		// start from an empty LGKM counter: the counted waits below must see only
+		// this loop's own reads (compiler-issued scalar loads would skew them)
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int i = 0; i < (VARIANT == 1 ? 0 : 10); ++i) issueRead(0, 0, i);
+#pragma unroll
+		for (int m = 0; m < (VARIANT == 1 ? 0 : 12); ++m) {
+			const int set = m & 1;
+			const bool more = (m + 1 < 12);
+#pragma unroll
+			for (int k = 0; k < 12; ++k) {
+				if (needs[k] >= 0) {
+					// outstanding reads allowed = (this step's reads younger than needs[k])
+					//                           + (next step's reads already issued = k)
+					const int allowed = (9 - needs[k]) + (more ? (k < 10 ? k : 10) : 0);
+					if (allowed >= 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+					else if (allowed == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+					else if (allowed == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+					else if (allowed == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+					else if (allowed == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+					else if (allowed == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+					else if (allowed == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+					else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+					else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+					else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+					else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				const int dy = k >> 2, rw = (k >> 1) & 1, nb = k & 1;
+				acc[nb][rw] = mfma32(fa[set][dy][nb], fb[set][rw + dy], acc[nb][rw]);
+				if (more && k < 10) issueRead(m + 1, set ^ 1, k);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		// ---- epilogue ----
+		// Each lane holds, per (row rw, cout block nb, group g), 4 consecutive output
+		// channels of ONE pixel: stored directly that is an 8-byte write into each of
+		// 32 different 128-byte pixel records per instruction, and a layer becomes ~1M
+		// partial-line L2 requests (measured: 9.4 of 19.5 us).  Instead the wave
+		// transposes its 2 rows x 32 px x 64 ch through LDS (its own 8 KiB slice of
+		// the input buffer it has just finished with) and stores whole records,
+		// 16 B per lane, 1 KiB contiguous per instruction.
+		__syncthreads();  // every wave is done reading this tile's input (halo rows are shared)
+		{
+			unsigned char *slice = smT + buf * kTowerTileBytes + wave * 8192;
+#pragma unroll
+			for (int rw = 0; rw < 2; ++rw) {
+				const int pi = rw * 32 + px;  // pixel index inside the slice
+#pragma unroll
+				for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						float v[4];
+#pragma unroll
+						for (int i = 0; i < 4; ++i) v[i] = acc[nb][rw][4 * g + i];
+						if (VARIANT != 2 && p.res != nullptr) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(resv[rw][nb][g][i]);
+						}
+						if (p.relu) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+						}
+						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]),
+						    static_cast<T>(v[2]), static_cast<T>(v[3])};
+						const int c = nb * 4 + g;  // 16-byte chunk = channels 8c .. 8c+7
+						*reinterpret_cast<Vec4<T> *>(
+						    slice + pi * 128 + ((c ^ (pi & 7)) << 4) + hh * 8) = o;
+					}
+				}
+			}
+			// same-wave exchange through LDS: order the writes before the reads
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			if (VARIANT != 2) {
+				T *outp = static_cast<T *>(p.out);
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					const int pi = i * 8 + (lane >> 3);
+					const int c = (lane & 7) ^ (pi & 7);
+					typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+					const u32x4 val = *reinterpret_cast<const u32x4 *>(slice + i * 1024 + lane * 16);
+					const int gy = ty * 8 + wave * 2 + (pi >> 5);
+					const int gxo = tx * 32 + (pi & 31);
+					if (gy < p.H && gxo < p.W) {
+						// (non-temporal stores measured no better: 18.2 vs 17.4 us)
+						*reinterpret_cast<u32x4 *>(
+						    outp + ((size_t)(gy + 1) * p.pitch + gxo + 1) * 64 + c * 8) = val;
+					}
+				}
+			} else {
+				asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[0][1]), "v"(acc[1][1]));
+			}
+		}
+		// End of iteration.  The next tile's DMA was already drained by the
+		// __syncthreads() in front of the epilogue (its fence waits vmcnt(0) while an
+		// LDS-DMA is pending), so nothing here waits on memory: in particular not on
+		// the record stores' acknowledgements (an s_waitcnt vmcnt(0) here cost ~1.5 us
+		// per tile).  Only the staging slices must be read out before the next
+		// iteration's DMA refills this buffer: LDS wait + raw s_barrier.
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
+int g_TowerVariant = 0;
+
+template <typename T, int VARIANT>
+void launchTowerT(const ConvParams &p, hipStream_t stream) {
+	auto kern = conv_tower_kernel<T, VARIANT>;
+	static bool attrSet = false;
+	if (!attrSet) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+		    hipFuncAttributeMaxDynamicSharedMemorySize, kTowerLds);
+		if (e != hipSuccess) {
+			throw std::runtime_error(
+			    std::string("hipFuncSetAttribute(tower LDS): ") + hipGetErrorString(e));
+		}
+		attrSet = true;
+	}
+	const int pitch = towerPitch(p.W);
+	const size_t origin = towerOrigin(p.W) * 64 * 2;  // bytes from allocation start to pixel (0,0)
+	TowerParams t{};
+	t.in = static_cast<const unsigned char *>(p.in) - origin;
+	t.wgt = p.wgt;
+	t.bias = p.bias;
+	t.res = p.res ? static_cast<const unsigned char *>(p.res) - origin : nullptr;
+	t.out = static_cast<unsigned char *>(p.out) - origin;
+	t.H = p.H;
+	t.W = p.W;
+	t.pitch = pitch;
+	t.tilesX = (p.W + 31) / 32;
+	t.numTiles = t.tilesX * ((p.H + 7) / 8);
+	t.relu = p.relu;
+	// The XCD remap in the kernel is a bijection only on grids that are a multiple
+	// of 8; surplus workgroups find no tile and exit after the weight prologue.
+	const int grid = ((t.numTiles < 256 ? t.numTiles : 256) + 7) / 8 * 8;
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(kTowerThreads), kTowerLds, stream, t);
+	hipCheckLaunch("conv_tower");
 }
 
 // ---------------------------------------------------------------------------
@@ -561,8 +898,28 @@ void launchConv(DType dt, const ConvParams &p, hipStream_t stream) {
 }
 
 void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
-	launchConv(dt, p, stream);
+	const int pitch = towerPitch(p.W);
+	const bool fits = p.taps == 9 && p.cin == 64 && p.cout == 64 && !p.outF32 &&
+	                  p.inPitch == pitch && p.outPitch == pitch &&
+	                  (p.res == nullptr || p.resPitch == pitch);
+	if (!fits) {
+		launchConv(dt, p, stream);
+		return;
+	}
+	if (dt == kF16) {
+		launchTowerT<f16, 0>(p, stream);
+		return;
+	}
+	switch (g_TowerVariant) {
+	case 1: launchTowerT<bf16, 1>(p, stream); break;
+	case 2: launchTowerT<bf16, 2>(p, stream); break;
+	case 3: launchTowerT<bf16, 3>(p, stream); break;
+	case 4: launchTowerT<bf16, 4>(p, stream); break;
+	default: launchTowerT<bf16, 0>(p, stream); break;
+	}
 }
+
+void setTowerVariant(int v) { g_TowerVariant = v; }
 
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,

@@ -84,6 +84,7 @@ def load_library() -> C.CDLL:
                                      P(C.c_size_t)]),
         "ju_time_steps": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, P(C.c_double),
                                     P(C.c_int), P(C.c_double)]),
+        "ju_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
         "ju_version": (C.c_char_p, []),
     }
     for name, (res, args) in sigs.items():

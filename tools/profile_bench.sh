@@ -1,0 +1,11 @@
+#!/bin/bash
+# Runs on the GPU box: bench line + rocprofv3 kernel-trace stats of the same command.
+# usage: bash tools/profile_bench.sh <tag>
+TAG=${1:-run}
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+timeout 300 python3 $R/bench.py > $R/gpurun_out/bench_$TAG.json 2> $R/gpurun_out/bench_$TAG.err
+tail -c 2500 $R/gpurun_out/bench_$TAG.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+tail -1 $R/gpurun_out/prof_$TAG.log | cut -c1-300
