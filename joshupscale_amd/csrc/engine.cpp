@@ -82,6 +82,10 @@ Engine::ConvWeights &Engine::addConv(
 	cw.cout = f.cout;
 	cw.taps = f.taps;
 	cw.cinReal = f.cin;
+	if (name.rfind("generator/block_", 0) == 0) {  // tower layers, in execution order
+		m_TowerHostW.insert(m_TowerHostW.end(), packed.begin(), packed.end());
+		m_TowerHostB.insert(m_TowerHostB.end(), f.bias.begin(), f.bias.end());
+	}
 	auto res = m_Convs.emplace(name, std::move(cw));
 	if (!res.second) throw std::logic_error("duplicate conv " + name);
 	return res.first->second;
@@ -266,13 +270,38 @@ void Engine::buildProgram(int set) {
 	    true, false);
 	const char *xs[2] = {"trunk_a", "trunk_b"};
 	int a = 0;
-	for (int i = 0; i < c.genBlocks; ++i) {
-		const std::string n = "generator/block_" + std::to_string(i + 1);
-		addConvStep(&prog, "tower", n + "/conv_1", Op(xs[a]), none, Op("trunk_t"), H, W, true,
-		    false, true);
-		addConvStep(&prog, "tower", n + "/conv_2", Op("trunk_t"), Op(xs[a]), Op(xs[a ^ 1]), H, W,
-		    true, false, true);
-		a ^= 1;
+	if (m_Resident) {
+		// zero the epoch flags, then one launch for the whole tower
+		unsigned *flags = m_ResFlags.as<unsigned>();
+		const std::size_t flagBytes = m_ResFlags.bytes();
+		ResidentTowerParams rp{};
+		rp.in = Op("trunk_a").ptr;
+		rp.out = Op("trunk_b").ptr;
+		rp.weights = m_TowerW.get();
+		rp.bias = m_TowerB.as<float>();
+		rp.mailbox = m_ResMail.get();
+		rp.flags = flags;
+		rp.error = m_ResErrorDev;
+		rp.H = H;
+		rp.W = W;
+		rp.GX = m_ResGX;
+		rp.GY = m_ResGY;
+		rp.RH = m_ResRH;
+		rp.nLayers = 2 * c.genBlocks;
+		prog.push_back({"tower", 2.0 * H * W * 9.0 * 64 * 64 * rp.nLayers, [=](hipStream_t s) {
+			                JU_HIP(hipMemsetAsync(flags, 0, flagBytes, s));  // epochs count within a launch
+			                launchResidentTower(dt, rp, s);
+		                }});
+		a = 1;
+	} else {
+		for (int i = 0; i < c.genBlocks; ++i) {
+			const std::string n = "generator/block_" + std::to_string(i + 1);
+			addConvStep(&prog, "tower", n + "/conv_1", Op(xs[a]), none, Op("trunk_t"), H, W, true,
+			    false, true);
+			addConvStep(&prog, "tower", n + "/conv_2", Op("trunk_t"), Op(xs[a]), Op(xs[a ^ 1]), H, W,
+			    true, false, true);
+			a ^= 1;
+		}
 	}
 	m_TrunkOut = xs[a];
 	addConvStep(&prog, "tail", "generator/conv_trans_1", Op(xs[a]), none, Op("tail_y"), H, W, true,
@@ -327,6 +356,29 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 
 	buildWeights(model);
 
+	// ---- resident tower: needs 64 filters and one co-resident workgroup per region ----
+	{
+		const char *mode = std::getenv("JU_TOWER");
+		int cus = 0;
+		JU_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+		const bool wanted = !(mode && std::string(mode) == "layers");
+		if (wanted && c.genFilters == 64 && c.genBlocks >= 1 &&
+		    residentTowerGeometry(c.frameHeight, c.frameWidth, cus, &m_ResGX, &m_ResGY, &m_ResRH)) {
+			m_Resident = true;
+			m_TowerW = DeviceBuffer(m_TowerHostW.size() * 2);
+			m_TowerW.upload(m_TowerHostW.data(), m_TowerHostW.size() * 2);
+			m_TowerB = DeviceBuffer(m_TowerHostB.size() * 4);
+			m_TowerB.upload(m_TowerHostB.data(), m_TowerHostB.size() * 4);
+			m_ResMail = DeviceBuffer(residentMailboxBytes(m_ResGX, m_ResGY));
+			m_ResFlags = DeviceBuffer((static_cast<std::size_t>(m_ResGX) * m_ResGY * 4 + 15) / 16 * 16);
+			JU_HIP(hipHostMalloc(reinterpret_cast<void **>(&m_ResErrorHost), 64, hipHostMallocMapped));
+			*m_ResErrorHost = 0;
+			JU_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&m_ResErrorDev), m_ResErrorHost, 0));
+		}
+		m_TowerHostW.clear();
+		m_TowerHostW.shrink_to_fit();
+	}
+
 	// ---- buffers (all zero-initialised) ----
 	const std::size_t lr = static_cast<std::size_t>(H) * W;
 	const std::size_t plr = static_cast<std::size_t>(PH) * PW;
@@ -370,6 +422,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		for (const Step &st : m_Program[s]) st.run(m_Stream);
 	}
 	m_Stream.synchronize();
+	checkResidentError();
 	reset();
 
 	const char *noGraph = std::getenv("JU_NO_GRAPH");
@@ -385,7 +438,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	std::ostringstream ss;
 	ss << "engine ready: " << W << "x" << H << " -> " << 4 * W << "x" << 4 * H << ", "
 	   << (m_DType == kF16 ? "fp16" : "bf16") << ", " << m_Program[0].size()
-	   << " kernels/frame, graph=" << (m_UseGraph ? "on" : "off");
+	   << " launches/frame, tower=" << (m_Resident ? "resident" : "per-layer")
+	   << ", graph=" << (m_UseGraph ? "on" : "off");
 	logMessage(LogLevel::Info, "Engine", ss.str());
 }
 
@@ -393,7 +447,20 @@ Engine::~Engine() {
 	try {
 		DeviceGuard g(m_Device);
 		(void)hipStreamSynchronize(m_Stream);
+		if (m_ResErrorHost) (void)hipHostFree(m_ResErrorHost);
 	} catch (...) {
+	}
+}
+
+void Engine::checkResidentError() {
+	if (m_ResErrorHost && *m_ResErrorHost != 0) {
+		const unsigned code = *m_ResErrorHost;
+		*m_ResErrorHost = 0;
+		std::ostringstream ss;
+		ss << "resident tower kernel: a bounded wait on a neighbouring workgroup expired (code 0x"
+		   << std::hex << code << "); are all " << std::dec << m_ResGX * m_ResGY
+		   << " workgroups co-resident? Set JU_TOWER=layers to use the per-layer path";
+		throw std::runtime_error(ss.str());
 	}
 }
 
@@ -532,11 +599,13 @@ void Engine::process(const Frame &in, const Frame &out) {
 	stageOut(out);
 	m_Stream.synchronize();
 	m_Idx ^= 1;
+	checkResidentError();
 }
 
 void Engine::synchronize() {
 	DeviceGuard g(m_Device);
 	m_Stream.synchronize();
+	checkResidentError();
 }
 
 std::vector<std::string> Engine::tensorNames() const {

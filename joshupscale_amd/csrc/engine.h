@@ -129,6 +129,15 @@ private:
 	DeviceBuffer m_TailW2, m_TailB2;
 	DeviceBuffer m_InStage, m_OutStage, m_RawStage;
 	DeviceBuffer m_State[2], m_Packed[2];
+	// resident tower (one launch for all residual-block convolutions)
+	bool m_Resident = false;
+	int m_ResGX = 0, m_ResGY = 0, m_ResRH = 0;
+	std::vector<std::uint16_t> m_TowerHostW;
+	std::vector<float> m_TowerHostB;
+	DeviceBuffer m_TowerW, m_TowerB, m_ResMail, m_ResFlags;
+	unsigned *m_ResErrorHost = nullptr;  // pinned, device-visible
+	unsigned *m_ResErrorDev = nullptr;
+	void checkResidentError();
 	std::vector<Step> m_Program[2];
 	GraphExec m_Graph[2];
 };

@@ -64,6 +64,28 @@ void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
 // pitch == towerPitch(W); other shapes fall back to launchConv.
 void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream);
 
+// ---- resident tower: every residual-block convolution in one launch --------
+// in/out: tower-layout tensors addressed at their interior origin.  weights:
+// nLayers consecutive 64->64 3x3 kernels in packConvWeights order; bias nLayers x 64.
+// mailbox (residentMailboxBytes) and flags (GX*GY u32, zeroed before each launch)
+// carry the halo exchange between neighbouring workgroups; *error is written
+// (non-zero) if a bounded wait expires.  Needs GX*GY co-resident workgroups.
+struct ResidentTowerParams {
+	const void *in;
+	void *out;
+	const void *weights;
+	const float *bias;
+	void *mailbox;
+	unsigned *flags;
+	unsigned *error;
+	int H, W;
+	int GX, GY, RH;
+	int nLayers;
+};
+bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH);
+std::size_t residentMailboxBytes(int GX, int GY);
+void launchResidentTower(DType dt, const ResidentTowerParams &p, hipStream_t stream);
+
 // Timing-only ablation switch of the tower kernel (0 = product kernel).
 void setTowerVariant(int variant);
 

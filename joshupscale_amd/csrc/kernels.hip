@@ -602,6 +602,369 @@ void launchTowerT(const ConvParams &p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
+// resident tower: all 2*B convolutions of the generator's residual blocks in
+// ONE launch, activations never leaving the CU
+// ---------------------------------------------------------------------------
+// Per-layer launches are memory- and latency-chain-bound:
+// a 64->64 layer moves ~46 MB for 9.6 GFLOP and pays a kernel boundary plus the
+// flush of 16.6 MB of dirty L2.  Here each workgroup (one per CU) owns a region
+// of 30 x RH (<= 17) pixels for the whole tower:
+//   * two LDS buffers of (RH+2) x 32 px x 128 B hold the block input X and the
+//     intermediate T, including a one-pixel halo ring; conv1 reads X writes T,
+//     conv2 reads T, adds the residual from X and writes X in place;
+//   * the wave's weights (its 32 output channels x 576) are the MFMA A operand
+//     straight from 144 VGPRs, double-buffered (288) so the next layer's weights
+//     stream in from L2 behind the current layer's MFMAs;
+//   * after every layer only the edge ring (<= 94 px) is exchanged with the <= 8
+//     neighbouring workgroups through a global mailbox: write-through (sc1)
+//     stores, every storing wave drains vmcnt, workgroup barrier, one lane
+//     publishes an epoch flag; the consumer polls the flags (bounded), then reads
+//     the payload with sc1 loads only (cdna_hip_programming.md Guideline 16, R1).
+// Nothing here depends on dispatch order or XCD placement; all workgroups must be
+// co-resident (grid <= #CUs, one workgroup per CU by LDS size), every spin is
+// bounded and reports through *error.
+constexpr int kResRW = 30;
+constexpr int kResMaxRH = 17;
+constexpr int kResRowBytes = 32 * 128;
+constexpr int kResBufBytes = (kResMaxRH + 2) * kResRowBytes;       // 77824
+constexpr int kResOffA = 0;
+constexpr int kResOffB = kResBufBytes + 256;                        // A's overrun pad
+constexpr int kResOffMisc = kResOffB + kResBufBytes + kResRowBytes + 256;
+constexpr int kResLds = kResOffMisc + 64;                           // 160320 B
+constexpr int kResMailWords = 4 * 32 * 16;                          // u64 per region per parity
+constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of s_memrealtime
+
+struct ResidentParams {
+	const void *in;           // tower-layout tensor, allocation start (block 0 input)
+	void *out;                // tower-layout tensor, allocation start (last block output)
+	const void *weights;      // nLayers x 73728 B, kernel-ready (packConvWeights)
+	const float *bias;        // nLayers x 64
+	unsigned long long *mail; // [regions][2][kResMailWords]
+	unsigned *flags;          // [regions], zeroed before every launch
+	unsigned *error;          // host-visible word, 0 = ok
+	int H, W, pitch;
+	int GX, GY, RH;
+	int nLayers;
+};
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6;
+	const int lane = tid & 63;
+	const int px = lane & 31;
+	const int hh = lane >> 5;
+	const int ch = wave & 1;   // cout half of this wave
+	const int rp = wave >> 1;  // row-pair parity of this wave
+	const int region = blockIdx.x;
+	const int gxr = region % p.GX;
+	const int gyr = region / p.GX;
+	const int x0 = gxr * kResRW;
+	const int y0 = gyr * p.RH;
+	const int rwv = min(kResRW, p.W - x0);  // valid columns / rows of this region
+	const int rhv = min(p.RH, p.H - y0);
+	volatile int *failFlag = reinterpret_cast<volatile int *>(smem + kResOffMisc);
+
+	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (__attribute__((address_space(3))) unsigned char *)smem));
+
+	// ---- zero both buffers (border, out-of-image area and overrun pads stay zero) ----
+	for (int i = tid; i < kResOffMisc / 16; i += 256) {
+		reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+	}
+	if (tid == 0) *failFlag = 0;
+	__syncthreads();
+
+	// ---- block 0 input: region + halo straight from the complete global tensor ----
+	{
+		const T *in = static_cast<const T *>(p.in);
+		const int nInstr = (rhv + 2) * 4;  // 8 pixels per wave-instruction, 32 px per row
+		for (int i = wave; i < nInstr; i += 4) {
+			const int q = i * 8 + (lane >> 3);
+			const int rr = q >> 5, cc = q & 31;
+			const int c = (lane & 7) ^ ((q >> 1) & 7);
+			glds16(in + ((size_t)(y0 + rr) * p.pitch + x0 + cc) * 64 + c * 8,
+			    smem + kResOffA + i * 1024);
+		}
+	}
+
+	// ---- register-resident weights: A fragment f = (dy*3+dx)*4+ks of this wave's cout half ----
+	Vec8<T> w0[36], w1[36];
+	auto loadWeights = [&](int layer, Vec8<T>(&w)[36]) {
+		const T *wl = static_cast<const T *>(p.weights) + (size_t)layer * (9 * 64 * 64) +
+		              (hh * 64 + ch * 32 + px) * 8;
+#pragma unroll
+		for (int f = 0; f < 36; ++f) w[f] = *reinterpret_cast<const Vec8<T> *>(wl + f * 1024);
+	};
+	loadWeights(0, w0);
+
+	// per-lane LDS address parts (the swizzle depends only on the column: rows are 32 px)
+	unsigned colsw[12];  // [dx*4+ks]: byte offset of this lane's B fragment inside a row
+#pragma unroll
+	for (int m = 0; m < 12; ++m) {
+		const int dx = m >> 2, ks = m & 3;
+		const int cq = px + dx;
+		colsw[m] = cq * 128 + (((ks * 2 + hh) ^ ((cq >> 1) & 7)) << 4);
+	}
+	unsigned outsw[4];  // [g]: byte offset of this lane's 4 output channels inside a row
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		const int cq = px + 1;
+		outsw[g] = cq * 128 + (((ch * 4 + g) ^ ((cq >> 1) & 7)) << 4) + hh * 8;
+	}
+
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+
+	// ------------------------------------------------------------------------
+	// one convolution layer over the region: in/out are LDS buffer offsets
+	// ------------------------------------------------------------------------
+	auto computeLayer = [&](const int layer, const int inOff, const int outOff,
+	                        const bool residual, const Vec8<T>(&w)[36]) {
+		f32x4 bias[4];
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			bias[g] = *reinterpret_cast<const f32x4 *>(
+			    p.bias + layer * 64 + ch * 32 + 8 * g + 4 * hh);
+		}
+		const int nPairs = (rhv + 1) >> 1;
+		for (int pair = rp; pair < nPairs; pair += 2) {
+			const int ra = 1 + 2 * pair;  // output rows ra, ra+1 (buffer row indices)
+			f32x16 acc[2];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					acc[0][4 * g + i] = bias[g][i];
+					acc[1][4 * g + i] = bias[g][i];
+				}
+			}
+			const unsigned rowAddr = ldsBase + inOff + (ra - 1) * kResRowBytes;
+			Vec8<T> fb[2][4];
+			auto issue = [&](int m, int set, int j) {
+				const unsigned a = rowAddr + colsw[m];
+				if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
+				else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[set][1]) : "v"(a));
+				else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fb[set][2]) : "v"(a));
+				else asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fb[set][3]) : "v"(a));
+			};
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) issue(0, 0, j);
+			// MFMA k = (dy, r) = (k>>1, k&1) uses w[(dy*3+dx)*4+ks] and fb[r+dy];
+			// reads are consumed in order b0 b1 b2 b3 -> index needed by MFMA k:
+			constexpr int needs[6] = {0, 1, -1, 2, -1, 3};
+#pragma unroll
+			for (int m = 0; m < 12; ++m) {
+				const int set = m & 1;
+				const bool more = (m + 1 < 12);
+				const int dx = m >> 2, ks = m & 3;
+#pragma unroll
+				for (int k = 0; k < 6; ++k) {
+					if (needs[k] >= 0) {
+						const int allowed = (3 - needs[k]) + (more ? (k < 4 ? k : 4) : 0);
+						if (allowed >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+						else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+						else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+						else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+						__builtin_amdgcn_sched_barrier(0);
+					}
+					const int dy = k >> 1, r = k & 1;
+					acc[r] = mfma32(w[(dy * 3 + dx) * 4 + ks], fb[set][r + dy], acc[r]);
+					if (more && k < 4) issue(m + 1, set ^ 1, k);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int rr = ra + r;
+				if (rr <= rhv && px < rwv) {
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						float v[4];
+#pragma unroll
+						for (int i = 0; i < 4; ++i) v[i] = acc[r][4 * g + i];
+						unsigned char *dst = smem + outOff + rr * kResRowBytes + outsw[g];
+						if (residual) {  // block input sits at the same place: read, add, overwrite
+							const Vec4<T> rv = *reinterpret_cast<const Vec4<T> *>(dst);
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[i]);
+						}
+#pragma unroll
+						for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
+						    static_cast<T>(v[3])};
+						*reinterpret_cast<Vec4<T> *>(dst) = o;
+					}
+				}
+			}
+		}
+	};
+
+	// ------------------------------------------------------------------------
+	// edge ring -> mailbox (publish) and neighbours' mailboxes -> halo ring
+	// ------------------------------------------------------------------------
+	// LDS address of 8-byte word w8 of pixel (rr, cc) in buffer `off`
+	auto ldsWord = [&](int off, int rr, int cc, int w8) -> unsigned char * {
+		const int c = w8 >> 1;
+		return smem + off + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4) + (w8 & 1) * 8;
+	};
+	auto publish = [&](int off, unsigned epoch) {
+		__syncthreads();  // the whole region's output is in LDS
+		gu64 *mb = (gu64 *)(p.mail + ((size_t)region * 2 + (epoch & 1)) * kResMailWords);
+#pragma unroll
+		for (int it = 0; it < kResMailWords / 256; ++it) {
+			const int idx = it * 256 + tid;
+			const int strip = idx >> 9, e = (idx >> 4) & 31, w8 = idx & 15;
+			int rr, cc;
+			bool valid;
+			if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
+			else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
+			else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
+			else { rr = e + 1; cc = rwv; valid = e < rhv; }
+			if (valid) {
+				const u64 v = *reinterpret_cast<const u64 *>(ldsWord(off, rr, cc, w8));
+				__hip_atomic_store(mb + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains
+		__syncthreads();
+		if (tid == 0) {
+			__hip_atomic_store((gu32 *)(p.flags + region), epoch, __ATOMIC_RELAXED,
+			    __HIP_MEMORY_SCOPE_AGENT);
+		}
+	};
+	// returns false on timeout (uniform across the workgroup)
+	auto fillHalo = [&](int off, unsigned epoch) -> bool {
+		if (wave == 0) {
+			bool ready = true;
+			if (lane < 8) {
+				const int k = lane < 4 ? lane : lane + 1;  // skip the centre of the 3x3
+				const int nx = gxr + (k % 3) - 1, ny = gyr + (k / 3) - 1;
+				if (nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY) {
+					const gu32 *f = (const gu32 *)(p.flags + ny * p.GX + nx);
+					const u64 t0 = __builtin_amdgcn_s_memrealtime();
+					for (;;) {
+						const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (v >= epoch) break;
+						if (__builtin_amdgcn_s_memrealtime() - t0 > kResTimeoutTicks) {
+							ready = false;
+							break;
+						}
+						__builtin_amdgcn_s_sleep(2);
+					}
+				}
+			}
+			if (!__all(ready)) {
+				if (lane == 0) {
+					*failFlag = 1;
+					__hip_atomic_store((gu32 *)p.error, 0x700u + epoch, __ATOMIC_RELAXED,
+					    __HIP_MEMORY_SCOPE_SYSTEM);
+				}
+			}
+		}
+		__syncthreads();
+		if (*failFlag) return false;
+		const int par = epoch & 1;
+#pragma unroll
+		for (int it = 0; it < kResMailWords / 256; ++it) {
+			const int idx = it * 256 + tid;
+			const int hp = idx >> 4, w8 = idx & 15;
+			const int side = hp >> 5, e = hp & 31;
+			// side 0: row above, 1: row below, 2: column left, 3: column right;
+			// entries 30/31 of the two row sides are the corners
+			int nx = gxr, ny = gyr, strip, se, rr, cc;
+			bool valid;
+			if (side < 2) {
+				ny += side == 0 ? -1 : 1;
+				strip = side == 0 ? 1 : 0;  // their bottom row / their top row
+				rr = side == 0 ? 0 : rhv + 1;
+				if (e < kResRW) { se = e; cc = e + 1; valid = e < rwv; }
+				else if (e == 30) { nx -= 1; se = kResRW - 1; cc = 0; valid = true; }
+				else { nx += 1; se = 0; cc = rwv + 1; valid = true; }
+			} else {
+				nx += side == 2 ? -1 : 1;
+				strip = side == 2 ? 3 : 2;  // their right column / their left column
+				se = e;
+				rr = e + 1;
+				cc = side == 2 ? 0 : rwv + 1;
+				valid = e < rhv;
+			}
+			valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
+			if (valid) {
+				const gu64 *mb = (const gu64 *)(p.mail + ((size_t)(ny * p.GX + nx) * 2 + par) * kResMailWords);
+				const u64 v = __hip_atomic_load(mb + (strip * 32 + se) * 16 + w8, __ATOMIC_RELAXED,
+				    __HIP_MEMORY_SCOPE_AGENT);  // sc1: never a stale L1/L2 line
+				*reinterpret_cast<u64 *>(ldsWord(off, rr, cc, w8)) = v;
+			}
+		}
+		__syncthreads();
+		return true;
+	};
+
+	// ------------------------------------------------------------------------
+	// the tower: conv1 X->T (weights w0), conv2 T->X (+X) (weights w1)
+	// ------------------------------------------------------------------------
+	const int nBlocks = p.nLayers >> 1;
+	for (int blk = 0; blk < nBlocks; ++blk) {
+		const int l0 = 2 * blk;
+		loadWeights(l0 + 1, w1);  // streams in behind conv1's MFMAs
+		if (blk > 0) {
+			if (!fillHalo(kResOffA, l0)) return;
+		}
+		computeLayer(l0, kResOffA, kResOffB, false, w0);
+		publish(kResOffB, l0 + 1);
+		if (l0 + 2 < p.nLayers) loadWeights(l0 + 2, w0);
+		if (!fillHalo(kResOffB, l0 + 1)) return;
+		computeLayer(l0 + 1, kResOffB, kResOffA, true, w1);
+		if (l0 + 2 < p.nLayers) publish(kResOffA, l0 + 2);
+	}
+	__syncthreads();
+
+	// ---- last block output: region interior -> global tower-layout tensor ----
+	{
+		T *out = static_cast<T *>(p.out);
+		for (int i = tid; i < rhv * kResRW * 8; i += 256) {
+			const int c = i & 7;
+			const int pxl = (i >> 3) % kResRW;
+			const int row = (i >> 3) / kResRW;
+			if (pxl < rwv) {
+				const int rr = row + 1, cc = pxl + 1;
+				const uint4 v = *reinterpret_cast<const uint4 *>(
+				    smem + kResOffA + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
+				*reinterpret_cast<uint4 *>(
+				    out + ((size_t)(y0 + rr) * p.pitch + x0 + cc) * 64 + c * 8) = v;
+			}
+		}
+	}
+}
+
+template <typename T>
+void launchResidentT(const ResidentParams &p, hipStream_t stream) {
+	auto kern = tower_resident_kernel<T>;
+	static bool attrSet = false;
+	if (!attrSet) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+		    hipFuncAttributeMaxDynamicSharedMemorySize, kResLds);
+		if (e != hipSuccess) {
+			throw std::runtime_error(
+			    std::string("hipFuncSetAttribute(resident tower LDS): ") + hipGetErrorString(e));
+		}
+		attrSet = true;
+	}
+	hipLaunchKernelGGL(kern, dim3(p.GX * p.GY), dim3(256), kResLds, stream, p);
+	hipCheckLaunch("tower_resident");
+}
+
+// ---------------------------------------------------------------------------
 // flow input packing
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float preprocessU8(unsigned v) {
@@ -920,6 +1283,41 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 }
 
 void setTowerVariant(int v) { g_TowerVariant = v; }
+
+bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH) {
+	const int gx = (W + kResRW - 1) / kResRW;
+	const int gy = (H + kResMaxRH - 1) / kResMaxRH;
+	if (gx * gy > numCUs) return false;
+	*GX = gx;
+	*GY = gy;
+	*RH = (H + gy - 1) / gy;  // <= kResMaxRH, balances the last row of regions
+	return true;
+}
+
+std::size_t residentMailboxBytes(int GX, int GY) {
+	return static_cast<std::size_t>(GX) * GY * 2 * kResMailWords * 8;
+}
+
+void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t stream) {
+	ResidentParams p{};
+	const std::size_t origin = towerOrigin(q.W) * 64 * 2;
+	p.in = static_cast<const unsigned char *>(q.in) - origin;
+	p.out = static_cast<unsigned char *>(q.out) - origin;
+	p.weights = q.weights;
+	p.bias = q.bias;
+	p.mail = static_cast<unsigned long long *>(q.mailbox);
+	p.flags = q.flags;
+	p.error = q.error;
+	p.H = q.H;
+	p.W = q.W;
+	p.pitch = towerPitch(q.W);
+	p.GX = q.GX;
+	p.GY = q.GY;
+	p.RH = q.RH;
+	p.nLayers = q.nLayers;
+	if (dt == kF16) launchResidentT<f16>(p, stream);
+	else launchResidentT<bf16>(p, stream);
+}
 
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
