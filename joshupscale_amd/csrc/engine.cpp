@@ -70,10 +70,17 @@ Engine::Operand Engine::operand(const std::string &name) {
 	return o;
 }
 
-Engine::ConvWeights &Engine::addConv(
-    const std::string &name, const FoldedConv &f, const std::vector<int> &cinMap) {
+Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &f,
+    const std::vector<int> &cinMap, int H, int W) {
 	ConvWeights cw;
-	const auto packed = packConvWeights(f, cinMap, m_DType);
+	const bool towerLayer = name.rfind("generator/block_", 0) == 0;
+	if (towerLayer && f.cout == 64) {
+		cw.nb = 2;  // the tower kernels read the 64-cout layout
+		cw.rw = 2;
+	} else {
+		convTiling(H, W, f.cout, &cw.nb, &cw.rw);
+	}
+	const auto packed = packConvWeights(f, cinMap, cw.nb, m_DType);
 	cw.w = DeviceBuffer(packed.size() * 2);
 	cw.w.upload(packed.data(), packed.size() * 2);
 	cw.bias = DeviceBuffer(f.bias.size() * 4);
@@ -82,7 +89,7 @@ Engine::ConvWeights &Engine::addConv(
 	cw.cout = f.cout;
 	cw.taps = f.taps;
 	cw.cinReal = f.cin;
-	if (name.rfind("generator/block_", 0) == 0) {  // tower layers, in execution order
+	if (towerLayer) {  // tower layers, in execution order
 		m_TowerHostW.insert(m_TowerHostW.end(), packed.begin(), packed.end());
 		m_TowerHostB.insert(m_TowerHostB.end(), f.bias.begin(), f.bias.end());
 	}
@@ -93,13 +100,15 @@ Engine::ConvWeights &Engine::addConv(
 
 void Engine::buildWeights(const ModelFile &model) {
 	const ModelConfig &c = m_Config;
-	auto plain = [&](const std::string &conv, const std::string &bn, bool bias) {
+	const int H = c.frameHeight, W = c.frameWidth;
+	auto plain = [&](const std::string &conv, const std::string &bn, bool bias, int h, int w) {
 		FoldedConv f = foldConv(model, conv, bn, bias);
-		addConv(conv, f, identityMap(f.cin, roundUp(f.cin, 16)));
+		addConv(conv, f, identityMap(f.cin, roundUp(f.cin, 16)), h, w);
 		return f.cout;
 	};
 	// ---- flow ----
 	const int flowCin = 3 * c.numFlowInputs;
+	int h = c.paddedHeight(), w = c.paddedWidth();
 	if (c.flowArch == 0) {
 		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
 		int cin = flowCin;
@@ -109,21 +118,28 @@ void Engine::buildWeights(const ModelFile &model) {
 			if (k.dims.size() != 4 || k.dims[2] != cin || k.dims[3] != c.flowFilters[i]) {
 				throw std::invalid_argument("Invalid model: flow filter mismatch at " + n);
 			}
-			plain(n + "/conv_1", n + "/bn_1", false);
-			cin = plain(n + "/conv_2", n + "/bn_2", false);
+			plain(n + "/conv_1", n + "/bn_1", false, h, w);
+			cin = plain(n + "/conv_2", n + "/bn_2", false, h, w);
+			if (i < nb) {
+				h /= 2;
+				w /= 2;
+			} else {
+				h *= 2;
+				w *= 2;
+			}
 		}
-		if (c.flowFilters.size() % 2) plain("flow/conv_1", "flow/bn_1", false);
-		if (plain("flow/conv_2", "", true) != 32) {
+		if (c.flowFilters.size() % 2) plain("flow/conv_1", "flow/bn_1", false, h, w);
+		if (plain("flow/conv_2", "", true, h, w) != 32) {
 			throw std::invalid_argument("Invalid model: flow head must have 32 channels");
 		}
 	} else {
-		plain("flow/conv_1", "flow/bn_1", false);
+		plain("flow/conv_1", "flow/bn_1", false, h, w);
 		for (int i = 0; i < c.flowResBlocks; ++i) {
 			const std::string n = "flow/block_" + std::to_string(i + 1);
-			plain(n + "/conv_1", n + "/bn_1", false);
-			plain(n + "/conv_2", n + "/bn_2", false);
+			plain(n + "/conv_1", n + "/bn_1", false, h, w);
+			plain(n + "/conv_2", n + "/bn_2", false, h, w);
 		}
-		if (plain("flow/conv_2", "", true) != 32) {
+		if (plain("flow/conv_2", "", true, h, w) != 32) {
 			throw std::invalid_argument("Invalid model: flow head must have 32 channels");
 		}
 	}
@@ -133,19 +149,19 @@ void Engine::buildWeights(const ModelFile &model) {
 		if (f.cin != 51 || f.cout != c.genFilters) {
 			throw std::invalid_argument("Invalid model: generator/conv_1 must be 51 -> gen_filters");
 		}
-		addConv("generator/conv_1", f, generatorInputMap());
+		addConv("generator/conv_1", f, generatorInputMap(), H, W);
 	}
 	for (int i = 0; i < c.genBlocks; ++i) {
 		const std::string n = "generator/block_" + std::to_string(i + 1);
-		plain(n + "/conv_1", n + "/bn_1", false);
-		plain(n + "/conv_2", n + "/bn_2", false);
+		plain(n + "/conv_1", n + "/bn_1", false, H, W);
+		plain(n + "/conv_2", n + "/bn_2", false, H, W);
 	}
 	{
 		FoldedConv f = foldConvTranspose2x2(model, "generator/conv_trans_1", "generator/bn_2");
 		if (f.cout != 128 || f.cin != c.genFilters) {
 			throw std::invalid_argument("Invalid model: conv_trans_1 must be gen_filters -> 32");
 		}
-		addConv("generator/conv_trans_1", f, identityMap(f.cin, roundUp(f.cin, 16)));
+		addConv("generator/conv_trans_1", f, identityMap(f.cin, roundUp(f.cin, 16)), H, W);
 		const TensorView &k2 = model.tensor("generator/conv_trans_2/kernel", {2, 2, 3, 32});
 		const TensorView &b2 = model.tensor("generator/conv_trans_2/bias", {3});
 		m_TailW2 = DeviceBuffer(k2.count * 4);
@@ -177,6 +193,8 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 	p.taps = cw.taps;
 	p.relu = relu ? 1 : 0;
 	p.outF32 = outF32 ? 1 : 0;
+	p.nb = cw.nb;
+	p.rw = cw.rw;
 	const DType dt = m_DType;
 	Step s;
 	s.tag = tag;

@@ -99,12 +99,14 @@ private:
 		DeviceBuffer w;
 		DeviceBuffer bias;
 		int cinP = 0, cout = 0, taps = 9, cinReal = 0;
+		int nb = 2, rw = 2;  // tile shape the weights were packed for
 	};
 
 	Tensor &addTensor(const std::string &name, std::size_t count, bool f32 = false,
 	    bool state = false);
+	// H x W: the resolution the layer runs at (decides its tile shape)
 	ConvWeights &addConv(const std::string &name, const FoldedConv &f,
-	    const std::vector<int> &cinMap);
+	    const std::vector<int> &cinMap, int H, int W);
 	void addConvStep(std::vector<Step> *prog, const std::string &tag, const std::string &wname,
 	    Operand in, Operand res, Operand out, int H, int W, bool relu, bool outF32,
 	    bool tower = false);

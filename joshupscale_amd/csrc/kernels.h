@@ -39,6 +39,9 @@ struct ConvParams {
 	// pixel (0,0); a tensor kept in the zero-bordered tower layout (below) is
 	// passed as its interior origin plus its pitch.
 	int inPitch, outPitch, resPitch;
+	// Tile shape chosen per layer (convTiling): couts per workgroup = 32*nb (the
+	// weights must be packed for the same nb), rows per wave rw (tile = 4*rw rows).
+	int nb, rw;
 };
 
 // Zero-bordered activation layout of the generator trunk ("tower layout"):
@@ -53,9 +56,38 @@ inline std::size_t towerPixels(int H, int W) {
 }
 inline std::size_t towerOrigin(int W) { return static_cast<std::size_t>(towerPitch(W)) + 1; }
 
-// Channel chunk / cout-block choice shared by the launcher and the packer.
+// Channel chunk shared by the launcher and the packer.
 inline int convCK(int cin) { return cin % 64 == 0 ? 64 : (cin % 32 == 0 ? 32 : 16); }
-inline int convNB(int cout) { return cout % 64 == 0 ? 2 : 1; }
+
+// Tile shape for an H x W layer: prefer the shape with the most operand reuse
+// (nb = 2 cout blocks, rw = 2 rows per wave) but fall back to smaller tiles until
+// the launch has enough workgroups to occupy the chip; the coarse levels of the
+// flow auto-encoder (34x60 ... 68x120 pixels) otherwise run on 40-80 of 256 CUs.
+inline void convTiling(int H, int W, int cout, int *nb, int *rw) {
+	const int tilesX = (W + 31) / 32;
+	int bestNb = 1, bestRw = 1;
+	long bestWgs = -1;
+	const int nbs[2] = {2, 1};
+	const int rws[2] = {2, 1};
+	for (int a = 0; a < 2; ++a) {
+		if (cout % (32 * nbs[a]) != 0) continue;
+		for (int b = 0; b < 2; ++b) {
+			const long wgs = (long)tilesX * ((H + 4 * rws[b] - 1) / (4 * rws[b])) * (cout / (32 * nbs[a]));
+			if (wgs >= 256) {
+				*nb = nbs[a];
+				*rw = rws[b];
+				return;
+			}
+			if (wgs > bestWgs) {
+				bestWgs = wgs;
+				bestNb = nbs[a];
+				bestRw = rws[b];
+			}
+		}
+	}
+	*nb = bestNb;
+	*rw = bestRw;
+}
 
 void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
 

@@ -246,29 +246,26 @@ void launchConvInst(const ConvParams &p, hipStream_t stream) {
 template <typename T>
 void launchConvT(const ConvParams &p, hipStream_t stream) {
 	const int ck = convCK(p.cin);
-	const int nb = convNB(p.cout);
-	if (p.cin % 16 != 0 || p.cout % 32 != 0) {
-		throw std::invalid_argument("conv: cin must be a multiple of 16, cout of 32");
+	if (p.cin % 16 != 0 || p.cout % 32 != 0 || (p.nb != 1 && p.nb != 2) ||
+	    (p.rw != 1 && p.rw != 2) || p.cout % (32 * p.nb) != 0) {
+		throw std::invalid_argument("conv: cin must be a multiple of 16, cout of 32*nb");
 	}
-#define JU_CONV_CASE(TAPS_, CK_, NB_)                                          \
-	if (p.taps == TAPS_ && ck == CK_ && nb == NB_) {                           \
-		launchConvInst<T, TAPS_, CK_, NB_, 2>(p, stream);                      \
-		return;                                                                \
+#define JU_CONV_CASE(TAPS_, CK_)                                                   \
+	if (p.taps == TAPS_ && ck == CK_) {                                            \
+		if (p.nb == 2 && p.rw == 2) launchConvInst<T, TAPS_, CK_, 2, 2>(p, stream);  \
+		else if (p.nb == 2) launchConvInst<T, TAPS_, CK_, 2, 1>(p, stream);          \
+		else if (p.rw == 2) launchConvInst<T, TAPS_, CK_, 1, 2>(p, stream);          \
+		else launchConvInst<T, TAPS_, CK_, 1, 1>(p, stream);                         \
+		return;                                                                    \
 	}
-	JU_CONV_CASE(9, 64, 2)
-	JU_CONV_CASE(9, 64, 1)
-	JU_CONV_CASE(9, 32, 2)
-	JU_CONV_CASE(9, 32, 1)
-	JU_CONV_CASE(9, 16, 2)
-	JU_CONV_CASE(9, 16, 1)
-	JU_CONV_CASE(1, 64, 2)
-	JU_CONV_CASE(1, 64, 1)
-	JU_CONV_CASE(1, 32, 2)
-	JU_CONV_CASE(1, 32, 1)
+	JU_CONV_CASE(9, 64)
+	JU_CONV_CASE(9, 32)
+	JU_CONV_CASE(9, 16)
+	JU_CONV_CASE(1, 64)
+	JU_CONV_CASE(1, 32)
 #undef JU_CONV_CASE
 	throw std::invalid_argument("conv: unsupported shape");
 }
-
 
 // ---------------------------------------------------------------------------
 // persistent 3x3 64->64 convolution of the generator's residual tower
@@ -630,7 +627,7 @@ constexpr int kResBufBytes = (kResMaxRH + 2) * kResRowBytes;       // 77824
 constexpr int kResOffA = 0;
 constexpr int kResOffB = kResBufBytes + 256;                        // A's overrun pad
 constexpr int kResOffMisc = kResOffB + kResBufBytes + kResRowBytes + 256;
-constexpr int kResLds = kResOffMisc + 64;                           // 160320 B
+constexpr int kResLds = kResOffMisc + 64 + 512;                     // 160832 B (flag, 2 bias slots)
 constexpr int kResMailWords = 4 * 32 * 16;                          // u64 per region per parity
 constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of s_memrealtime
 
@@ -651,7 +648,8 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-template <typename T>
+// VARIANT: timing ablation only (0 = product; bit 0 = no halo exchange, bit 1 = no MFMA loop)
+template <typename T, int VARIANT>
 __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
@@ -702,6 +700,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		for (int f = 0; f < 36; ++f) w[f] = *reinterpret_cast<const Vec8<T> *>(wl + f * 1024);
 	};
 	loadWeights(0, w0);
+	float biasNext = 0.f;  // wave 0: next layer's bias in flight (one value per lane)
+	if (wave == 0) reinterpret_cast<float *>(smem + kResOffMisc + 64)[lane] = p.bias[lane];
 
 	// per-lane LDS address parts (the swizzle depends only on the column: rows are 32 px)
 	unsigned colsw[12];  // [dx*4+ks]: byte offset of this lane's B fragment inside a row
@@ -724,13 +724,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// ------------------------------------------------------------------------
 	// one convolution layer over the region: in/out are LDS buffer offsets
 	// ------------------------------------------------------------------------
+	// bias of layer l sits in LDS slot l&1 (staged one layer ahead, see the tower loop)
+	float *ldsBias = reinterpret_cast<float *>(smem + kResOffMisc + 64);
 	auto computeLayer = [&](const int layer, const int inOff, const int outOff,
 	                        const bool residual, const Vec8<T>(&w)[36]) {
 		f32x4 bias[4];
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
 			bias[g] = *reinterpret_cast<const f32x4 *>(
-			    p.bias + layer * 64 + ch * 32 + 8 * g + 4 * hh);
+			    ldsBias + (layer & 1) * 64 + ch * 32 + 8 * g + 4 * hh);
 		}
 		const int nPairs = (rhv + 1) >> 1;
 		for (int pair = rp; pair < nPairs; pair += 2) {
@@ -756,12 +758,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for (int j = 0; j < 4; ++j) issue(0, 0, j);
+			for (int j = 0; j < ((VARIANT & 2) ? 0 : 4); ++j) issue(0, 0, j);
 			// MFMA k = (dy, r) = (k>>1, k&1) uses w[(dy*3+dx)*4+ks] and fb[r+dy];
 			// reads are consumed in order b0 b1 b2 b3 -> index needed by MFMA k:
 			constexpr int needs[6] = {0, 1, -1, 2, -1, 3};
 #pragma unroll
-			for (int m = 0; m < 12; ++m) {
+			for (int m = 0; m < ((VARIANT & 2) ? 0 : 12); ++m) {
 				const int set = m & 1;
 				const bool more = (m + 1 < 12);
 				const int dx = m >> 2, ks = m & 3;
@@ -874,6 +876,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		__syncthreads();
 		if (*failFlag) return false;
 		const int par = epoch & 1;
+		// All 8 loads are issued unconditionally (invalid entries read this region's
+		// own mailbox and are dropped) so they are in flight together; a load inside
+		// `if (valid)` makes hipcc wait vmcnt(0) per element: 8 serial round trips.
+		u64 hv[kResMailWords / 256];
+		unsigned char *hd[kResMailWords / 256];
 #pragma unroll
 		for (int it = 0; it < kResMailWords / 256; ++it) {
 			const int idx = it * 256 + tid;
@@ -899,12 +906,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				valid = e < rhv;
 			}
 			valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
-			if (valid) {
-				const gu64 *mb = (const gu64 *)(p.mail + ((size_t)(ny * p.GX + nx) * 2 + par) * kResMailWords);
-				const u64 v = __hip_atomic_load(mb + (strip * 32 + se) * 16 + w8, __ATOMIC_RELAXED,
-				    __HIP_MEMORY_SCOPE_AGENT);  // sc1: never a stale L1/L2 line
-				*reinterpret_cast<u64 *>(ldsWord(off, rr, cc, w8)) = v;
-			}
+			const int nreg = valid ? ny * p.GX + nx : region;
+			const gu64 *mb = (const gu64 *)(p.mail + ((size_t)nreg * 2 + par) * kResMailWords);
+			hv[it] = __hip_atomic_load(mb + (strip * 32 + se) * 16 + w8, __ATOMIC_RELAXED,
+			    __HIP_MEMORY_SCOPE_AGENT);  // sc1: never a stale L1/L2 line
+			hd[it] = valid ? ldsWord(off, rr, cc, w8) : nullptr;
+		}
+#pragma unroll
+		for (int it = 0; it < kResMailWords / 256; ++it) {
+			if (hd[it] != nullptr) *reinterpret_cast<u64 *>(hd[it]) = hv[it];
 		}
 		__syncthreads();
 		return true;
@@ -916,16 +926,30 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int nBlocks = p.nLayers >> 1;
 	for (int blk = 0; blk < nBlocks; ++blk) {
 		const int l0 = 2 * blk;
-		loadWeights(l0 + 1, w1);  // streams in behind conv1's MFMAs
-		if (blk > 0) {
+		constexpr bool xchg = !(VARIANT & 1);
+		// Order matters: vmcnt is in-order, so the next layer's weight stream (36 loads
+		// per lane) is issued AFTER the halo's sc1 loads and lands behind the MFMAs.
+		if (blk > 0 && xchg) {
 			if (!fillHalo(kResOffA, l0)) return;
 		}
+		loadWeights(l0 + 1, w1);
+		if (wave == 0) biasNext = p.bias[(l0 + 1) * 64 + lane];
 		computeLayer(l0, kResOffA, kResOffB, false, w0);
-		publish(kResOffB, l0 + 1);
-		if (l0 + 2 < p.nLayers) loadWeights(l0 + 2, w0);
-		if (!fillHalo(kResOffB, l0 + 1)) return;
+		if (wave == 0) ldsBias[((l0 + 1) & 1) * 64 + lane] = biasNext;
+		if (xchg) publish(kResOffB, l0 + 1);
+		else __syncthreads();
+		if (xchg) {
+			if (!fillHalo(kResOffB, l0 + 1)) return;
+		}
+		const bool last = l0 + 2 >= p.nLayers;
+		if (!last) {
+			loadWeights(l0 + 2, w0);
+			if (wave == 0) biasNext = p.bias[(l0 + 2) * 64 + lane];
+		}
 		computeLayer(l0 + 1, kResOffB, kResOffA, true, w1);
-		if (l0 + 2 < p.nLayers) publish(kResOffA, l0 + 2);
+		if (!last && wave == 0) ldsBias[((l0 + 2) & 1) * 64 + lane] = biasNext;
+		if (!last && xchg) publish(kResOffA, l0 + 2);
+		else __syncthreads();
 	}
 	__syncthreads();
 
@@ -947,9 +971,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	}
 }
 
-template <typename T>
+template <typename T, int VARIANT>
 void launchResidentT(const ResidentParams &p, hipStream_t stream) {
-	auto kern = tower_resident_kernel<T>;
+	auto kern = tower_resident_kernel<T, VARIANT>;
 	static bool attrSet = false;
 	if (!attrSet) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1262,7 +1286,7 @@ void launchConv(DType dt, const ConvParams &p, hipStream_t stream) {
 
 void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 	const int pitch = towerPitch(p.W);
-	const bool fits = p.taps == 9 && p.cin == 64 && p.cout == 64 && !p.outF32 &&
+	const bool fits = p.taps == 9 && p.cin == 64 && p.cout == 64 && !p.outF32 && p.nb == 2 &&
 	                  p.inPitch == pitch && p.outPitch == pitch &&
 	                  (p.res == nullptr || p.resPitch == pitch);
 	if (!fits) {
@@ -1315,8 +1339,16 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.GY = q.GY;
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
-	if (dt == kF16) launchResidentT<f16>(p, stream);
-	else launchResidentT<bf16>(p, stream);
+	if (dt == kF16) {
+		launchResidentT<f16, 0>(p, stream);
+		return;
+	}
+	switch (g_TowerVariant) {
+	case 1: launchResidentT<bf16, 1>(p, stream); break;
+	case 2: launchResidentT<bf16, 2>(p, stream); break;
+	case 3: launchResidentT<bf16, 3>(p, stream); break;
+	default: launchResidentT<bf16, 0>(p, stream); break;
+	}
 }
 
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,

@@ -224,13 +224,13 @@ std::uint16_t floatToBF16(float f) {
 }
 
 std::vector<std::uint16_t> packConvWeights(
-    const FoldedConv &c, const std::vector<int> &cinMap, DType dt) {
+    const FoldedConv &c, const std::vector<int> &cinMap, int nb, DType dt) {
 	const int cinP = static_cast<int>(cinMap.size());
-	if (cinP % 16 != 0 || c.cout % 32 != 0) {
-		throw std::invalid_argument("packConvWeights: cin must pad to 16, cout to 32");
+	if (cinP % 16 != 0 || (nb != 1 && nb != 2) || c.cout % (32 * nb) != 0) {
+		throw std::invalid_argument("packConvWeights: cin must pad to 16, cout to 32*nb");
 	}
 	const int CK = convCK(cinP);
-	const int COG = 32 * convNB(c.cout);
+	const int COG = 32 * nb;
 	const int KS = CK / 16;
 	const int nCC = cinP / CK;
 	const int nCOG = c.cout / COG;

@@ -85,11 +85,12 @@ FoldedConv foldConvTranspose2x2(
     const ModelFile &m, const std::string &convName, const std::string &bnPrefix);
 
 // Kernel-ready 16-bit weights for conv_mfma_kernel:
-// [cout/COG][cinP/CK][tap][CK/16][2][COG][8] with COG = 32*convNB(cout),
-// CK = convCK(cinP).  `cinMap[k]` = source input channel of packed channel k, or
-// -1 for a zero channel (cinMap.size() == cinP, a multiple of 16).
+// [cout/COG][cinP/CK][tap][CK/16][2][COG][8] with COG = 32*nb (the cout block the
+// launch will use, see convTiling), CK = convCK(cinP).  `cinMap[k]` = source input
+// channel of packed channel k, or -1 for a zero channel (cinMap.size() == cinP,
+// a multiple of 16).
 std::vector<std::uint16_t> packConvWeights(
-    const FoldedConv &c, const std::vector<int> &cinMap, DType dt);
+    const FoldedConv &c, const std::vector<int> &cinMap, int nb, DType dt);
 
 std::uint16_t floatToF16(float f);
 std::uint16_t floatToBF16(float f);

@@ -9,7 +9,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from joshupscale_amd import model_file as M  # noqa: E402
 from joshupscale_amd import runtime as R  # noqa: E402
 
-NAMES = {0: "full", 1: "no MFMA loop", 2: "no epilogue", 3: "no tile staging", 4: "no weight staging"}
+NAMES = {0: "full", 1: "no halo exchange", 2: "no MFMA loop", 3: "neither"}
+if os.environ.get("JU_TOWER") == "layers":
+    NAMES = {0: "full", 1: "no MFMA loop", 2: "no epilogue", 3: "no tile staging", 4: "no weight staging"}
 cfg = M.PRESETS["psp-quality"]
 rt = R.Runtime(M.serialize(cfg, M.make_seeded_weights(cfg)), 0, R.DTYPE_BF16)
 lib = R.load_library()
