@@ -139,7 +139,8 @@ def main() -> int:
                 "whole_frame_tflops": total_flops * fps / world / 1e12,
             },
             "roofline": {
-                "kernel": "conv_mfma 3x3 64->64 (generator residual tower)",
+                "kernel": "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch"
+                          if launches == 1 else "conv_tower_kernel 3x3 64->64 (one residual-block conv)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": None,
                 "launch_ms": ms, "launches_per_frame": launches,

@@ -289,16 +289,14 @@ void Engine::buildProgram(int set) {
 	const char *xs[2] = {"trunk_a", "trunk_b"};
 	int a = 0;
 	if (m_Resident) {
-		// zero the epoch flags, then one launch for the whole tower
-		unsigned *flags = m_ResFlags.as<unsigned>();
-		const std::size_t flagBytes = m_ResFlags.bytes();
+		// one launch for the whole tower (plus the 1-thread generation bump)
 		ResidentTowerParams rp{};
 		rp.in = Op("trunk_a").ptr;
 		rp.out = Op("trunk_b").ptr;
 		rp.weights = m_TowerW.get();
 		rp.bias = m_TowerB.as<float>();
 		rp.mailbox = m_ResMail.get();
-		rp.flags = flags;
+		rp.generation = m_ResFlags.as<unsigned>();
 		rp.error = m_ResErrorDev;
 		rp.H = H;
 		rp.W = W;
@@ -306,10 +304,8 @@ void Engine::buildProgram(int set) {
 		rp.GY = m_ResGY;
 		rp.RH = m_ResRH;
 		rp.nLayers = 2 * c.genBlocks;
-		prog.push_back({"tower", 2.0 * H * W * 9.0 * 64 * 64 * rp.nLayers, [=](hipStream_t s) {
-			                JU_HIP(hipMemsetAsync(flags, 0, flagBytes, s));  // epochs count within a launch
-			                launchResidentTower(dt, rp, s);
-		                }});
+		prog.push_back({"tower", 2.0 * H * W * 9.0 * 64 * 64 * rp.nLayers,
+		    [=](hipStream_t s) { launchResidentTower(dt, rp, s); }});
 		a = 1;
 	} else {
 		for (int i = 0; i < c.genBlocks; ++i) {
@@ -388,7 +384,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 			m_TowerB = DeviceBuffer(m_TowerHostB.size() * 4);
 			m_TowerB.upload(m_TowerHostB.data(), m_TowerHostB.size() * 4);
 			m_ResMail = DeviceBuffer(residentMailboxBytes(m_ResGX, m_ResGY));
-			m_ResFlags = DeviceBuffer((static_cast<std::size_t>(m_ResGX) * m_ResGY * 4 + 15) / 16 * 16);
+			// word 0: launch generation; from byte 64: one flag word per region
+			m_ResFlags = DeviceBuffer(64 + (static_cast<std::size_t>(m_ResGX) * m_ResGY * 4 + 15) / 16 * 16);
 			JU_HIP(hipHostMalloc(reinterpret_cast<void **>(&m_ResErrorHost), 64, hipHostMallocMapped));
 			*m_ResErrorHost = 0;
 			JU_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&m_ResErrorDev), m_ResErrorHost, 0));

@@ -99,8 +99,9 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream);
 // ---- resident tower: every residual-block convolution in one launch --------
 // in/out: tower-layout tensors addressed at their interior origin.  weights:
 // nLayers consecutive 64->64 3x3 kernels in packConvWeights order; bias nLayers x 64.
-// mailbox (residentMailboxBytes) and flags (GX*GY u32, zeroed before each launch)
-// carry the halo exchange between neighbouring workgroups; *error is written
+// mailbox (residentMailboxBytes, zeroed once) carries the halo exchange between
+// neighbouring workgroups as tagged granules; *generation (one zero-initialised
+// device word) is bumped by every launch so tags never repeat; *error is written
 // (non-zero) if a bounded wait expires.  Needs GX*GY co-resident workgroups.
 struct ResidentTowerParams {
 	const void *in;
@@ -108,7 +109,7 @@ struct ResidentTowerParams {
 	const void *weights;
 	const float *bias;
 	void *mailbox;
-	unsigned *flags;
+	unsigned *generation;
 	unsigned *error;
 	int H, W;
 	int GX, GY, RH;

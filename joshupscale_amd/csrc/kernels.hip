@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -612,14 +613,18 @@ void launchTowerT(const ConvParams &p, hipStream_t stream) {
 //   * the wave's weights (its 32 output channels x 576) are the MFMA A operand
 //     straight from 144 VGPRs, double-buffered (288) so the next layer's weights
 //     stream in from L2 behind the current layer's MFMAs;
-//   * after every layer only the edge ring (<= 94 px) is exchanged with the <= 8
-//     neighbouring workgroups through a global mailbox: write-through (sc1)
-//     stores, every storing wave drains vmcnt, workgroup barrier, one lane
-//     publishes an epoch flag; the consumer polls the flags (bounded), then reads
-//     the payload with sc1 loads only (cdna_hip_programming.md Guideline 16, R1).
-// Nothing here depends on dispatch order or XCD placement; all workgroups must be
-// co-resident (grid <= #CUs, one workgroup per CU by LDS size), every spin is
-// bounded and reports through *error.
+//   * after every layer only the edge ring (<= 94 px, 12 KB) is exchanged with the
+//     <= 8 neighbouring workgroups through a global mailbox of self-validating
+//     16-byte slots (epoch tag in the 8 free sign bits of post-ReLU values), one
+//     write-through (sc1) store each, no drain and no release; a relaxed flag is
+//     only a hint to start looking; the consumer reads with 16-byte sc1 loads and
+//     retries slots whose tag is still old (cdna_hip_programming.md Guideline 16:
+//     the "data is the flag" form R2, at 16 B).  Measured alternatives: drained
+//     stores + flag + load (R1) 4.1 us per layer; 8-byte {tag,data} granules 13 us
+//     (write-through stores are one fabric transaction each, so width matters).
+// Nothing depends on dispatch order or XCD placement; all workgroups must be
+// co-resident (grid <= #CUs, one workgroup per CU by LDS size); every wait is
+// bounded in time and reports through *error.
 constexpr int kResRW = 30;
 constexpr int kResMaxRH = 17;
 constexpr int kResRowBytes = 32 * 128;
@@ -627,8 +632,8 @@ constexpr int kResBufBytes = (kResMaxRH + 2) * kResRowBytes;       // 77824
 constexpr int kResOffA = 0;
 constexpr int kResOffB = kResBufBytes + 256;                        // A's overrun pad
 constexpr int kResOffMisc = kResOffB + kResBufBytes + kResRowBytes + 256;
-constexpr int kResLds = kResOffMisc + 64 + 512;                     // 160832 B (flag, 2 bias slots)
-constexpr int kResMailWords = 4 * 32 * 16;                          // u64 per region per parity
+constexpr int kResLds = kResOffMisc + 64 + 512;                     // flag, 2 bias slots
+constexpr int kResMailSlots = 4 * 32 * 8;                           // 16-byte slots per region per parity
 constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of s_memrealtime
 
 struct ResidentParams {
@@ -636,8 +641,9 @@ struct ResidentParams {
 	void *out;                // tower-layout tensor, allocation start (last block output)
 	const void *weights;      // nLayers x 73728 B, kernel-ready (packConvWeights)
 	const float *bias;        // nLayers x 64
-	unsigned long long *mail; // [regions][2][kResMailWords]
-	unsigned *flags;          // [regions], zeroed before every launch
+	uint4 *mail;              // [regions][2][kResMailSlots] 16-byte slots
+	unsigned *flag;           // [regions] {generation<<8 | layers published}
+	const unsigned *gen;      // launch generation (bumped by bump_generation_kernel)
 	unsigned *error;          // host-visible word, 0 = ok
 	int H, W, pitch;
 	int GX, GY, RH;
@@ -648,10 +654,15 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
+__global__ void bump_generation_kernel(unsigned *gen) {
+	*gen = *gen + 1;
+}
+
 // VARIANT: timing ablation only (0 = product; bit 0 = no halo exchange, bit 1 = no MFMA loop)
 template <typename T, int VARIANT>
 __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr bool xchg = !(VARIANT & 1);
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6;
 	const int lane = tid & 63;
@@ -667,6 +678,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int rwv = min(kResRW, p.W - x0);  // valid columns / rows of this region
 	const int rhv = min(p.RH, p.H - y0);
 	volatile int *failFlag = reinterpret_cast<volatile int *>(smem + kResOffMisc);
+	float *ldsBias = reinterpret_cast<float *>(smem + kResOffMisc + 64);
+	const unsigned genTag = (*p.gen) << 8;  // uniform; never matches a previous launch
 
 	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
 	    (__attribute__((address_space(3))) unsigned char *)smem));
@@ -701,15 +714,17 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	};
 	loadWeights(0, w0);
 	float biasNext = 0.f;  // wave 0: next layer's bias in flight (one value per lane)
-	if (wave == 0) reinterpret_cast<float *>(smem + kResOffMisc + 64)[lane] = p.bias[lane];
+	if (wave == 0) ldsBias[lane] = p.bias[lane];
 
 	// per-lane LDS address parts (the swizzle depends only on the column: rows are 32 px)
-	unsigned colsw[12];  // [dx*4+ks]: byte offset of this lane's B fragment inside a row
+	// B fragment of macro-step (dx, ks): byte offset inside a row =
+	// colBase[dx] + (((ks*2+hh) ^ colSwz[dx]) << 4); 6 registers instead of 12
+	unsigned colBase[3], colSwz[3];
 #pragma unroll
-	for (int m = 0; m < 12; ++m) {
-		const int dx = m >> 2, ks = m & 3;
+	for (int dx = 0; dx < 3; ++dx) {
 		const int cq = px + dx;
-		colsw[m] = cq * 128 + (((ks * 2 + hh) ^ ((cq >> 1) & 7)) << 4);
+		colBase[dx] = cq * 128;
+		colSwz[dx] = (cq >> 1) & 7;
 	}
 	unsigned outsw[4];  // [g]: byte offset of this lane's 4 output channels inside a row
 #pragma unroll
@@ -724,69 +739,94 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// ------------------------------------------------------------------------
 	// one convolution layer over the region: in/out are LDS buffer offsets
 	// ------------------------------------------------------------------------
-	// bias of layer l sits in LDS slot l&1 (staged one layer ahead, see the tower loop)
-	float *ldsBias = reinterpret_cast<float *>(smem + kResOffMisc + 64);
 	auto computeLayer = [&](const int layer, const int inOff, const int outOff,
 	                        const bool residual, const Vec8<T>(&w)[36]) {
-		f32x4 bias[4];
-#pragma unroll
-		for (int g = 0; g < 4; ++g) {
-			bias[g] = *reinterpret_cast<const f32x4 *>(
-			    ldsBias + (layer & 1) * 64 + ch * 32 + 8 * g + 4 * hh);
-		}
-		const int nPairs = (rhv + 1) >> 1;
-		for (int pair = rp; pair < nPairs; pair += 2) {
-			const int ra = 1 + 2 * pair;  // output rows ra, ra+1 (buffer row indices)
-			f32x16 acc[2];
+		const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
+
+		// rows of this wave: full pairs j = rp, rp+2, ... and, for an odd region
+		// height, the last row as a single-row unit on the wave group with fewer pairs
+		const int np2 = rhv >> 1;
+		const int nUnits = np2 + (rhv & 1);
+		Vec8<T> fb[2][4];
+		auto issue = [&](unsigned rowAddr, int m, int set, int j) {
+			const int dx = m >> 2, ks = m & 3;
+			const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
+			if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
+			else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[set][1]) : "v"(a));
+			else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fb[set][2]) : "v"(a));
+			else asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fb[set][3]) : "v"(a));
+		};
+		auto rowAddrOf = [&](int unit) { return ldsBase + inOff + (2 * unit) * kResRowBytes; };
+
+		// ROWS = 2: a row pair; ROWS = 1: the odd last row.  `primed`: this unit's
+		// first 4 fragments were already issued by the previous unit's last step.
+		auto unitBody = [&](auto rowsTag, const int unit, const bool primed, const int nextUnit) {
+			constexpr int ROWS = decltype(rowsTag)::value;
+			constexpr int NR = ROWS + 2;      // input rows / fragment reads per macro-step
+			constexpr int NM = 3 * ROWS;      // MFMAs per macro-step
+			const int ra = 1 + 2 * unit;      // first output row (buffer row index)
+			f32x16 acc[ROWS];
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
+				const f32x4 bg = *reinterpret_cast<const f32x4 *>(biasPtr + 8 * g);
 #pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					acc[0][4 * g + i] = bias[g][i];
-					acc[1][4 * g + i] = bias[g][i];
+				for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = bg[i];
 				}
 			}
-			const unsigned rowAddr = ldsBase + inOff + (ra - 1) * kResRowBytes;
-			Vec8<T> fb[2][4];
-			auto issue = [&](int m, int set, int j) {
-				const unsigned a = rowAddr + colsw[m];
-				if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
-				else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[set][1]) : "v"(a));
-				else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fb[set][2]) : "v"(a));
-				else asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fb[set][3]) : "v"(a));
-			};
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-			__builtin_amdgcn_sched_barrier(0);
+			const unsigned rowAddr = rowAddrOf(unit);
+			if (!(VARIANT & 2)) {
+				if (!primed) {
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for (int j = 0; j < ((VARIANT & 2) ? 0 : 4); ++j) issue(0, 0, j);
-			// MFMA k = (dy, r) = (k>>1, k&1) uses w[(dy*3+dx)*4+ks] and fb[r+dy];
-			// reads are consumed in order b0 b1 b2 b3 -> index needed by MFMA k:
-			constexpr int needs[6] = {0, 1, -1, 2, -1, 3};
+					for (int j = 0; j < NR; ++j) issue(rowAddr, 0, 0, j);
+				}
 #pragma unroll
-			for (int m = 0; m < ((VARIANT & 2) ? 0 : 12); ++m) {
-				const int set = m & 1;
-				const bool more = (m + 1 < 12);
-				const int dx = m >> 2, ks = m & 3;
+				for (int m = 0; m < 12; ++m) {
+					const int set = m & 1;
+					const bool more = (m + 1 < 12);
+					const int dx = m >> 2, ks = m & 3;
 #pragma unroll
-				for (int k = 0; k < 6; ++k) {
-					if (needs[k] >= 0) {
-						const int allowed = (3 - needs[k]) + (more ? (k < 4 ? k : 4) : 0);
-						if (allowed >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-						else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-						else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-						else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-						else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					for (int k = 0; k < NM; ++k) {
+						// MFMA k = (dy, r): ROWS=2 -> (k>>1, k&1); ROWS=1 -> (k, 0); it needs
+						// fragment r+dy, fragments are read (and return) in order 0..NR-1
+						const int dy = ROWS == 2 ? (k >> 1) : k;
+						const int r = ROWS == 2 ? (k & 1) : 0;
+						const int need = r + dy;
+						const bool fresh = ROWS == 2 ? (k == 0 || k == 1 || k == 3 || k == 5) : true;
+						if (fresh) {
+							// outstanding allowed = younger reads of this step + next step's issued so far
+							const int issuedNext = more ? (k < NR ? k : NR) : 0;
+							const int allowed = (NR - 1 - need) + issuedNext;
+							if (allowed >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+							else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+							else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+							else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+							else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+							__builtin_amdgcn_sched_barrier(0);
+						}
+						acc[r] = mfma32(w[(dy * 3 + dx) * 4 + ks], fb[set][need], acc[r]);
+						if (more && k < NR) issue(rowAddr, m + 1, set ^ 1, k);
 						__builtin_amdgcn_sched_barrier(0);
 					}
-					const int dy = k >> 1, r = k & 1;
-					acc[r] = mfma32(w[(dy * 3 + dx) * 4 + ks], fb[set][r + dy], acc[r]);
-					if (more && k < 4) issue(m + 1, set ^ 1, k);
+				}
+				// prime the next unit (always a pair or single with >= 3 input rows): its
+				// first fragments travel while this unit's epilogue runs
+				if (nextUnit >= 0) {
+					const unsigned na = rowAddrOf(nextUnit);
+					const bool nextSingle = (nextUnit == np2);
+#pragma unroll
+					for (int j = 0; j < 3; ++j) issue(na, 0, 0, j);
+					if (!nextSingle) issue(na, 0, 0, 3);
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
-			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
+			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior;
+			//      edge pixels also go to the mailbox as tagged granules ----
 #pragma unroll
-			for (int r = 0; r < 2; ++r) {
+			for (int r = 0; r < ROWS; ++r) {
 				const int rr = ra + r;
 				if (rr <= rhv && px < rwv) {
 #pragma unroll
@@ -808,24 +848,57 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					}
 				}
 			}
+		};
+
+		// pairs u = rp, rp+2, ... ; the odd last row goes to the wave group with fewer
+		// pairs (group 0 when both have the same number)
+		const bool mySingle = (rhv & 1) && rp == (np2 & 1);
+		bool primed = false;
+		for (int u = rp; u < np2; u += 2) {
+			const int nu = (u + 2 < np2) ? u + 2 : (mySingle ? np2 : -1);
+			unitBody(std::integral_constant<int, 2>{}, u, primed, nu);
+			primed = nu >= 0 && !(VARIANT & 2);
 		}
+		if (mySingle) unitBody(std::integral_constant<int, 1>{}, np2, primed, -1);
+		(void)nUnits;
 	};
 
 	// ------------------------------------------------------------------------
 	// edge ring -> mailbox (publish) and neighbours' mailboxes -> halo ring
 	// ------------------------------------------------------------------------
-	// LDS address of 8-byte word w8 of pixel (rr, cc) in buffer `off`
-	auto ldsWord = [&](int off, int rr, int cc, int w8) -> unsigned char * {
-		const int c = w8 >> 1;
-		return smem + off + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4) + (w8 & 1) * 8;
+	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * kResMailSlots * 16), 0x00020000);
+	constexpr int kSc1 = 16;  // cache-policy bit of sc1 (write-through store / L2-bypassing load)
+	// LDS address of 16-byte chunk c of pixel (rr, cc) in buffer `off`
+	auto ldsChunk = [&](int off, int rr, int cc, int c) -> unsigned char * {
+		return smem + off + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4);
 	};
-	auto publish = [&](int off, unsigned epoch) {
-		__syncthreads();  // the whole region's output is in LDS
-		gu64 *mb = (gu64 *)(p.mail + ((size_t)region * 2 + (epoch & 1)) * kResMailWords);
+	// Self-validating slots: every tower output is post-ReLU (>= 0), so the sign bit
+	// of each of the 8 values in a 16-byte slot is free; it carries one bit of an
+	// 8-bit epoch tag {generation & 3, layer + 1}.  Consecutive writes to the same
+	// slot (layers l-2, l, l+2, ... and the previous launch) always differ in tag,
+	// so a consumer can tell "new" from "old" from the payload itself and the
+	// producer needs neither a drain nor a release: ONE hop instead of
+	// store-ack -> flag -> load.  The flag below is only a hint that keeps 65k
+	// threads from polling the fabric before the data can possibly be there.
+	auto tagMasks = [&](int layer, u32x4 *m) {
+		const unsigned t = ((genTag >> 8) & 3u) << 6 | (unsigned)((layer + 1) & 63);
 #pragma unroll
-		for (int it = 0; it < kResMailWords / 256; ++it) {
+		for (int k = 0; k < 4; ++k) {
+			(*m)[k] = ((t >> (2 * k)) & 1u) << 15 | ((t >> (2 * k + 1)) & 1u) << 31;
+		}
+	};
+	// `layer`: the layer whose output (in buffer `off`) is published
+	auto publish = [&](int off, int layer) {
+		__syncthreads();  // the whole region's output is in LDS
+		u32x4 tm;
+		tagMasks(layer, &tm);
+		const unsigned base = (unsigned)((region * 2 + ((layer + 1) & 1)) * kResMailSlots) * 16u;
+#pragma unroll
+		for (int it = 0; it < kResMailSlots / 256; ++it) {
 			const int idx = it * 256 + tid;
-			const int strip = idx >> 9, e = (idx >> 4) & 31, w8 = idx & 15;
+			const int strip = idx >> 8, e = (idx >> 3) & 31, c = idx & 7;
 			int rr, cc;
 			bool valid;
 			if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
@@ -833,58 +906,55 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
 			else { rr = e + 1; cc = rwv; valid = e < rhv; }
 			if (valid) {
-				const u64 v = *reinterpret_cast<const u64 *>(ldsWord(off, rr, cc, w8));
-				__hip_atomic_store(mb + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1
+				u32x4 v = *reinterpret_cast<const u32x4 *>(ldsChunk(off, rr, cc, c));
+				v = (v & 0x7fff7fffu) | tm;
+				__builtin_amdgcn_raw_buffer_store_b128(v, mailRsrc, base + idx * 16, 0, kSc1);
 			}
 		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains
-		__syncthreads();
-		if (tid == 0) {
-			__hip_atomic_store((gu32 *)(p.flags + region), epoch, __ATOMIC_RELAXED,
-			    __HIP_MEMORY_SCOPE_AGENT);
+		if (tid == 0) {  // hint only: no drain, no barrier
+			__hip_atomic_store((gu32 *)(p.flag + region), genTag | (unsigned)(layer + 1),
+			    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	};
+	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
 	// returns false on timeout (uniform across the workgroup)
-	auto fillHalo = [&](int off, unsigned epoch) -> bool {
-		if (wave == 0) {
+	constexpr bool kUseHint = false;  // measured: polling a hint flag first is not faster than sweeping
+	auto fillHalo = [&](int off, int layer) -> bool {
+		const unsigned want = genTag | (unsigned)(layer + 1);
+		(void)want;
+		const u64 t0 = __builtin_amdgcn_s_memrealtime();
+		if (wave == 0 && kUseHint) {
 			bool ready = true;
+			const gu32 *f = nullptr;
 			if (lane < 8) {
 				const int k = lane < 4 ? lane : lane + 1;  // skip the centre of the 3x3
 				const int nx = gxr + (k % 3) - 1, ny = gyr + (k / 3) - 1;
 				if (nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY) {
-					const gu32 *f = (const gu32 *)(p.flags + ny * p.GX + nx);
-					const u64 t0 = __builtin_amdgcn_s_memrealtime();
-					for (;;) {
-						const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						if (v >= epoch) break;
-						if (__builtin_amdgcn_s_memrealtime() - t0 > kResTimeoutTicks) {
-							ready = false;
-							break;
-						}
-						__builtin_amdgcn_s_sleep(2);
-					}
+					f = (const gu32 *)(p.flag + ny * p.GX + nx);
+					ready = false;
 				}
 			}
-			if (!__all(ready)) {
-				if (lane == 0) {
-					*failFlag = 1;
-					__hip_atomic_store((gu32 *)p.error, 0x700u + epoch, __ATOMIC_RELAXED,
-					    __HIP_MEMORY_SCOPE_SYSTEM);
+			while (!__all(ready)) {
+				if (!ready) {
+					const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					ready = (v - want) <= 1u;  // a neighbour is at most one layer ahead
 				}
+				if (__builtin_amdgcn_s_memrealtime() - t0 > kResTimeoutTicks) break;  // the sweep reports it
+				__builtin_amdgcn_s_sleep(1);
 			}
 		}
-		__syncthreads();
-		if (*failFlag) return false;
-		const int par = epoch & 1;
-		// All 8 loads are issued unconditionally (invalid entries read this region's
-		// own mailbox and are dropped) so they are in flight together; a load inside
-		// `if (valid)` makes hipcc wait vmcnt(0) per element: 8 serial round trips.
-		u64 hv[kResMailWords / 256];
-		unsigned char *hd[kResMailWords / 256];
+		if (kUseHint) __syncthreads();
+		const int par = (layer + 1) & 1;
+		u32x4 tm;
+		tagMasks(layer, &tm);
+		constexpr int NS = kResMailSlots / 256;
+		unsigned hsrc[NS];
+		unsigned char *hd[NS];
+		unsigned pending = 0;
 #pragma unroll
-		for (int it = 0; it < kResMailWords / 256; ++it) {
+		for (int it = 0; it < NS; ++it) {
 			const int idx = it * 256 + tid;
-			const int hp = idx >> 4, w8 = idx & 15;
+			const int hp = idx >> 3, c = idx & 7;
 			const int side = hp >> 5, e = hp & 31;
 			// side 0: row above, 1: row below, 2: column left, 3: column right;
 			// entries 30/31 of the two row sides are the corners
@@ -907,17 +977,39 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			}
 			valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
 			const int nreg = valid ? ny * p.GX + nx : region;
-			const gu64 *mb = (const gu64 *)(p.mail + ((size_t)nreg * 2 + par) * kResMailWords);
-			hv[it] = __hip_atomic_load(mb + (strip * 32 + se) * 16 + w8, __ATOMIC_RELAXED,
-			    __HIP_MEMORY_SCOPE_AGENT);  // sc1: never a stale L1/L2 line
-			hd[it] = valid ? ldsWord(off, rr, cc, w8) : nullptr;
+			hsrc[it] = (unsigned)((nreg * 2 + par) * kResMailSlots + (strip * 32 + se) * 8 + c) * 16u;
+			hd[it] = ldsChunk(off, rr, cc, c);
+			if (valid) pending |= 1u << it;
 		}
+		// sweep: all loads of a pass in flight together, sc1 (never a stale L1/L2 line);
+		// a slot is accepted only when all 8 tag bits match
+		while (__any(pending != 0)) {
+			u32x4 hv[NS];
 #pragma unroll
-		for (int it = 0; it < kResMailWords / 256; ++it) {
-			if (hd[it] != nullptr) *reinterpret_cast<u64 *>(hd[it]) = hv[it];
+			for (int it = 0; it < NS; ++it) {
+				hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, hsrc[it], 0, kSc1);
+			}
+#pragma unroll
+			for (int it = 0; it < NS; ++it) {
+				const u32x4 tg = hv[it] & 0x80008000u;
+				const bool ok = tg[0] == tm[0] && tg[1] == tm[1] && tg[2] == tm[2] && tg[3] == tm[3];
+				if ((pending >> it & 1u) && ok) {
+					*reinterpret_cast<u32x4 *>(hd[it]) = hv[it] & 0x7fff7fffu;
+					pending &= ~(1u << it);
+				}
+			}
+			if (pending != 0) {
+				if (__builtin_amdgcn_s_memrealtime() - t0 > kResTimeoutTicks) {
+					*failFlag = 1;
+					__hip_atomic_store((gu32 *)p.error, 0x700u + (unsigned)layer, __ATOMIC_RELAXED,
+					    __HIP_MEMORY_SCOPE_SYSTEM);
+					break;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
 		}
 		__syncthreads();
-		return true;
+		return *failFlag == 0;
 	};
 
 	// ------------------------------------------------------------------------
@@ -926,32 +1018,31 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int nBlocks = p.nLayers >> 1;
 	for (int blk = 0; blk < nBlocks; ++blk) {
 		const int l0 = 2 * blk;
-		constexpr bool xchg = !(VARIANT & 1);
-		// Order matters: vmcnt is in-order, so the next layer's weight stream (36 loads
-		// per lane) is issued AFTER the halo's sc1 loads and lands behind the MFMAs.
+		const bool last = l0 + 2 >= p.nLayers;
+		// vmcnt is in-order: the next layer's weight stream (36 loads per lane) is issued
+		// AFTER the halo loads so they never queue behind it, and lands behind the MFMAs.
 		if (blk > 0 && xchg) {
-			if (!fillHalo(kResOffA, l0)) return;
+			if (!fillHalo(kResOffA, l0 - 1)) return;
 		}
 		loadWeights(l0 + 1, w1);
 		if (wave == 0) biasNext = p.bias[(l0 + 1) * 64 + lane];
 		computeLayer(l0, kResOffA, kResOffB, false, w0);
 		if (wave == 0) ldsBias[((l0 + 1) & 1) * 64 + lane] = biasNext;
-		if (xchg) publish(kResOffB, l0 + 1);
-		else __syncthreads();
 		if (xchg) {
-			if (!fillHalo(kResOffB, l0 + 1)) return;
+			publish(kResOffB, l0);
+			if (!fillHalo(kResOffB, l0)) return;
+		} else {
+			__syncthreads();
 		}
-		const bool last = l0 + 2 >= p.nLayers;
 		if (!last) {
 			loadWeights(l0 + 2, w0);
 			if (wave == 0) biasNext = p.bias[(l0 + 2) * 64 + lane];
 		}
 		computeLayer(l0 + 1, kResOffB, kResOffA, true, w1);
 		if (!last && wave == 0) ldsBias[((l0 + 2) & 1) * 64 + lane] = biasNext;
-		if (!last && xchg) publish(kResOffA, l0 + 2);
+		if (!last && xchg) publish(kResOffA, l0 + 1);
 		else __syncthreads();
 	}
-	__syncthreads();
 
 	// ---- last block output: region interior -> global tower-layout tensor ----
 	{
@@ -984,6 +1075,8 @@ void launchResidentT(const ResidentParams &p, hipStream_t stream) {
 		}
 		attrSet = true;
 	}
+	hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream,
+	    const_cast<unsigned *>(p.gen));
 	hipLaunchKernelGGL(kern, dim3(p.GX * p.GY), dim3(256), kResLds, stream, p);
 	hipCheckLaunch("tower_resident");
 }
@@ -1319,7 +1412,7 @@ bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH) 
 }
 
 std::size_t residentMailboxBytes(int GX, int GY) {
-	return static_cast<std::size_t>(GX) * GY * 2 * kResMailWords * 8;
+	return static_cast<std::size_t>(GX) * GY * 2 * kResMailSlots * 16;
 }
 
 void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t stream) {
@@ -1329,8 +1422,9 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.out = static_cast<unsigned char *>(q.out) - origin;
 	p.weights = q.weights;
 	p.bias = q.bias;
-	p.mail = static_cast<unsigned long long *>(q.mailbox);
-	p.flags = q.flags;
+	p.mail = static_cast<uint4 *>(q.mailbox);
+	p.gen = q.generation;
+	p.flag = q.generation + 16;  // same small buffer: word 0 = generation, flags from byte 64
 	p.error = q.error;
 	p.H = q.H;
 	p.W = q.W;
