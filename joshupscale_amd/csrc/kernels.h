@@ -63,6 +63,9 @@ inline int convCK(int cin) { return cin % 64 == 0 ? 64 : (cin % 32 == 0 ? 32 : 1
 // (nb = 2 cout blocks, rw = 2 rows per wave) but fall back to smaller tiles until
 // the launch has enough workgroups to occupy the chip; the coarse levels of the
 // flow auto-encoder (34x60 ... 68x120 pixels) otherwise run on 40-80 of 256 CUs.
+// >= 2 workgroups per CU: the generic kernel stages synchronously, so a second
+// resident workgroup is what overlaps loads with MFMAs.
+constexpr long kConvTargetWgs = 512;
 inline void convTiling(int H, int W, int cout, int *nb, int *rw) {
 	const int tilesX = (W + 31) / 32;
 	int bestNb = 1, bestRw = 1;
@@ -73,7 +76,9 @@ inline void convTiling(int H, int W, int cout, int *nb, int *rw) {
 		if (cout % (32 * nbs[a]) != 0) continue;
 		for (int b = 0; b < 2; ++b) {
 			const long wgs = (long)tilesX * ((H + 4 * rws[b] - 1) / (4 * rws[b])) * (cout / (32 * nbs[a]));
-			if (wgs >= 256) {
+			// the largest tile is kept as soon as it fills the chip once (least weight
+			// restaging); smaller tiles must reach two workgroups per CU to pay
+			if (wgs >= ((a == 0 && b == 0) ? 256 : kConvTargetWgs)) {
 				*nb = nbs[a];
 				*rw = rws[b];
 				return;

@@ -134,23 +134,39 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 			const uint4 *src = reinterpret_cast<const uint4 *>(
 			    wgt + (size_t)(cog * nCC + cc) * (TAPS * CK * COG));
 			uint4 *dst = reinterpret_cast<uint4 *>(smW);
-#pragma unroll 4
+#pragma unroll 6
 			for (int i = tid; i < W_BYTES / 16; i += kConvThreads) dst[i] = src[i];
 		}
 		// ---- stage the input tile (+halo), zero outside the image ----
-		for (int i = tid; i < IH * IW * P; i += kConvThreads) {
-			const int q = i / P;
-			const int c = i % P;
-			const int r = q / IW;
-			const int x = q - r * IW;
-			const int gy = ty0 - HALO + r;
-			const int gx = tx0 - HALO + x;
-			uint4 v = make_uint4(0, 0, 0, 0);
-			if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-				v = *reinterpret_cast<const uint4 *>(
-				    in + ((size_t)gy * inPitch + gx) * p.cin + cc * CK + c * 8);
+		// Loads are issued unconditionally on clamped coordinates and zeroed by a
+		// select: a load under `if (in bounds)` makes hipcc wait vmcnt(0) per element,
+		// i.e. one serial memory round trip per 16 bytes per thread.
+		{
+			constexpr int N = IH * IW * P;
+			constexpr int ITER = (N + kConvThreads - 1) / kConvThreads;
+			uint4 v[ITER];
+			int dstOff[ITER];
+#pragma unroll
+			for (int k = 0; k < ITER; ++k) {
+				const int i = min(tid + k * kConvThreads, N - 1);
+				const int q = i / P;
+				const int c = i % P;
+				const int r = q / IW;
+				const int x = q - r * IW;
+				const int gy = ty0 - HALO + r;
+				const int gx = tx0 - HALO + x;
+				const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+				const int cy = min(max(gy, 0), p.H - 1);
+				const int cx = min(max(gx, 0), p.W - 1);
+				v[k] = *reinterpret_cast<const uint4 *>(
+				    in + ((size_t)cy * inPitch + cx) * p.cin + cc * CK + c * 8);
+				if (!inb) v[k] = make_uint4(0, 0, 0, 0);
+				dstOff[k] = (tid + k * kConvThreads < N) ? q * (CK * 2) + ((c ^ swz<P>(q)) << 4) : -1;
 			}
-			*reinterpret_cast<uint4 *>(smI + q * (CK * 2) + ((c ^ swz<P>(q)) << 4)) = v;
+#pragma unroll
+			for (int k = 0; k < ITER; ++k) {
+				if (dstOff[k] >= 0) *reinterpret_cast<uint4 *>(smI + dstOff[k]) = v[k];
+			}
 		}
 		__syncthreads();
 		// ---- MFMA over taps x k-steps ----
