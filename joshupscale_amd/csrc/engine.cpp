@@ -73,7 +73,8 @@ Engine::Operand Engine::operand(const std::string &name) {
 Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &f,
     const std::vector<int> &cinMap, int H, int W) {
 	ConvWeights cw;
-	const bool towerLayer = name.rfind("generator/block_", 0) == 0;
+	// generator conv_1 (64 padded input channels) runs as layer 0 of the resident tower
+	const bool towerLayer = name.rfind("generator/block_", 0) == 0 || name == "generator/conv_1";
 	if (towerLayer && f.cout == 64) {
 		cw.nb = 2;  // the tower kernels read the 64-cout layout
 		cw.rw = 2;
@@ -284,14 +285,18 @@ void Engine::buildProgram(int set) {
 		                }});
 	}
 	// ---- generator ----
-	addConvStep(&prog, "gen_head", "generator/conv_1", Op("gen_in"), none, Op("trunk_a"), H, W,
-	    true, false);
+	if (!m_Resident) {
+		addConvStep(&prog, "gen_head", "generator/conv_1", Op("gen_in"), none, Op("trunk_a"), H, W,
+		    true, false);
+	}
 	const char *xs[2] = {"trunk_a", "trunk_b"};
 	int a = 0;
 	if (m_Resident) {
 		// one launch for the whole tower (plus the 1-thread generation bump)
 		ResidentTowerParams rp{};
-		rp.in = Op("trunk_a").ptr;
+		rp.in = Op("gen_in").ptr;  // dense [H][W][64]; conv_1 is layer 0 of the launch
+		rp.inPitch = W;
+		rp.hasHead = 1;
 		rp.out = Op("trunk_b").ptr;
 		rp.weights = m_TowerW.get();
 		rp.bias = m_TowerB.as<float>();
@@ -303,8 +308,8 @@ void Engine::buildProgram(int set) {
 		rp.GX = m_ResGX;
 		rp.GY = m_ResGY;
 		rp.RH = m_ResRH;
-		rp.nLayers = 2 * c.genBlocks;
-		prog.push_back({"tower", 2.0 * H * W * 9.0 * 64 * 64 * rp.nLayers,
+		rp.nLayers = 1 + 2 * c.genBlocks;
+		prog.push_back({"tower", 2.0 * H * W * 9.0 * (51.0 * 64 + 64.0 * 64 * 2 * c.genBlocks),
 		    [=](hipStream_t s) { launchResidentTower(dt, rp, s); }});
 		a = 1;
 	} else {

@@ -102,14 +102,19 @@ void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
 void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream);
 
 // ---- resident tower: every residual-block convolution in one launch --------
-// in/out: tower-layout tensors addressed at their interior origin.  weights:
-// nLayers consecutive 64->64 3x3 kernels in packConvWeights order; bias nLayers x 64.
+// in: first layer's input addressed at image pixel (0,0) with row pitch inPitch
+// (0 = dense W); out: tower-layout tensor addressed at its interior origin.
+// weights: nLayers consecutive 64->64 3x3 kernels in packConvWeights (nb = 2)
+// order, bias nLayers x 64.  hasHead: layer 0 is a plain conv+ReLU (generator
+// conv_1), residual blocks (conv, conv + skip) follow.
 // mailbox (residentMailboxBytes, zeroed once) carries the halo exchange between
 // neighbouring workgroups as tagged granules; *generation (one zero-initialised
 // device word) is bumped by every launch so tags never repeat; *error is written
 // (non-zero) if a bounded wait expires.  Needs GX*GY co-resident workgroups.
 struct ResidentTowerParams {
 	const void *in;
+	int inPitch;
+	int hasHead;
 	void *out;
 	const void *weights;
 	const float *bias;

@@ -653,8 +653,10 @@ constexpr int kResMailSlots = 4 * 32 * 8;                           // 16-byte s
 constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of s_memrealtime
 
 struct ResidentParams {
-	const void *in;           // tower-layout tensor, allocation start (block 0 input)
-	void *out;                // tower-layout tensor, allocation start (last block output)
+	const void *in;           // first layer's input, addressed at image pixel (0,0)
+	int inPitch;              // its row pitch in pixels (dense W, or towerPitch(W))
+	int hasHead;              // 1: layer 0 is the generator's conv_1 (no residual), blocks follow
+	void *out;                // tower-layout tensor, allocation start (last layer's output)
 	const void *weights;      // nLayers x 73728 B, kernel-ready (packConvWeights)
 	const float *bias;        // nLayers x 64
 	uint4 *mail;              // [regions][2][kResMailSlots] 16-byte slots
@@ -675,7 +677,8 @@ __global__ void bump_generation_kernel(unsigned *gen) {
 }
 
 // VARIANT: timing ablation only (0 = product; bit 0 = no halo exchange, bit 1 = no MFMA loop)
-template <typename T, int VARIANT>
+// HEAD: layer 0 is the generator's conv_1 (plain conv + ReLU), residual blocks follow
+template <typename T, int VARIANT, bool HEAD>
 __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr bool xchg = !(VARIANT & 1);
@@ -707,7 +710,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	if (tid == 0) *failFlag = 0;
 	__syncthreads();
 
-	// ---- block 0 input: region + halo straight from the complete global tensor ----
+	// ---- first layer's input: region + halo straight from the complete global tensor;
+	//      pixels outside the image stay zero (the buffers were just cleared) ----
 	{
 		const T *in = static_cast<const T *>(p.in);
 		const int nInstr = (rhv + 2) * 4;  // 8 pixels per wave-instruction, 32 px per row
@@ -715,8 +719,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			const int q = i * 8 + (lane >> 3);
 			const int rr = q >> 5, cc = q & 31;
 			const int c = (lane & 7) ^ ((q >> 1) & 7);
-			glds16(in + ((size_t)(y0 + rr) * p.pitch + x0 + cc) * 64 + c * 8,
-			    smem + kResOffA + i * 1024);
+			const int gy = y0 - 1 + rr, gx = x0 - 1 + cc;
+			if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+				glds16(in + ((size_t)gy * p.inPitch + gx) * 64 + c * 8, smem + kResOffA + i * 1024);
+			}
 		}
 	}
 
@@ -755,8 +761,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// ------------------------------------------------------------------------
 	// one convolution layer over the region: in/out are LDS buffer offsets
 	// ------------------------------------------------------------------------
-	auto computeLayer = [&](const int layer, const int inOff, const int outOff,
-	                        const bool residual, const Vec8<T>(&w)[36]) {
+	auto computeLayer = [&](auto residualTag, const int layer, const int inOff, const int outOff,
+	                        const Vec8<T>(&w)[36]) {
+		constexpr bool residual = decltype(residualTag)::value;
 		const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
 
 		// rows of this wave: full pairs j = rp, rp+2, ... and, for an odd region
@@ -1031,34 +1038,50 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// ------------------------------------------------------------------------
 	// the tower: conv1 X->T (weights w0), conv2 T->X (+X) (weights w1)
 	// ------------------------------------------------------------------------
-	const int nBlocks = p.nLayers >> 1;
-	for (int blk = 0; blk < nBlocks; ++blk) {
-		const int l0 = 2 * blk;
-		const bool last = l0 + 2 >= p.nLayers;
+	// Layer i reads buffer (i even ? A : B) and writes the other one: conv1 X->T, and
+	// conv2 T->X adds the residual already sitting in its output buffer.  With a head
+	// layer (generator conv_1) everything shifts by one.  Layer i uses weight set i&1.
+	const int L = p.nLayers;
+	// RES / PAR are compile-time: a runtime `if (residual)` around the epilogue's LDS
+	// read makes hipcc branch and wait per element (+1 us per layer, measured).
+	auto layerStep = [&](auto resTag, auto parTag, const int i, const Vec8<T>(&wc)[36],
+	                     Vec8<T>(&wn)[36]) -> bool {
+		constexpr int PAR = decltype(parTag)::value;
+		constexpr int inOff = PAR ? kResOffB : kResOffA;
+		constexpr int outOff = PAR ? kResOffA : kResOffB;
+		const bool more = i + 1 < L;
 		// vmcnt is in-order: the next layer's weight stream (36 loads per lane) is issued
 		// AFTER the halo loads so they never queue behind it, and lands behind the MFMAs.
-		if (blk > 0 && xchg) {
-			if (!fillHalo(kResOffA, l0 - 1)) return;
+		if (i > 0 && xchg) {
+			if (!fillHalo(inOff, i - 1)) return false;
 		}
-		loadWeights(l0 + 1, w1);
-		if (wave == 0) biasNext = p.bias[(l0 + 1) * 64 + lane];
-		computeLayer(l0, kResOffA, kResOffB, false, w0);
-		if (wave == 0) ldsBias[((l0 + 1) & 1) * 64 + lane] = biasNext;
-		if (xchg) {
-			publish(kResOffB, l0);
-			if (!fillHalo(kResOffB, l0)) return;
-		} else {
-			__syncthreads();
+		if (more) {
+			loadWeights(i + 1, wn);
+			if (wave == 0) biasNext = p.bias[(i + 1) * 64 + lane];
 		}
-		if (!last) {
-			loadWeights(l0 + 2, w0);
-			if (wave == 0) biasNext = p.bias[(l0 + 2) * 64 + lane];
-		}
-		computeLayer(l0 + 1, kResOffB, kResOffA, true, w1);
-		if (!last && wave == 0) ldsBias[((l0 + 2) & 1) * 64 + lane] = biasNext;
-		if (!last && xchg) publish(kResOffA, l0 + 1);
+		computeLayer(resTag, i, inOff, outOff, wc);
+		if (more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
+		if (more && xchg) publish(outOff, i);
 		else __syncthreads();
+		return true;
+	};
+	using No = std::false_type;
+	using Yes = std::true_type;
+	using P0 = std::integral_constant<int, 0>;
+	using P1 = std::integral_constant<int, 1>;
+	if (HEAD) {  // conv_1, then (conv1, conv2+skip) pairs: L is odd
+		if (!layerStep(No{}, P0{}, 0, w0, w1)) return;
+		for (int i = 1; i + 1 < L; i += 2) {
+			if (!layerStep(No{}, P1{}, i, w1, w0)) return;
+			if (!layerStep(Yes{}, P0{}, i + 1, w0, w1)) return;
+		}
+	} else {  // (conv1, conv2+skip) pairs: L is even
+		for (int i = 0; i + 1 < L; i += 2) {
+			if (!layerStep(No{}, P0{}, i, w0, w1)) return;
+			if (!layerStep(Yes{}, P1{}, i + 1, w1, w0)) return;
+		}
 	}
+	const int finalOff = (L & 1) ? kResOffB : kResOffA;
 
 	// ---- last block output: region interior -> global tower-layout tensor ----
 	{
@@ -1070,7 +1093,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			if (pxl < rwv) {
 				const int rr = row + 1, cc = pxl + 1;
 				const uint4 v = *reinterpret_cast<const uint4 *>(
-				    smem + kResOffA + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
+				    smem + finalOff + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
 				*reinterpret_cast<uint4 *>(
 				    out + ((size_t)(y0 + rr) * p.pitch + x0 + cc) * 64 + c * 8) = v;
 			}
@@ -1078,9 +1101,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	}
 }
 
-template <typename T, int VARIANT>
+template <typename T, int VARIANT, bool HEAD>
 void launchResidentT(const ResidentParams &p, hipStream_t stream) {
-	auto kern = tower_resident_kernel<T, VARIANT>;
+	auto kern = tower_resident_kernel<T, VARIANT, HEAD>;
 	static bool attrSet = false;
 	if (!attrSet) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1434,7 +1457,9 @@ std::size_t residentMailboxBytes(int GX, int GY) {
 void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t stream) {
 	ResidentParams p{};
 	const std::size_t origin = towerOrigin(q.W) * 64 * 2;
-	p.in = static_cast<const unsigned char *>(q.in) - origin;
+	p.in = q.in;
+	p.inPitch = q.inPitch ? q.inPitch : q.W;
+	p.hasHead = q.hasHead;
 	p.out = static_cast<unsigned char *>(q.out) - origin;
 	p.weights = q.weights;
 	p.bias = q.bias;
@@ -1449,15 +1474,23 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.GY = q.GY;
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
+	if ((p.nLayers & 1) != (p.hasHead ? 1 : 0)) {
+		throw std::invalid_argument("resident tower: layer count must be 2*blocks (+1 with a head)");
+	}
+	if (!p.hasHead) {
+		if (dt == kF16) launchResidentT<f16, 0, false>(p, stream);
+		else launchResidentT<bf16, 0, false>(p, stream);
+		return;
+	}
 	if (dt == kF16) {
-		launchResidentT<f16, 0>(p, stream);
+		launchResidentT<f16, 0, true>(p, stream);
 		return;
 	}
 	switch (g_TowerVariant) {
-	case 1: launchResidentT<bf16, 1>(p, stream); break;
-	case 2: launchResidentT<bf16, 2>(p, stream); break;
-	case 3: launchResidentT<bf16, 3>(p, stream); break;
-	default: launchResidentT<bf16, 0>(p, stream); break;
+	case 1: launchResidentT<bf16, 1, true>(p, stream); break;
+	case 2: launchResidentT<bf16, 2, true>(p, stream); break;
+	case 3: launchResidentT<bf16, 3, true>(p, stream); break;
+	default: launchResidentT<bf16, 0, true>(p, stream); break;
 	}
 }
 
