@@ -303,6 +303,7 @@ void Engine::buildProgram(int set) {
 		rp.mailbox = m_ResMail.get();
 		rp.generation = m_ResFlags.as<unsigned>();
 		rp.error = m_ResErrorDev;
+		rp.debug = m_Tensors.at("tower_profile").buf.get();
 		rp.H = H;
 		rp.W = W;
 		rp.GX = m_ResGX;
@@ -432,6 +433,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	addTowerTensor("trunk_b", H, W, c.genFilters);
 	addTowerTensor("trunk_t", H, W, c.genFilters);
 	addTensor("tail_y", lr * 128);
+	addTensor("tower_profile", 256 * 4 * 8 * 2, true);  // u64 cycle sums of the diagnostic tower variant
 
 	buildProgram(0);
 	buildProgram(1);

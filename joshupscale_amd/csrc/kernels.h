@@ -121,6 +121,7 @@ struct ResidentTowerParams {
 	void *mailbox;
 	unsigned *generation;
 	unsigned *error;
+	void *debug;  // optional: GX*GY*4*8 u64 cycle sums (diagnostic variant 4 only)
 	int H, W;
 	int GX, GY, RH;
 	int nLayers;

@@ -54,6 +54,20 @@ __device__ __forceinline__ f32x16 mfma32(Vec8<bf16> a, Vec8<bf16> b, f32x16 c) {
 	return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// ReLU on values already rounded to the 16-bit type, as a packed signed-int16 max
+// with 0: a negative bf16/f16 (sign bit set, -0.0 included) is a negative int16.
+// Rounding keeps the sign, so this equals relu-then-round bit for bit, and it is 2
+// v_pk_max_i16 per 4 values instead of 8 v_max_f32 (hipcc puts a canonicalising
+// max in front of every fmaxf on an MFMA result).
+template <typename T>
+__device__ __forceinline__ Vec4<T> reluPacked(Vec4<T> v) {
+	typedef short s16x4 __attribute__((ext_vector_type(4)));
+	s16x4 b = __builtin_bit_cast(s16x4, v);
+	const s16x4 z = {0, 0, 0, 0};
+	b = __builtin_elementwise_max(b, z);
+	return __builtin_bit_cast(Vec4<T>, b);
+}
+
 inline void hipCheckLaunch(const char *what) {
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) {
@@ -663,6 +677,7 @@ struct ResidentParams {
 	unsigned *flag;           // [regions] {generation<<8 | layers published}
 	const unsigned *gen;      // launch generation (bumped by bump_generation_kernel)
 	unsigned *error;          // host-visible word, 0 = ok
+	unsigned long long *debug;  // VARIANT 4 only: [regions][4 waves][8] cycle sums
 	int H, W, pitch;
 	int GX, GY, RH;
 	int nLayers;
@@ -727,12 +742,21 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	}
 
 	// ---- register-resident weights: A fragment f = (dy*3+dx)*4+ks of this wave's cout half ----
+	// Buffer loads: per-lane byte offset in ONE VGPR, fragment/layer offset scalar, so
+	// a load costs no address VALU and no temporaries (a flat load 2048*f bytes away is
+	// out of immediate range and needs a 64-bit add per load).
+	typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+	const __amdgpu_buffer_rsrc_t wRsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    const_cast<void *>(p.weights), 0, p.nLayers * 73728, 0x00020000);
+	const unsigned wLaneOff = (unsigned)((hh * 64 + ch * 32 + px) * 16);
+	auto loadWeightFrag = [&](int layer, int f) -> Vec8<T> {
+		const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(wRsrc, wLaneOff, layer * 73728 + f * 2048, 0);
+		return __builtin_bit_cast(Vec8<T>, v);
+	};
 	Vec8<T> w0[36], w1[36];
 	auto loadWeights = [&](int layer, Vec8<T>(&w)[36]) {
-		const T *wl = static_cast<const T *>(p.weights) + (size_t)layer * (9 * 64 * 64) +
-		              (hh * 64 + ch * 32 + px) * 8;
 #pragma unroll
-		for (int f = 0; f < 36; ++f) w[f] = *reinterpret_cast<const Vec8<T> *>(wl + f * 1024);
+		for (int f = 0; f < 36; ++f) w[f] = loadWeightFrag(layer, f);
 	};
 	loadWeights(0, w0);
 	float biasNext = 0.f;  // wave 0: next layer's bias in flight (one value per lane)
@@ -758,12 +782,26 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
 
+	// VARIANT 4 (diagnostic build only): per-wave cycle sums of the phases below
+	u64 prof[7] = {0, 0, 0, 0, 0, 0, 0};
+	auto stamp = [&]() -> u64 {
+		if constexpr (VARIANT == 4) {
+			__builtin_amdgcn_sched_barrier(0);
+			u64 t;
+			asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+			__builtin_amdgcn_sched_barrier(0);
+			return t;
+		} else {
+			return 0;
+		}
+	};
 	// ------------------------------------------------------------------------
 	// one convolution layer over the region: in/out are LDS buffer offsets
 	// ------------------------------------------------------------------------
 	auto computeLayer = [&](auto residualTag, const int layer, const int inOff, const int outOff,
 	                        const Vec8<T>(&w)[36]) {
 		constexpr bool residual = decltype(residualTag)::value;
+
 		const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
 
 		// rows of this wave: full pairs j = rp, rp+2, ... and, for an odd region
@@ -785,6 +823,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		// first 4 fragments were already issued by the previous unit's last step.
 		auto unitBody = [&](auto rowsTag, const int unit, const bool primed, const int nextUnit) {
 			constexpr int ROWS = decltype(rowsTag)::value;
+			const u64 tu0 = stamp();
 			constexpr int NR = ROWS + 2;      // input rows / fragment reads per macro-step
 			constexpr int NM = 3 * ROWS;      // MFMAs per macro-step
 			const int ra = 1 + 2 * unit;      // first output row (buffer row index)
@@ -846,8 +885,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
-			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior;
-			//      edge pixels also go to the mailbox as tagged granules ----
+			const u64 tu1 = stamp();
+			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
 #pragma unroll
 			for (int r = 0; r < ROWS; ++r) {
 				const int rr = ra + r;
@@ -863,26 +902,29 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #pragma unroll
 							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[i]);
 						}
-#pragma unroll
-						for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
 						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
 						    static_cast<T>(v[3])};
-						*reinterpret_cast<Vec4<T> *>(dst) = o;
+						*reinterpret_cast<Vec4<T> *>(dst) = reluPacked<T>(o);
 					}
 				}
 			}
+			const u64 tu2 = stamp();
+			prof[5] += tu1 - tu0;
+			prof[6] += tu2 - tu1;
 		};
 
 		// pairs u = rp, rp+2, ... ; the odd last row goes to the wave group with fewer
 		// pairs (group 0 when both have the same number)
+		using R2 = std::integral_constant<int, 2>;
+		using R1 = std::integral_constant<int, 1>;
 		const bool mySingle = (rhv & 1) && rp == (np2 & 1);
 		bool primed = false;
 		for (int u = rp; u < np2; u += 2) {
 			const int nu = (u + 2 < np2) ? u + 2 : (mySingle ? np2 : -1);
-			unitBody(std::integral_constant<int, 2>{}, u, primed, nu);
+			unitBody(R2{}, u, primed, nu);
 			primed = nu >= 0 && !(VARIANT & 2);
 		}
-		if (mySingle) unitBody(std::integral_constant<int, 1>{}, np2, primed, -1);
+		if (mySingle) unitBody(R1{}, np2, primed, -1);
 		(void)nUnits;
 	};
 
@@ -914,7 +956,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	};
 	// `layer`: the layer whose output (in buffer `off`) is published
 	auto publish = [&](int off, int layer) {
-		__syncthreads();  // the whole region's output is in LDS
+		// (the caller has just passed the workgroup barrier: the region's output is in LDS)
 		u32x4 tm;
 		tagMasks(layer, &tm);
 		const unsigned base = (unsigned)((region * 2 + ((layer + 1) & 1)) * kResMailSlots) * 16u;
@@ -1050,19 +1092,38 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		constexpr int inOff = PAR ? kResOffB : kResOffA;
 		constexpr int outOff = PAR ? kResOffA : kResOffB;
 		const bool more = i + 1 < L;
+		const u64 t0 = stamp();
 		// vmcnt is in-order: the next layer's weight stream (36 loads per lane) is issued
 		// AFTER the halo loads so they never queue behind it, and lands behind the MFMAs.
 		if (i > 0 && xchg) {
 			if (!fillHalo(inOff, i - 1)) return false;
 		}
+		const u64 t1 = stamp();
+		// (Interleaving these 36 loads into the first unit's MFMA loop was tried: the
+		// burst costs ~2.2k cycles of issue stall per layer -- four waves push 144 KB
+		// through the CU's 64 B/clk address path -- but the interleaved form was no
+		// faster end to end and doubled the code.)
 		if (more) {
 			loadWeights(i + 1, wn);
 			if (wave == 0) biasNext = p.bias[(i + 1) * 64 + lane];
 		}
+		const u64 t2 = stamp();
 		computeLayer(resTag, i, inOff, outOff, wc);
+		const u64 t3 = stamp();
 		if (more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
-		if (more && xchg) publish(outOff, i);
-		else __syncthreads();
+		if (more && xchg) {
+			__syncthreads();  // (publish starts with this barrier; split out for the profile)
+			const u64 t4 = stamp();
+			publish(outOff, i);
+			const u64 t5 = stamp();
+			prof[3] += t4 - t3;
+			prof[4] += t5 - t4;
+		} else {
+			__syncthreads();
+		}
+		prof[0] += t1 - t0;
+		prof[1] += t2 - t1;
+		prof[2] += t3 - t2;
 		return true;
 	};
 	using No = std::false_type;
@@ -1082,6 +1143,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 	}
 	const int finalOff = (L & 1) ? kResOffB : kResOffA;
+	if constexpr (VARIANT == 4) {
+		if (lane == 0 && p.debug != nullptr) {
+			for (int k = 0; k < 7; ++k) p.debug[(region * 4 + wave) * 8 + k] = prof[k];
+		}
+	}
 
 	// ---- last block output: region interior -> global tower-layout tensor ----
 	{
@@ -1466,6 +1532,7 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.mail = static_cast<uint4 *>(q.mailbox);
 	p.gen = q.generation;
 	p.flag = q.generation + 16;  // same small buffer: word 0 = generation, flags from byte 64
+	p.debug = static_cast<unsigned long long *>(q.debug);
 	p.error = q.error;
 	p.H = q.H;
 	p.W = q.W;
@@ -1490,6 +1557,7 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	case 1: launchResidentT<bf16, 1, true>(p, stream); break;
 	case 2: launchResidentT<bf16, 2, true>(p, stream); break;
 	case 3: launchResidentT<bf16, 3, true>(p, stream); break;
+	case 4: launchResidentT<bf16, 4, true>(p, stream); break;
 	default: launchResidentT<bf16, 0, true>(p, stream); break;
 	}
 }
