@@ -167,7 +167,7 @@ void Engine::buildWeights(const ModelFile &model) {
 		const TensorView &b2 = model.tensor("generator/conv_trans_2/bias", {3});
 		m_TailW2 = DeviceBuffer(k2.count * 4);
 		m_TailW2.upload(k2.data, k2.count * 4);
-		m_TailB2 = DeviceBuffer(16);
+		m_TailB2 = DeviceBuffer(32);  // convT2 bias (3 f32) + from byte 16: the frame's channel sums
 		m_TailB2.upload(b2.data, 12);
 	}
 }
@@ -227,9 +227,17 @@ void Engine::buildProgram(int set) {
 	auto Op = [&](const std::string &n) { return operand(n); };
 	const Operand none{};
 
+	// normalize_brightness: three integer channel sums per frame, consumed by the pack,
+	// warp and tail kernels (models.py:772-779, 802-803, 809-810)
+	const unsigned *sums = c.normalizeBrightness ? m_TailB2.as<unsigned>() + 4 : nullptr;
+	if (sums) {
+		unsigned *sumsOut = m_TailB2.as<unsigned>() + 4;
+		prog.push_back({"pack", 0.0,
+		    [=](hipStream_t s) { launchFrameSums(frame, fstride, H, W, sumsOut, s); }});
+	}
 	prog.push_back({"pack", 0.0, [=](hipStream_t s) {
 		                launchPackFrames(dt, frame, fstride, packedIn, packedOut, H, W, PH, PW,
-		                    padTop, padLeft, nIn, s);
+		                    padTop, padLeft, nIn, sums, s);
 	                }});
 	// ---- flow net ----
 	Operand cur{packedOut, 0};
@@ -281,7 +289,7 @@ void Engine::buildProgram(int set) {
 		void *genIn = T("gen_in");
 		prog.push_back({"warp", 0.0, [=](hipStream_t s) {
 			                launchWarpPack(dt, stateIn, flow, frame, fstride, genIn, H, W, PW, padTop,
-			                    padLeft, s);
+			                    padLeft, sums, s);
 		                }});
 	}
 	// ---- generator ----
@@ -332,7 +340,7 @@ void Engine::buildProgram(int set) {
 		const float *b2 = m_TailB2.as<float>();
 		auto *outU8 = m_OutStage.as<std::uint8_t>();
 		prog.push_back({"tail", 2.0 * (2 * H) * (2 * W) * 4 * 32 * 3, [=](hipStream_t s) {
-			                launchTail(dt, y, w2, b2, frame, fstride, stateOut, outU8, H, W, s);
+			                launchTail(dt, y, w2, b2, frame, fstride, stateOut, outU8, H, W, sums, s);
 		                }});
 	}
 }
@@ -350,10 +358,6 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	int dt = dtypeOverride >= 0 ? dtypeOverride : c.computeDtype;
 	if (dt != kF16 && dt != kBF16) throw std::invalid_argument("Unsupported compute dtype");
 	m_DType = static_cast<DType>(dt);
-	if (c.normalizeBrightness) {
-		throw std::invalid_argument(
-		    "Unsupported model: normalize_brightness is not implemented by this runtime yet");
-	}
 	if (c.genFilters % 32 != 0 || c.genFilters <= 0 || c.genBlocks < 0) {
 		throw std::invalid_argument("Unsupported model: gen_filters must be a multiple of 32");
 	}

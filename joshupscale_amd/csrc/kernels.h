@@ -139,7 +139,13 @@ void setTowerVariant(int variant);
 // ch 3-11 = previous ch 0-8, ch 12-15 zero.
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
-    int padLeft, int numInputs, hipStream_t stream);
+    int padLeft, int numInputs, const unsigned *sums, hipStream_t stream);
+
+// normalize_brightness (reference models.py:772-779): exact integer sums of the B, G, R
+// bytes of the frame -> sums[0..2]; the kernels taking `sums` derive the scalar
+// brightness from them (nullptr = feature off).
+void launchFrameSums(const std::uint8_t *frame, std::ptrdiff_t frameStride, int H, int W,
+    unsigned *sums, hipStream_t stream);
 
 void launchMaxPool2(DType dt, const void *in, void *out, int H, int W, int C,
     hipStream_t stream);  // in [H][W][C] -> out [H/2][W/2][C]
@@ -156,7 +162,7 @@ void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C,
 //         ch 12,13,14 = current LR frame B,G,R, other spare slots zero.
 void launchWarpPack(DType dt, const void *state, const float *flow,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *out, int H, int W, int PW,
-    int padTop, int padLeft, hipStream_t stream);
+    int padTop, int padLeft, const unsigned *sums, hipStream_t stream);
 
 // ---- generator tail ---------------------------------------------------------
 // y     : [H][W][128] 16-bit = relu(BN(convT1)) with channel (a*2+b)*32 + o
@@ -165,7 +171,7 @@ void launchWarpPack(DType dt, const void *state, const float *flow,
 // stateOut : f16 [4H][4W][4]; outU8 : BGRX [4H][4W][4], X = 0
 void launchTail(DType dt, const void *y, const float *w2, const float *b2,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *stateOut,
-    std::uint8_t *outU8, int H, int W, hipStream_t stream);
+    std::uint8_t *outU8, int H, int W, const unsigned *sums, hipStream_t stream);
 
 // ---- staging ----------------------------------------------------------------
 // Row-wise device copy with signed strides (bottom-up frames).

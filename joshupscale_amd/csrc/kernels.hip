@@ -1194,12 +1194,57 @@ __device__ __forceinline__ float preprocessU8(unsigned v) {
 	return static_cast<float>(v) / 255.0f - 0.5f;
 }
 
+// normalize_brightness (reference models.py:772-779, utils.py:151): the scalar
+// b = mean(x * BGR_LUMA * 3) over H, W, C of the preprocessed frame
+//   = sum_c luma_c * (S_c / (255 N) - 0.5)
+// from the three exact integer channel sums S_c (order-independent, so the
+// reduction is deterministic).  sums == nullptr: feature off, b = 0.
+__device__ __forceinline__ float brightnessOf(const unsigned *__restrict__ sums, float invN) {
+	if (sums == nullptr) return 0.0f;
+	const float mb = static_cast<float>(sums[0]) * invN / 255.0f - 0.5f;
+	const float mg = static_cast<float>(sums[1]) * invN / 255.0f - 0.5f;
+	const float mr = static_cast<float>(sums[2]) * invN / 255.0f - 0.5f;
+	return 0.114f * mb + 0.587f * mg + 0.2989f * mr;
+}
+
+__global__ __launch_bounds__(1024) void frame_sums_kernel(const std::uint8_t *__restrict__ frame,
+    std::ptrdiff_t frameStride, int H, int W, unsigned *__restrict__ sums) {
+	__shared__ unsigned part[3][16];
+	unsigned s0 = 0, s1 = 0, s2 = 0;
+	for (int i = threadIdx.x; i < H * W; i += 1024) {
+		const int y = i / W, x = i - y * W;
+		const unsigned v = *reinterpret_cast<const unsigned *>(frame + y * frameStride + x * 4);
+		s0 += v & 0xff;
+		s1 += (v >> 8) & 0xff;
+		s2 += (v >> 16) & 0xff;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		s0 += __shfl_down(s0, o);
+		s1 += __shfl_down(s1, o);
+		s2 += __shfl_down(s2, o);
+	}
+	const int wv = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0) {
+		part[0][wv] = s0;
+		part[1][wv] = s1;
+		part[2][wv] = s2;
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		unsigned t = 0;
+		for (int k = 0; k < 16; ++k) t += part[threadIdx.x][k];
+		sums[threadIdx.x] = t;
+	}
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_frames_kernel(const std::uint8_t *__restrict__ frame,
     std::ptrdiff_t frameStride, const T *__restrict__ prev, T *__restrict__ cur, int H, int W,
-    int PH, int PW, int padTop, int padLeft, int numInputs) {
+    int PH, int PW, int padTop, int padLeft, int numInputs, const unsigned *__restrict__ sums) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= PH * PW) return;
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));
 	const int py = idx / PW;
 	const int pxx = idx - py * PW;
 	const int y = py - padTop;
@@ -1207,9 +1252,11 @@ __global__ __launch_bounds__(256) void pack_frames_kernel(const std::uint8_t *__
 	float c0 = 0.f, c1 = 0.f, c2 = 0.f;  // ZeroPadding2D after preprocess: 0.0 in the border
 	if (y >= 0 && y < H && x >= 0 && x < W) {
 		const unsigned v = *reinterpret_cast<const unsigned *>(frame + y * frameStride + x * 4);
-		c0 = preprocessU8(v & 0xff);
-		c1 = preprocessU8((v >> 8) & 0xff);
-		c2 = preprocessU8((v >> 16) & 0xff);
+		// the flow net sees the brightness-normalised frame (models.py:779); the pad
+		// border stays exactly zero (ZeroPadding2D comes after the subtraction)
+		c0 = preprocessU8(v & 0xff) - bright;
+		c1 = preprocessU8((v >> 8) & 0xff) - bright;
+		c2 = preprocessU8((v >> 16) & 0xff) - bright;
 	}
 	const Vec8<T> p0 = *reinterpret_cast<const Vec8<T> *>(prev + (size_t)idx * 16);
 	const Vec8<T> p1 = *reinterpret_cast<const Vec8<T> *>(prev + (size_t)idx * 16 + 8);
@@ -1306,9 +1353,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ state,
     const float *__restrict__ flow, const std::uint8_t *__restrict__ frame,
     std::ptrdiff_t frameStride, T *__restrict__ out, int H, int W, int PW, int padTop,
-    int padLeft) {
+    int padLeft, const unsigned *__restrict__ sums) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= H * W * 4) return;
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));  // pre_warp += b (models.py:803)
 	const int i = idx & 3;
 	const int pix = idx >> 2;
 	const int w = pix % W;
@@ -1345,7 +1393,7 @@ __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ 
 			const float d = static_cast<float>(bl[c]), e = static_cast<float>(br[c]);
 			const float top = ax * (b - a) + a;
 			const float bot = ax * (e - d) + d;
-			o[j * 3 + c] = static_cast<T>(ay * (bot - top) + top);
+			o[j * 3 + c] = static_cast<T>(ay * (bot - top) + top + bright);
 		}
 	}
 	float l0 = 0.f, l1 = 0.f, l2 = 0.f;
@@ -1381,7 +1429,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
     const float *__restrict__ w2, const float *__restrict__ b2,
     const std::uint8_t *__restrict__ frame, std::ptrdiff_t frameStride,
-    f16 *__restrict__ stateOut, std::uint8_t *__restrict__ outU8, int H, int W) {
+    f16 *__restrict__ stateOut, std::uint8_t *__restrict__ outU8, int H, int W,
+    const unsigned *__restrict__ sums) {
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));
 	const int MW = 2 * W, MH = 2 * H;
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= MW * MH) return;
@@ -1435,7 +1485,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
 				const float skip = top + (bot - top) * fy;
 				float r = tanhf(acc) + skip;
 				r = fminf(fmaxf(r, -0.5f), 0.5f);  // ClipLayer
-				st[b2i * 4 + c] = static_cast<f16>(r);
+				st[b2i * 4 + c] = static_cast<f16>(r - bright);  // fed-back state: output_raw - b (models.py:810)
 				// PostprocessLayer + truncating cast (cuda_convert.cc.cu:76-81)
 				const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);
 				packed |= (u & 0xff) << (8 * c);
@@ -1564,16 +1614,16 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
-    int padLeft, int numInputs, hipStream_t stream) {
+    int padLeft, int numInputs, const unsigned *sums, hipStream_t stream) {
 	const unsigned nb = blocksFor((size_t)PH * PW);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(pack_frames_kernel<f16>, dim3(nb), dim3(256), 0, stream, frame,
 		    frameStride, static_cast<const f16 *>(prevPacked), static_cast<f16 *>(curPacked), H, W,
-		    PH, PW, padTop, padLeft, numInputs);
+		    PH, PW, padTop, padLeft, numInputs, sums);
 	} else {
 		hipLaunchKernelGGL(pack_frames_kernel<bf16>, dim3(nb), dim3(256), 0, stream, frame,
 		    frameStride, static_cast<const bf16 *>(prevPacked), static_cast<bf16 *>(curPacked), H,
-		    W, PH, PW, padTop, padLeft, numInputs);
+		    W, PH, PW, padTop, padLeft, numInputs, sums);
 	}
 	hipCheckLaunch("pack_frames");
 }
@@ -1604,34 +1654,41 @@ void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, h
 
 void launchWarpPack(DType dt, const void *state, const float *flow, const std::uint8_t *frame,
     std::ptrdiff_t frameStride, void *out, int H, int W, int PW, int padTop, int padLeft,
-    hipStream_t stream) {
+    const unsigned *sums, hipStream_t stream) {
 	const unsigned nb = blocksFor((size_t)H * W * 4);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(warp_pack_kernel<f16>, dim3(nb), dim3(256), 0, stream,
 		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<f16 *>(out), H,
-		    W, PW, padTop, padLeft);
+		    W, PW, padTop, padLeft, sums);
 	} else {
 		hipLaunchKernelGGL(warp_pack_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
 		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<bf16 *>(out), H,
-		    W, PW, padTop, padLeft);
+		    W, PW, padTop, padLeft, sums);
 	}
 	hipCheckLaunch("warp_pack");
 }
 
 void launchTail(DType dt, const void *y, const float *w2, const float *b2,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *stateOut, std::uint8_t *outU8,
-    int H, int W, hipStream_t stream) {
+    int H, int W, const unsigned *sums, hipStream_t stream) {
 	const unsigned nb = blocksFor((size_t)4 * H * W);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(tail_kernel<f16>, dim3(nb), dim3(256), 0, stream,
 		    static_cast<const f16 *>(y), w2, b2, frame, frameStride, static_cast<f16 *>(stateOut),
-		    outU8, H, W);
+		    outU8, H, W, sums);
 	} else {
 		hipLaunchKernelGGL(tail_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
 		    static_cast<const bf16 *>(y), w2, b2, frame, frameStride, static_cast<f16 *>(stateOut),
-		    outU8, H, W);
+		    outU8, H, W, sums);
 	}
 	hipCheckLaunch("tail");
+}
+
+void launchFrameSums(const std::uint8_t *frame, std::ptrdiff_t frameStride, int H, int W,
+    unsigned *sums, hipStream_t stream) {
+	hipLaunchKernelGGL(frame_sums_kernel, dim3(1), dim3(1024), 0, stream, frame, frameStride, H, W,
+	    sums);
+	hipCheckLaunch("frame_sums");
 }
 
 void launchCopyRows(const std::uint8_t *src, std::ptrdiff_t srcStride, std::uint8_t *dst,

@@ -283,3 +283,61 @@ def test_avisynth_style_warmup_sequence():
         ref = sess.run(clip[n])
     check_u8(out, ref, R.DTYPE_F16, "after warm-up")
     rt.close()
+
+
+def test_cpp_plugin_surface_harness(tmp_path):
+    """tools/plugin_harness.cpp is compiled against include/JoshUpscale/core.h only and
+    reproduces the AviSynth (16 mirrored warm-up frames, bottom-up RGB32 / negative
+    stride) and OBS (steady loop, destroy + recreate) call patterns of the reference's
+    plugins; its outputs must equal the C-ABI path byte for byte."""
+    import subprocess
+    exe = os.path.join(ROOT, "build", "plugin_harness")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", ROOT, "harness"])
+    cfg = small_config()
+    wts = M.make_seeded_weights(cfg)
+    model = str(tmp_path / "m.jupw")
+    M.save(model, cfg, wts)
+    n = 5
+    frames = M.synthetic_frames(n, 30, 48, seed=4, kind="smooth")
+    frames.tofile(str(tmp_path / "frames.raw"))
+    out_path = str(tmp_path / "out.raw")
+    r = subprocess.run([exe, model, str(tmp_path / "frames.raw"), str(n), out_path],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "3 errors caught as exceptions" in r.stdout
+    got = np.fromfile(out_path, np.uint8).reshape(2, 120, 192, 4)
+    rt = R.Runtime(model, 0)                     # container's dtype hint, like the harness
+    order = [min(abs(k), n - 1) for k in range(-16, 0)] + list(range(n))
+    for k in order:
+        a = rt.process_image(frames[k])
+    assert np.array_equal(got[0], a)             # AviSynth pattern
+    rt.reset()
+    for k in range(n):
+        b = rt.process_image(frames[k])
+    assert np.array_equal(got[1], b)             # OBS pattern after destroy/recreate
+    rt.close()
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
+def test_normalize_brightness_branch(dtype):
+    """Optional branch of get_inference_model (reference models.py:772-779, 802-803,
+    809-810): flow on x - b, pre_warp + b, fed-back state output_raw - b."""
+    cfg = small_config(normalize_brightness=True)
+    wts, blob, rt = make(cfg, dtype)
+    oc = oracle_config(cfg)
+    assert oc.normalize_brightness
+    sess = O.Session(wts, oc)
+    plain = O.Session(wts, oracle_config(small_config()))
+    frames = M.synthetic_frames(4, 30, 48, seed=17, kind="smooth")
+    frames[..., :3] = (frames[..., :3].astype(np.int32) * 3 // 4 + 60).astype(np.uint8)  # bright clip: b != 0
+    differs = False
+    for t in range(4):
+        ref = sess.run(frames[t])
+        out = rt.process_image(frames[t])
+        check_u8(out, ref, dtype, ("brightness", t))
+        state = rt.read_tensor("state").reshape(120, 192, 4)[..., :3]
+        assert err(state, sess.state.pre_gen)["max_abs"] <= TOL[dtype]["raw"]
+        differs |= not np.array_equal(ref, plain.run(frames[t]))
+    assert differs, "the brightness branch must change the result on this clip"
+    rt.close()
