@@ -216,8 +216,7 @@ void Engine::buildProgram(int set) {
 	const int H = c.frameHeight, W = c.frameWidth;
 	const int PH = c.paddedHeight(), PW = c.paddedWidth();
 	const int padTop = (PH - H) / 2, padLeft = (PW - W) / 2;  // models.py:783-787
-	const auto *frame = m_InStage.as<std::uint8_t>();
-	const std::ptrdiff_t fstride = static_cast<std::ptrdiff_t>(W) * 4;
+	const FrameIO *io = &m_IO;  // read at launch time: staging buffers or the caller's
 	const void *packedIn = m_Packed[set].get();
 	void *packedOut = m_Packed[set ^ 1].get();
 	const void *stateIn = m_State[set].get();
@@ -233,11 +232,12 @@ void Engine::buildProgram(int set) {
 	if (sums) {
 		unsigned *sumsOut = m_TailB2.as<unsigned>() + 4;
 		prog.push_back({"pack", 0.0,
-		    [=](hipStream_t s) { launchFrameSums(frame, fstride, H, W, sumsOut, s); }});
+		    [=](hipStream_t s) { launchFrameSums(io->in, io->inStride, H, W, sumsOut, s); }});
 	}
+	unsigned *generation = m_Resident ? m_ResFlags.as<unsigned>() : nullptr;
 	prog.push_back({"pack", 0.0, [=](hipStream_t s) {
-		                launchPackFrames(dt, frame, fstride, packedIn, packedOut, H, W, PH, PW,
-		                    padTop, padLeft, nIn, sums, s);
+		                launchPackFrames(dt, io->in, io->inStride, packedIn, packedOut, H, W, PH, PW,
+		                    padTop, padLeft, nIn, sums, generation, s);
 	                }});
 	// ---- flow net ----
 	Operand cur{packedOut, 0};
@@ -288,8 +288,8 @@ void Engine::buildProgram(int set) {
 		const float *flow = static_cast<const float *>(T("flow"));
 		void *genIn = T("gen_in");
 		prog.push_back({"warp", 0.0, [=](hipStream_t s) {
-			                launchWarpPack(dt, stateIn, flow, frame, fstride, genIn, H, W, PW, padTop,
-			                    padLeft, sums, s);
+			                launchWarpPack(dt, stateIn, flow, io->in, io->inStride, genIn, H, W, PW,
+			                    padTop, padLeft, sums, s);
 		                }});
 	}
 	// ---- generator ----
@@ -318,6 +318,7 @@ void Engine::buildProgram(int set) {
 		rp.GY = m_ResGY;
 		rp.RH = m_ResRH;
 		rp.nLayers = 1 + 2 * c.genBlocks;
+		rp.bumpGeneration = 0;  // pack_frames, the first kernel of the frame, bumps it
 		prog.push_back({"tower", 2.0 * H * W * 9.0 * (51.0 * 64 + 64.0 * 64 * 2 * c.genBlocks),
 		    [=](hipStream_t s) { launchResidentTower(dt, rp, s); }});
 		a = 1;
@@ -338,9 +339,9 @@ void Engine::buildProgram(int set) {
 		const void *y = T("tail_y");
 		const float *w2 = m_TailW2.as<float>();
 		const float *b2 = m_TailB2.as<float>();
-		auto *outU8 = m_OutStage.as<std::uint8_t>();
 		prog.push_back({"tail", 2.0 * (2 * H) * (2 * W) * 4 * 32 * 3, [=](hipStream_t s) {
-			                launchTail(dt, y, w2, b2, frame, fstride, stateOut, outU8, H, W, sums, s);
+			                launchTail(dt, y, w2, b2, io->in, io->inStride, stateOut, io->out,
+			                    io->outStride, H, W, sums, s);
 		                }});
 	}
 }
@@ -442,6 +443,10 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	buildProgram(0);
 	buildProgram(1);
 
+	m_IO.in = m_InStage.as<std::uint8_t>();
+	m_IO.inStride = static_cast<std::ptrdiff_t>(W) * 4;
+	m_IO.out = m_OutStage.as<std::uint8_t>();
+	m_IO.outStride = static_cast<std::ptrdiff_t>(W) * 16;
 	// One eager pass per binding set: sets the kernels' dynamic-LDS attributes
 	// and surfaces launch errors before anything is captured.
 	for (int s = 0; s < 2; ++s) {
@@ -451,6 +456,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	checkResidentError();
 	reset();
 
+	const char *direct = std::getenv("JU_DIRECT");
+	m_PreferDirect = !(direct && direct[0] == '0');
 	const char *noGraph = std::getenv("JU_NO_GRAPH");
 	m_UseGraph = !(noGraph && noGraph[0] == '1');
 	if (m_UseGraph) {
@@ -603,28 +610,54 @@ void Engine::stageOut(const Frame &out) {
 }
 
 void Engine::runProgram() {
-	if (m_UseGraph && m_Graph[m_Idx].valid()) {
+	if (m_UseGraph && !m_DirectIO && m_Graph[m_Idx].valid()) {
 		m_Graph[m_Idx].launch(m_Stream);
 	} else {
 		for (const Step &st : m_Program[m_Idx]) st.run(m_Stream);
 	}
 }
 
+void Engine::submit(const Frame &in, const Frame &out) {
+	const FrameSize fs = frameSize();
+	// Device-resident frames + eager launches: the kernels read the caller's input and
+	// write the caller's output directly (any signed stride), no staging copies.
+	m_DirectIO = m_PreferDirect && in.location == Location::Device &&
+	             out.location == Location::Device && in.ptr != nullptr && out.ptr != nullptr &&
+	             in.width == fs.inputWidth && in.height == fs.inputHeight &&
+	             out.width == fs.outputWidth && out.height == fs.outputHeight &&
+	             (in.stride >= static_cast<std::ptrdiff_t>(fs.inputWidth * 4) ||
+	                 -in.stride >= static_cast<std::ptrdiff_t>(fs.inputWidth * 4)) &&
+	             (out.stride >= static_cast<std::ptrdiff_t>(fs.outputWidth * 4) ||
+	                 -out.stride >= static_cast<std::ptrdiff_t>(fs.outputWidth * 4)) &&
+	             (reinterpret_cast<std::uintptr_t>(in.ptr) % 4 == 0) && in.stride % 4 == 0 &&
+	             (reinterpret_cast<std::uintptr_t>(out.ptr) % 8 == 0) && out.stride % 8 == 0;
+	if (m_DirectIO) {
+		m_IO.in = static_cast<const std::uint8_t *>(in.ptr);
+		m_IO.inStride = in.stride;
+		m_IO.out = static_cast<std::uint8_t *>(out.ptr);
+		m_IO.outStride = out.stride;
+		runProgram();
+	} else {
+		m_IO.in = m_InStage.as<std::uint8_t>();
+		m_IO.inStride = static_cast<std::ptrdiff_t>(fs.inputWidth) * 4;
+		m_IO.out = m_OutStage.as<std::uint8_t>();
+		m_IO.outStride = static_cast<std::ptrdiff_t>(fs.outputWidth) * 4;
+		stageIn(in);
+		runProgram();
+		stageOut(out);
+	}
+	m_Idx ^= 1;  // state ping-pong (tensorrt_backend.cc:277)
+}
+
 void Engine::enqueue(const Frame &in, const Frame &out) {
 	DeviceGuard g(m_Device);
-	stageIn(in);
-	runProgram();
-	stageOut(out);
-	m_Idx ^= 1;  // state ping-pong (tensorrt_backend.cc:277)
+	submit(in, out);
 }
 
 void Engine::process(const Frame &in, const Frame &out) {
 	DeviceGuard g(m_Device);
-	stageIn(in);
-	runProgram();
-	stageOut(out);
+	submit(in, out);
 	m_Stream.synchronize();
-	m_Idx ^= 1;
 	checkResidentError();
 }
 
@@ -704,10 +737,19 @@ double Engine::timeSteps(const std::string &tag, int iters, int *launches) {
 	}
 	if (launches) *launches = static_cast<int>(steps.size());
 	if (steps.empty() || iters <= 0) return 0.0;
+	// Run in isolation the tower never sees pack_frames, which bumps the launch
+	// generation of its halo tags: do it here, or stale slots would match at once.
+	const bool bump = m_Resident && tag == "tower";
+	m_IO.in = m_InStage.as<std::uint8_t>();
+	m_IO.inStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 4;
+	m_IO.out = m_OutStage.as<std::uint8_t>();
+	m_IO.outStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 16;
+	if (bump) launchBumpGeneration(m_ResFlags.as<unsigned>(), m_Stream);
 	for (const Step *s : steps) s->run(m_Stream);  // warm
 	Event t0, t1;
 	t0.record(m_Stream);
 	for (int i = 0; i < iters; ++i) {
+		if (bump) launchBumpGeneration(m_ResFlags.as<unsigned>(), m_Stream);
 		for (const Step *s : steps) s->run(m_Stream);
 	}
 	t1.record(m_Stream);

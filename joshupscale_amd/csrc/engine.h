@@ -117,6 +117,19 @@ private:
 	void stageIn(const Frame &in);
 	void stageOut(const Frame &out);
 	void runProgram();
+	// Frame buffers the kernels read / write in THIS call.  Graph replay always uses
+	// the internal staging buffers (static pointers); eager launches of device-resident
+	// frames use the caller's buffers directly (no staging copies).
+	struct FrameIO {
+		const std::uint8_t *in = nullptr;
+		std::ptrdiff_t inStride = 0;
+		std::uint8_t *out = nullptr;
+		std::ptrdiff_t outStride = 0;
+	};
+	FrameIO m_IO;
+	bool m_DirectIO = false;  // decided per call
+	bool m_PreferDirect = true;  // JU_DIRECT=0: always stage (and replay the graph)
+	void submit(const Frame &in, const Frame &out);
 
 	int m_Device;
 	ModelConfig m_Config;

@@ -125,7 +125,9 @@ struct ResidentTowerParams {
 	int H, W;
 	int GX, GY, RH;
 	int nLayers;
+	int bumpGeneration;  // 1: bump *generation in a 1-thread launch first (0: someone else did)
 };
+void launchBumpGeneration(unsigned *generation, hipStream_t stream);
 bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH);
 std::size_t residentMailboxBytes(int GX, int GY);
 void launchResidentTower(DType dt, const ResidentTowerParams &p, hipStream_t stream);
@@ -136,10 +138,11 @@ void setTowerVariant(int variant);
 // ---- flow-net helpers -------------------------------------------------------
 // cur frame (u8 BGRX, signed row stride) + previous packed history ->
 // packed [PH][PW][16]: ch 0-2 current frame (x/255-0.5, zero in the pad border),
-// ch 3-11 = previous ch 0-8, ch 12-15 zero.
+// ch 3-11 = previous ch 0-8, ch 12-15 zero.  generation (optional): device word
+// incremented once per launch (the resident tower's launch generation).
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
-    int padLeft, int numInputs, const unsigned *sums, hipStream_t stream);
+    int padLeft, int numInputs, const unsigned *sums, unsigned *generation, hipStream_t stream);
 
 // normalize_brightness (reference models.py:772-779): exact integer sums of the B, G, R
 // bytes of the frame -> sums[0..2]; the kernels taking `sums` derive the scalar
@@ -171,7 +174,8 @@ void launchWarpPack(DType dt, const void *state, const float *flow,
 // stateOut : f16 [4H][4W][4]; outU8 : BGRX [4H][4W][4], X = 0
 void launchTail(DType dt, const void *y, const float *w2, const float *b2,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *stateOut,
-    std::uint8_t *outU8, int H, int W, const unsigned *sums, hipStream_t stream);
+    std::uint8_t *outU8, std::ptrdiff_t outStride, int H, int W, const unsigned *sums,
+    hipStream_t stream);
 
 // ---- staging ----------------------------------------------------------------
 // Row-wise device copy with signed strides (bottom-up frames).

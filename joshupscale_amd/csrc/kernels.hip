@@ -681,6 +681,7 @@ struct ResidentParams {
 	int H, W, pitch;
 	int GX, GY, RH;
 	int nLayers;
+	int bumpGeneration;  // host-side only: launch bump_generation_kernel first
 };
 
 typedef unsigned long long u64;
@@ -1180,8 +1181,10 @@ void launchResidentT(const ResidentParams &p, hipStream_t stream) {
 		}
 		attrSet = true;
 	}
-	hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream,
-	    const_cast<unsigned *>(p.gen));
+	if (p.bumpGeneration) {
+		hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream,
+		    const_cast<unsigned *>(p.gen));
+	}
 	hipLaunchKernelGGL(kern, dim3(p.GX * p.GY), dim3(256), kResLds, stream, p);
 	hipCheckLaunch("tower_resident");
 }
@@ -1241,8 +1244,12 @@ __global__ __launch_bounds__(1024) void frame_sums_kernel(const std::uint8_t *__
 template <typename T>
 __global__ __launch_bounds__(256) void pack_frames_kernel(const std::uint8_t *__restrict__ frame,
     std::ptrdiff_t frameStride, const T *__restrict__ prev, T *__restrict__ cur, int H, int W,
-    int PH, int PW, int padTop, int padLeft, int numInputs, const unsigned *__restrict__ sums) {
+    int PH, int PW, int padTop, int padLeft, int numInputs, const unsigned *__restrict__ sums,
+    unsigned *generation) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
+	// first kernel of every frame: bump the launch generation the resident tower tags
+	// its halo slots with (saves a 1-thread launch)
+	if (idx == 0 && generation != nullptr) *generation = *generation + 1;
 	if (idx >= PH * PW) return;
 	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));
 	const int py = idx / PW;
@@ -1429,8 +1436,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
     const float *__restrict__ w2, const float *__restrict__ b2,
     const std::uint8_t *__restrict__ frame, std::ptrdiff_t frameStride,
-    f16 *__restrict__ stateOut, std::uint8_t *__restrict__ outU8, int H, int W,
-    const unsigned *__restrict__ sums) {
+    f16 *__restrict__ stateOut, std::uint8_t *__restrict__ outU8, std::ptrdiff_t outStride,
+    int H, int W, const unsigned *__restrict__ sums) {
 	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));
 	const int MW = 2 * W, MH = 2 * H;
 	const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1494,7 +1501,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
 			pk[b2i] = packed;  // X byte = 0
 		}
 		*reinterpret_cast<Vec8<f16> *>(stateOut + ((size_t)Y * WW + 2 * mx) * 4) = st;
-		*reinterpret_cast<uint2 *>(outU8 + ((size_t)Y * WW + 2 * mx) * 4) = make_uint2(pk[0], pk[1]);
+		*reinterpret_cast<uint2 *>(outU8 + Y * outStride + 2 * mx * 4) = make_uint2(pk[0], pk[1]);
 	}
 }
 
@@ -1556,6 +1563,11 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 
 void setTowerVariant(int v) { g_TowerVariant = v; }
 
+void launchBumpGeneration(unsigned *generation, hipStream_t stream) {
+	hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream, generation);
+	hipCheckLaunch("bump_generation");
+}
+
 bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH) {
 	const int gx = (W + kResRW - 1) / kResRW;
 	const int gy = (H + kResMaxRH - 1) / kResMaxRH;
@@ -1591,6 +1603,7 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.GY = q.GY;
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
+	p.bumpGeneration = q.bumpGeneration;
 	if ((p.nLayers & 1) != (p.hasHead ? 1 : 0)) {
 		throw std::invalid_argument("resident tower: layer count must be 2*blocks (+1 with a head)");
 	}
@@ -1614,16 +1627,17 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
-    int padLeft, int numInputs, const unsigned *sums, hipStream_t stream) {
+    int padLeft, int numInputs, const unsigned *sums, unsigned *generation,
+    hipStream_t stream) {
 	const unsigned nb = blocksFor((size_t)PH * PW);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(pack_frames_kernel<f16>, dim3(nb), dim3(256), 0, stream, frame,
 		    frameStride, static_cast<const f16 *>(prevPacked), static_cast<f16 *>(curPacked), H, W,
-		    PH, PW, padTop, padLeft, numInputs, sums);
+		    PH, PW, padTop, padLeft, numInputs, sums, generation);
 	} else {
 		hipLaunchKernelGGL(pack_frames_kernel<bf16>, dim3(nb), dim3(256), 0, stream, frame,
 		    frameStride, static_cast<const bf16 *>(prevPacked), static_cast<bf16 *>(curPacked), H,
-		    W, PH, PW, padTop, padLeft, numInputs, sums);
+		    W, PH, PW, padTop, padLeft, numInputs, sums, generation);
 	}
 	hipCheckLaunch("pack_frames");
 }
@@ -1670,16 +1684,16 @@ void launchWarpPack(DType dt, const void *state, const float *flow, const std::u
 
 void launchTail(DType dt, const void *y, const float *w2, const float *b2,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *stateOut, std::uint8_t *outU8,
-    int H, int W, const unsigned *sums, hipStream_t stream) {
+    std::ptrdiff_t outStride, int H, int W, const unsigned *sums, hipStream_t stream) {
 	const unsigned nb = blocksFor((size_t)4 * H * W);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(tail_kernel<f16>, dim3(nb), dim3(256), 0, stream,
 		    static_cast<const f16 *>(y), w2, b2, frame, frameStride, static_cast<f16 *>(stateOut),
-		    outU8, H, W, sums);
+		    outU8, outStride, H, W, sums);
 	} else {
 		hipLaunchKernelGGL(tail_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
 		    static_cast<const bf16 *>(y), w2, b2, frame, frameStride, static_cast<f16 *>(stateOut),
-		    outU8, H, W, sums);
+		    outU8, outStride, H, W, sums);
 	}
 	hipCheckLaunch("tail");
 }

@@ -178,6 +178,12 @@ def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
         rt.process_image(frames[0])
     assert all(np.array_equal(a, b) for a, b in zip(first, inter))
     rt2.close()
+    monkeypatch.setenv("JU_TOWER", "layers")            # per-layer tower kernels: same arithmetic
+    rt4 = R.Runtime(blob, 0, R.DTYPE_BF16)
+    layered = [rt4.process_image(f).copy() for f in frames]
+    assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(first, layered))
+    rt4.close()
+    monkeypatch.delenv("JU_TOWER")
     monkeypatch.setenv("JU_NO_GRAPH", "1")              # eager launches == graph replay
     rt3 = R.Runtime(blob, 0, R.DTYPE_BF16)
     eager = [rt3.process_image(f).copy() for f in frames]
