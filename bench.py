@@ -73,7 +73,7 @@ def main() -> int:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torchrun, also with a single rank
         jdist.init("nccl")  # RCCL
 
     cfg = M.PRESETS[args.preset]
@@ -121,6 +121,13 @@ def main() -> int:
         flops_per_launch = flops / max(launches, 1)
         achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         total_flops = rt.time_steps("", 0)[2]
+        # HBM traffic of the dominant kernel from the committed PMC summary (bench.py cannot
+        # run rocprofv3 around itself); only used when it describes the kernel measured here
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_tower_traffic.json")
+        if launches == 1 and args.preset == "psp-quality" and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("bytes_per_launch")
         result = {
             "metric": "frames/sec 480x270->1920x1080 recurrent SR" if args.preset.startswith("psp")
                       else f"frames/sec {w}x{h}->{4 * w}x{4 * h} recurrent SR",
@@ -142,7 +149,8 @@ def main() -> int:
                 "kernel": "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch"
                           if launches == 1 else "conv_tower_kernel 3x3 64->64 (one residual-block conv)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_tower_traffic.json)",
                 "launch_ms": ms, "launches_per_frame": launches,
                 "flops_per_launch": flops_per_launch,
             },
@@ -152,7 +160,7 @@ def main() -> int:
         print(json.dumps(result), flush=True)
     jdist.barrier()
     rt.close()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     return 0
 

@@ -36,7 +36,7 @@ def broadcast_model(blob: Optional[bytes], device: torch.device, src: int = 0) -
 
     Two collectives: the length (one int64), then the payload as uint8 on
     ``device`` (for "nccl" a GPU tensor, i.e. RCCL moves it over xGMI)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         if blob is None:
             raise ValueError("single process needs the model bytes")
         return blob
