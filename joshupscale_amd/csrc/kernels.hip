@@ -636,10 +636,12 @@ void launchTowerT(const ConvParams &p, hipStream_t stream) {
 // Per-layer launches are memory- and latency-chain-bound:
 // a 64->64 layer moves ~46 MB for 9.6 GFLOP and pays a kernel boundary plus the
 // flush of 16.6 MB of dirty L2.  Here each workgroup (one per CU) owns a region
-// of 30 x RH (<= 17) pixels for the whole tower:
-//   * two LDS buffers of (RH+2) x 32 px x 128 B hold the block input X and the
+// of 32 x RH (<= 16) pixels for the whole tower (480x270: 15 x 17 = 255 regions):
+//   * two LDS buffers of (RH+2) x 34 px x 128 B hold the block input X and the
 //     intermediate T, including a one-pixel halo ring; conv1 reads X writes T,
-//     conv2 reads T, adds the residual from X and writes X in place;
+//     conv2 reads T, adds the residual from X and writes X in place; the 16-byte
+//     chunk swizzle is keyed on the COLUMN ((cc>>1)&7): a row is 272 x 16 B, a
+//     multiple of the 16-slot bank row, so rows do not shift the slot pattern;
 //   * the wave's weights (its 32 output channels x 576) are the MFMA A operand
 //     straight from 144 VGPRs, double-buffered (288) so the next layer's weights
 //     stream in from L2 behind the current layer's MFMAs;
@@ -655,13 +657,15 @@ void launchTowerT(const ConvParams &p, hipStream_t stream) {
 // Nothing depends on dispatch order or XCD placement; all workgroups must be
 // co-resident (grid <= #CUs, one workgroup per CU by LDS size); every wait is
 // bounded in time and reports through *error.
-constexpr int kResRW = 30;
-constexpr int kResMaxRH = 17;
-constexpr int kResRowBytes = 32 * 128;
-constexpr int kResBufBytes = (kResMaxRH + 2) * kResRowBytes;       // 77824
+constexpr int kResRW = 32;                                          // region width = one MFMA block
+constexpr int kResMaxRH = 16;                                       // 8 row pairs, 4 per wave group
+constexpr int kResPitch = kResRW + 2;                               // LDS row: 32 px + halo column each side
+constexpr int kResRowBytes = kResPitch * 128;                       // 4352
+constexpr int kResBufBytes = (kResMaxRH + 2) * kResRowBytes;       // 78336
 constexpr int kResOffA = 0;
-constexpr int kResOffB = kResBufBytes + 256;                        // A's overrun pad
-constexpr int kResOffMisc = kResOffB + kResBufBytes + kResRowBytes + 256;
+constexpr int kResOffB = kResBufBytes;
+constexpr int kResOffMisc = kResOffB + kResBufBytes;
+static_assert(kResRowBytes == 4352, "the ds_read immediates in tower_resident_kernel assume a 4352-byte row");
 constexpr int kResLds = kResOffMisc + 64 + 512;                     // flag, 2 bias slots
 constexpr int kResMailSlots = 4 * 32 * 8;                           // 16-byte slots per region per parity
 constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of s_memrealtime
@@ -730,13 +734,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	//      pixels outside the image stay zero (the buffers were just cleared) ----
 	{
 		const T *in = static_cast<const T *>(p.in);
-		const int nInstr = (rhv + 2) * 4;  // 8 pixels per wave-instruction, 32 px per row
+		const int nPix = (rhv + 2) * kResPitch;
+		const int nInstr = (nPix + 7) / 8;  // 8 pixels (1 KiB) per wave-instruction, rows back to back
 		for (int i = wave; i < nInstr; i += 4) {
 			const int q = i * 8 + (lane >> 3);
-			const int rr = q >> 5, cc = q & 31;
-			const int c = (lane & 7) ^ ((q >> 1) & 7);
+			const int rr = q / kResPitch, cc = q - rr * kResPitch;
+			const int c = (lane & 7) ^ ((cc >> 1) & 7);
 			const int gy = y0 - 1 + rr, gx = x0 - 1 + cc;
-			if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+			if (q < nPix && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
 				glds16(in + ((size_t)gy * p.inPitch + gx) * 64 + c * 8, smem + kResOffA + i * 1024);
 			}
 		}
@@ -814,9 +819,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			const int dx = m >> 2, ks = m & 3;
 			const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
 			if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
-			else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fb[set][1]) : "v"(a));
-			else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fb[set][2]) : "v"(a));
-			else asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fb[set][3]) : "v"(a));
+			else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4352" : "=v"(fb[set][1]) : "v"(a));
+			else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8704" : "=v"(fb[set][2]) : "v"(a));
+			else asm volatile("ds_read_b128 %0, %1 offset:13056" : "=v"(fb[set][3]) : "v"(a));
 		};
 		auto rowAddrOf = [&](int unit) { return ldsBase + inOff + (2 * unit) * kResRowBytes; };
 
@@ -1013,33 +1018,48 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		const int par = (layer + 1) & 1;
 		u32x4 tm;
 		tagMasks(layer, &tm);
-		constexpr int NS = kResMailSlots / 256;
+		constexpr int NS = kResMailSlots / 256 + 1;  // 4 sides x 32 entries x 8 chunks, + the 4 corners
 		unsigned hsrc[NS];
 		unsigned char *hd[NS];
 		unsigned pending = 0;
 #pragma unroll
 		for (int it = 0; it < NS; ++it) {
-			const int idx = it * 256 + tid;
-			const int hp = idx >> 3, c = idx & 7;
-			const int side = hp >> 5, e = hp & 31;
-			// side 0: row above, 1: row below, 2: column left, 3: column right;
-			// entries 30/31 of the two row sides are the corners
-			int nx = gxr, ny = gyr, strip, se, rr, cc;
+			int nx = gxr, ny = gyr, strip, se, rr, cc, c;
 			bool valid;
-			if (side < 2) {
-				ny += side == 0 ? -1 : 1;
-				strip = side == 0 ? 1 : 0;  // their bottom row / their top row
-				rr = side == 0 ? 0 : rhv + 1;
-				if (e < kResRW) { se = e; cc = e + 1; valid = e < rwv; }
-				else if (e == 30) { nx -= 1; se = kResRW - 1; cc = 0; valid = true; }
-				else { nx += 1; se = 0; cc = rwv + 1; valid = true; }
+			if (it < NS - 1) {
+				const int idx = it * 256 + tid;
+				const int hp = idx >> 3;
+				c = idx & 7;
+				const int side = hp >> 5, e = hp & 31;
+				// side 0: row above, 1: row below, 2: column left, 3: column right
+				if (side < 2) {
+					ny += side == 0 ? -1 : 1;
+					strip = side == 0 ? 1 : 0;  // their bottom row / their top row
+					rr = side == 0 ? 0 : rhv + 1;
+					se = e;
+					cc = e + 1;
+					valid = e < rwv;
+				} else {
+					nx += side == 2 ? -1 : 1;
+					strip = side == 2 ? 3 : 2;  // their right column / their left column
+					se = e;
+					rr = e + 1;
+					cc = side == 2 ? 0 : rwv + 1;
+					valid = e < rhv;
+				}
 			} else {
-				nx += side == 2 ? -1 : 1;
-				strip = side == 2 ? 3 : 2;  // their right column / their left column
-				se = e;
-				rr = e + 1;
-				cc = side == 2 ? 0 : rwv + 1;
-				valid = e < rhv;
+				// corners: threads 0..31 = 4 corners x 8 chunks; the diagonal neighbour's
+				// bottom/top row strip, last/first entry (interior columns are 32 wide)
+				const int k = tid >> 3;
+				c = tid & 7;
+				const bool up = k < 2, left = (k & 1) == 0;
+				ny += up ? -1 : 1;
+				nx += left ? -1 : 1;
+				strip = up ? 1 : 0;
+				se = left ? kResRW - 1 : 0;
+				rr = up ? 0 : rhv + 1;
+				cc = left ? 0 : rwv + 1;
+				valid = tid < 32;
 			}
 			valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
 			const int nreg = valid ? ny * p.GX + nx : region;
