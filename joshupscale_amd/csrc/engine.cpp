@@ -75,8 +75,8 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 	ConvWeights cw;
 	// generator conv_1 (64 padded input channels) runs as layer 0 of the resident tower
 	const bool towerLayer = name.rfind("generator/block_", 0) == 0 || name == "generator/conv_1";
-	if (towerLayer && f.cout == 64) {
-		cw.nb = 2;  // the tower kernels read the 64-cout layout
+	if ((towerLayer && f.cout == 64) || name == "generator/conv_trans_1") {
+		cw.nb = 2;  // the tower kernels and the fused tail read the 64-cout-block layout
 		cw.rw = 2;
 	} else {
 		convTiling(H, W, f.cout, &cw.nb, &cw.rw);
@@ -169,6 +169,9 @@ void Engine::buildWeights(const ModelFile &model) {
 		m_TailW2.upload(k2.data, k2.count * 4);
 		m_TailB2 = DeviceBuffer(32);  // convT2 bias (3 f32) + from byte 16: the frame's channel sums
 		m_TailB2.upload(b2.data, 12);
+		const auto frag = packTailWeights(k2.data, m_DType);
+		m_TailW2Frag = DeviceBuffer(frag.size() * 2);
+		m_TailW2Frag.upload(frag.data(), frag.size() * 2);
 	}
 }
 
@@ -333,9 +336,31 @@ void Engine::buildProgram(int set) {
 		}
 	}
 	m_TrunkOut = xs[a];
-	addConvStep(&prog, "tail", "generator/conv_trans_1", Op(xs[a]), none, Op("tail_y"), H, W, true,
-	    false);
-	{
+	if (m_FusedTail && c.genFilters == 64) {
+		const ConvWeights &cw = m_Convs.at("generator/conv_trans_1");
+		TailFusedLaunch tf{};
+		const Operand xin = Op(xs[a]);
+		tf.x = xin.ptr;
+		tf.xPitch = xin.pitch;
+		tf.w1 = cw.w.get();
+		tf.b1 = cw.bias.as<float>();
+		tf.w2 = m_TailW2Frag.get();
+		tf.b2 = m_TailB2.as<float>();
+		tf.state = stateOut;
+		tf.sums = sums;
+		tf.H = H;
+		tf.W = W;
+		prog.push_back({"tail", 2.0 * H * W * (64.0 * 128 + 4 * 4 * 32 * 3), [=](hipStream_t s) {
+			                TailFusedLaunch t = tf;
+			                t.frame = io->in;
+			                t.frameStride = io->inStride;
+			                t.outU8 = io->out;
+			                t.outStride = io->outStride;
+			                launchTailFused(dt, t, s);
+		                }});
+	} else {
+		addConvStep(&prog, "tail", "generator/conv_trans_1", Op(xs[a]), none, Op("tail_y"), H, W,
+		    true, false);
 		const void *y = T("tail_y");
 		const float *w2 = m_TailW2.as<float>();
 		const float *b2 = m_TailB2.as<float>();
@@ -378,6 +403,9 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	} else if (c.flowResFilters % 32 != 0) {
 		throw std::invalid_argument("Unsupported model: flow filters must be multiples of 32");
 	}
+
+	const char *tailMode = std::getenv("JU_TAIL");
+	m_FusedTail = !(tailMode && std::string(tailMode) == "split");
 
 	buildWeights(model);
 

@@ -141,7 +141,8 @@ private:
 
 	std::map<std::string, Tensor> m_Tensors;
 	std::map<std::string, ConvWeights> m_Convs;
-	DeviceBuffer m_TailW2, m_TailB2;
+	DeviceBuffer m_TailW2, m_TailB2, m_TailW2Frag;
+	bool m_FusedTail = true;  // JU_TAIL=split: convT1 as a conv launch + the VALU tail kernel
 	DeviceBuffer m_InStage, m_OutStage, m_RawStage;
 	DeviceBuffer m_State[2], m_Packed[2];
 	// resident tower (one launch for all residual-block convolutions)

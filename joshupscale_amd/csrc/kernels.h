@@ -177,6 +177,27 @@ void launchTail(DType dt, const void *y, const float *w2, const float *b2,
     std::uint8_t *outU8, std::ptrdiff_t outStride, int H, int W, const unsigned *sums,
     hipStream_t stream);
 
+// Fused tail: both transposed convs on the matrix cores + tanh + skip + clip + pack.
+// x: trunk addressed at pixel (0,0) with pitch xPitch (0 = dense); w1/b1: convT1 as a
+// 1x1 conv 64->128 (packConvWeights, nb = 2) and its folded bias; w2: convT2 A fragments
+// from packTailWeights(); b2 [3]; needs 64 trunk channels and 32 mid channels.
+struct TailFusedLaunch {
+	const void *x;
+	int xPitch;
+	const void *w1;
+	const float *b1;
+	const void *w2;
+	const float *b2;
+	const std::uint8_t *frame;
+	std::ptrdiff_t frameStride;
+	void *state;
+	std::uint8_t *outU8;
+	std::ptrdiff_t outStride;
+	const unsigned *sums;
+	int H, W;
+};
+void launchTailFused(DType dt, const TailFusedLaunch &p, hipStream_t stream);
+
 // ---- staging ----------------------------------------------------------------
 // Row-wise device copy with signed strides (bottom-up frames).
 void launchCopyRows(const std::uint8_t *src, std::ptrdiff_t srcStride, std::uint8_t *dst,

@@ -1525,6 +1525,225 @@ __global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
 	}
 }
 
+
+// ---------------------------------------------------------------------------
+// fused generator tail on the matrix cores
+// ---------------------------------------------------------------------------
+// trunk [H][W][64] -> ConvT(2x2,s2,64->32)+BN+ReLU -> ConvT(2x2,s2,32->3)+bias -> tanh
+// -> + bilinear x4 of the LR frame -> clip -> HR state (f16) and BGRX u8, in ONE
+// pass (reference models.py:559-593, keras_layers.py:211-230, cuda_convert.cc.cu:76-81).
+// The two-kernel form wrote and re-read a [H][W][128] tensor (66 MB per frame).
+//   stage 1  D1[128][32 px] = W1[128][64] x X[64][32 px]: 4 cout blocks x 4 k-steps.
+//            Cout block nb = (a*2+b) IS the mid-resolution pixel (2h+a, 2w+b)'s 32
+//            channels, so after bias + ReLU each block goes to LDS pixel-major
+//            (64 B per mid pixel) and is directly the B operand of
+//   stage 2  D2[16][32 mid px] = W2[16][32] x Y[32][32 mid px], rows m = 4*(a'*2+b') + c:
+//            lane (mid px, hh), register group g2 then holds the 3 channels of ONE HR
+//            pixel (a' = g2, b' = hh).
+// One workgroup = 8 LR rows x 32 px (4 waves x 2 rows); outputs are staged in LDS
+// and written as whole rows, 16 B per lane.
+constexpr int kTailLdsIn = 8 * 32 * 128;          // 32 KiB input tile
+constexpr int kTailLdsW1 = 64 * 128 * 2;          // 16 KiB convT1 weights (fragment order)
+constexpr int kTailLdsMid = 4 * 4 * 32 * 64;      // per wave: 4 mid-pixel groups x 32 px x 64 B = 8 KiB
+constexpr int kTailLdsOut = 4 * (4 * 128 * 8 + 4 * 128 * 4);  // per wave: 4 HR rows x 128 px x (8 + 4) B
+constexpr int kTailLds = kTailLdsIn + kTailLdsW1 + kTailLdsMid + kTailLdsOut;
+
+struct TailFusedParams {
+	const void *x;        // trunk, addressed at image pixel (0,0)
+	int xPitch;           // row pitch in pixels
+	const void *w1;       // convT1 as 1x1 conv 64->128, packConvWeights order with nb = 2
+	const float *b1;      // [128]
+	const void *w2;       // A fragments of convT2: [2 ks][64 lanes][8] 16-bit
+	const float *b2;      // [3]
+	const std::uint8_t *frame;
+	std::ptrdiff_t frameStride;
+	void *state;          // f16 [4H][4W][4]
+	std::uint8_t *outU8;
+	std::ptrdiff_t outStride;
+	const unsigned *sums;
+	int H, W;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	unsigned char *smI = smem;
+	unsigned char *smW = smem + kTailLdsIn;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
+	unsigned char *smMid = smem + kTailLdsIn + kTailLdsW1 + wave * (kTailLdsMid / 4);
+	unsigned char *smOut = smem + kTailLdsIn + kTailLdsW1 + kTailLdsMid + wave * (kTailLdsOut / 4);
+	const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
+	const T *__restrict__ x = static_cast<const T *>(p.x);
+	const float bright = brightnessOf(p.sums, 1.0f / static_cast<float>(p.H * p.W));
+
+	// ---- stage weights (linear) and the 8 x 32 input tile (swizzled chunks, zero outside) ----
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(p.w1);
+		uint4 *dst = reinterpret_cast<uint4 *>(smW);
+#pragma unroll
+		for (int k = 0; k < kTailLdsW1 / 16 / 256; ++k) dst[tid + k * 256] = src[tid + k * 256];
+		uint4 v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const int i = tid + k * 256;  // 8 rows x 32 px x 8 chunks = 2048
+			const int q = i >> 3, c = i & 7;
+			const int r = q >> 5, xx = q & 31;
+			const int gy = min(ty0 + r, p.H - 1), gx = min(tx0 + xx, p.W - 1);
+			v[k] = *reinterpret_cast<const uint4 *>(x + ((size_t)gy * p.xPitch + gx) * 64 + c * 8);
+		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const int i = tid + k * 256;
+			const int q = i >> 3, c = i & 7;
+			*reinterpret_cast<uint4 *>(smI + q * 128 + ((c ^ ((q >> 1) & 7)) << 4)) = v[k];
+		}
+	}
+	// convT2 A fragments (2 k-steps) and biases in registers
+	Vec8<T> a2[2];
+	a2[0] = reinterpret_cast<const Vec8<T> *>(p.w2)[lane];
+	a2[1] = reinterpret_cast<const Vec8<T> *>(p.w2)[64 + lane];
+	const float b2v[3] = {p.b2[0], p.b2[1], p.b2[2]};
+	__syncthreads();
+
+	for (int rw = 0; rw < 2; ++rw) {
+		const int lr = wave * 2 + rw;  // LR row inside the tile
+		const int h = ty0 + lr;
+		// ---- stage 1: 128 couts x 32 px ----
+		f32x16 acc[4];
+#pragma unroll
+		for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const f32x4 b = *reinterpret_cast<const f32x4 *>(p.b1 + nb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) acc[nb][4 * g + i] = b[i];
+			}
+		}
+#pragma unroll
+		for (int ks = 0; ks < 4; ++ks) {
+			const int q = lr * 32 + px;
+			const int c = ks * 2 + hh;
+			const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(smI + q * 128 + ((c ^ ((q >> 1) & 7)) << 4));
+#pragma unroll
+			for (int nb = 0; nb < 4; ++nb) {
+				// weights: [cog = nb>>1][tap 0][ks][h][n = 64][8]
+				const Vec8<T> a = *reinterpret_cast<const Vec8<T> *>(
+				    smW + (nb >> 1) * (64 * 64 * 2) + (((ks * 2 + hh) * 64 + (nb & 1) * 32 + px) << 4));
+				acc[nb] = mfma32(a, b, acc[nb]);
+			}
+		}
+		// ReLU, 16-bit, to LDS as mid pixels: group nb, pixel px, 64 B (4 chunks, P = 4 swizzle)
+#pragma unroll
+		for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				Vec4<T> o = {static_cast<T>(acc[nb][4 * g + 0]), static_cast<T>(acc[nb][4 * g + 1]),
+				    static_cast<T>(acc[nb][4 * g + 2]), static_cast<T>(acc[nb][4 * g + 3])};
+				*reinterpret_cast<Vec4<T> *>(smMid + nb * 2048 + px * 64 +
+				                             ((g ^ ((px >> 2) & 3)) << 4) + hh * 8) = reluPacked<T>(o);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// LR neighbourhood for the bilinear x4 skip of this lane's LR pixel (px)
+		const int w = tx0 + px;
+		const int hc = min(h, p.H - 1), wc = min(w, p.W - 1);
+		const int h1 = min(hc + 1, p.H - 1), w1 = min(wc + 1, p.W - 1);
+		float lrv[2][2][3];
+#pragma unroll
+		for (int yy = 0; yy < 2; ++yy) {
+#pragma unroll
+			for (int xx = 0; xx < 2; ++xx) {
+				const unsigned v = *reinterpret_cast<const unsigned *>(
+				    p.frame + (yy ? h1 : hc) * p.frameStride + (xx ? w1 : wc) * 4);
+				lrv[yy][xx][0] = preprocessU8(v & 0xff);
+				lrv[yy][xx][1] = preprocessU8((v >> 8) & 0xff);
+				lrv[yy][xx][2] = preprocessU8((v >> 16) & 0xff);
+			}
+		}
+		// ---- stage 2 per mid-pixel group (a, b) ----
+#pragma unroll
+		for (int nb = 0; nb < 4; ++nb) {
+			const int a = nb >> 1, bb = nb & 1;
+			f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks) {
+				const int c = ks * 2 + hh;
+				const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(
+				    smMid + nb * 2048 + px * 64 + ((c ^ ((px >> 2) & 3)) << 4));
+				d = mfma32(a2[ks], b, d);
+			}
+			// lane (px, hh), g2: HR pixel (4h + 2a + g2, 4w + 2b + hh), channels d[4*g2 + 0..2]
+#pragma unroll
+			for (int g2 = 0; g2 < 2; ++g2) {
+				const int yq = 2 * a + g2, xq = 2 * bb + hh;  // position inside the 4x4 HR block
+				const float fy = yq * 0.25f, fx = xq * 0.25f;
+				Vec4<f16> st;
+				unsigned packed = 0;
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const float top = lrv[0][0][c] + (lrv[0][1][c] - lrv[0][0][c]) * fx;
+					const float bot = lrv[1][0][c] + (lrv[1][1][c] - lrv[1][0][c]) * fx;
+					const float skip = top + (bot - top) * fy;
+					float r = tanhf(d[4 * g2 + c] + b2v[c]) + skip;
+					r = fminf(fmaxf(r, -0.5f), 0.5f);
+					st[c] = static_cast<f16>(r - bright);
+					const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);
+					packed |= (u & 0xff) << (8 * c);
+				}
+				st[3] = static_cast<f16>(0.f);
+				const int xcol = 4 * px + xq;  // HR column inside the 128-px row segment
+				*reinterpret_cast<Vec4<f16> *>(smOut + yq * 1024 + xcol * 8) = st;
+				*reinterpret_cast<unsigned *>(smOut + 4096 + yq * 512 + xcol * 4) = packed;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// ---- coalesced output: 4 HR rows x 128 px ----
+		if (h < p.H) {
+			const int WW = 4 * p.W;
+			const int nValidPx = min(128, 4 * (p.W - tx0));
+			f16 *stateOut = static_cast<f16 *>(p.state);
+#pragma unroll
+			for (int yq = 0; yq < 4; ++yq) {
+				const int Y = 4 * h + yq;
+				// state: 1024 B per row = 64 lanes x 16 B (2 px per lane)
+				if (2 * lane < nValidPx) {
+					const uint4 v = *reinterpret_cast<const uint4 *>(smOut + yq * 1024 + lane * 16);
+					*reinterpret_cast<uint4 *>(stateOut + ((size_t)Y * WW + 4 * tx0 + 2 * lane) * 4) = v;
+				}
+				// u8: 512 B per row = 64 lanes x 8 B (2 px per lane)
+				if (2 * lane < nValidPx) {
+					const uint2 v = *reinterpret_cast<const uint2 *>(smOut + 4096 + yq * 512 + lane * 8);
+					*reinterpret_cast<uint2 *>(p.outU8 + Y * p.outStride + (4 * tx0 + 2 * lane) * 4) = v;
+				}
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+template <typename T>
+void launchTailFusedT(const TailFusedParams &p, hipStream_t stream) {
+	auto kern = tail_fused_kernel<T>;
+	static bool attrSet = false;
+	if (!attrSet) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+		    hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds);
+		if (e != hipSuccess) {
+			throw std::runtime_error(std::string("hipFuncSetAttribute(tail LDS): ") + hipGetErrorString(e));
+		}
+		attrSet = true;
+	}
+	dim3 grid((p.W + 31) / 32, (p.H + 7) / 8);
+	hipLaunchKernelGGL(kern, grid, dim3(256), kTailLds, stream, p);
+	hipCheckLaunch("tail_fused");
+}
+
 // ---------------------------------------------------------------------------
 // staging helpers
 // ---------------------------------------------------------------------------
@@ -1716,6 +1935,26 @@ void launchTail(DType dt, const void *y, const float *w2, const float *b2,
 		    outU8, outStride, H, W, sums);
 	}
 	hipCheckLaunch("tail");
+}
+
+void launchTailFused(DType dt, const TailFusedLaunch &q, hipStream_t stream) {
+	TailFusedParams p{};
+	p.x = q.x;
+	p.xPitch = q.xPitch ? q.xPitch : q.W;
+	p.w1 = q.w1;
+	p.b1 = q.b1;
+	p.w2 = q.w2;
+	p.b2 = q.b2;
+	p.frame = q.frame;
+	p.frameStride = q.frameStride;
+	p.state = q.state;
+	p.outU8 = q.outU8;
+	p.outStride = q.outStride;
+	p.sums = q.sums;
+	p.H = q.H;
+	p.W = q.W;
+	if (dt == kF16) launchTailFusedT<f16>(p, stream);
+	else launchTailFusedT<bf16>(p, stream);
 }
 
 void launchFrameSums(const std::uint8_t *frame, std::ptrdiff_t frameStride, int H, int W,

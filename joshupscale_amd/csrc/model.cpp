@@ -223,6 +223,24 @@ std::uint16_t floatToBF16(float f) {
 	return static_cast<std::uint16_t>(x >> 16);
 }
 
+std::vector<std::uint16_t> packTailWeights(const float *k2, DType dt) {
+	std::vector<std::uint16_t> out(2 * 64 * 8);
+	for (int ks = 0; ks < 2; ++ks) {
+		for (int l = 0; l < 64; ++l) {
+			for (int j = 0; j < 8; ++j) {
+				const int m = l & 31, k = 16 * ks + 8 * (l >> 5) + j;
+				float v = 0.f;
+				if (m < 16 && (m & 3) < 3) {
+					const int q = m >> 2, c = m & 3;  // q = a'*2 + b'
+					v = k2[(q * 3 + c) * 32 + k];     // [a'][b'][c][o]
+				}
+				out[(ks * 64 + l) * 8 + j] = dt == kF16 ? floatToF16(v) : floatToBF16(v);
+			}
+		}
+	}
+	return out;
+}
+
 std::vector<std::uint16_t> packConvWeights(
     const FoldedConv &c, const std::vector<int> &cinMap, int nb, DType dt) {
 	const int cinP = static_cast<int>(cinMap.size());

@@ -92,6 +92,11 @@ FoldedConv foldConvTranspose2x2(
 std::vector<std::uint16_t> packConvWeights(
     const FoldedConv &c, const std::vector<int> &cinMap, int nb, DType dt);
 
+// convT2 (keras kernel [2][2][3][32]) as MFMA A fragments for tail_fused_kernel:
+// A[m][k], m = 4*(a'*2+b') + c (c < 3, other rows zero), k = input channel;
+// [2 k-steps][64 lanes][8]: lane l holds A[l & 31][16 ks + 8 (l >> 5) + j].
+std::vector<std::uint16_t> packTailWeights(const float *k2, DType dt);
+
 std::uint16_t floatToF16(float f);
 std::uint16_t floatToBF16(float f);
 

@@ -184,6 +184,12 @@ def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
     assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(first, layered))
     rt4.close()
     monkeypatch.delenv("JU_TOWER")
+    monkeypatch.setenv("JU_TAIL", "split")              # two-kernel tail: same arithmetic up to fp32 order
+    rt5 = R.Runtime(blob, 0, R.DTYPE_BF16)
+    split = [rt5.process_image(f).copy() for f in frames]
+    assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(first, split))
+    rt5.close()
+    monkeypatch.delenv("JU_TAIL")
     monkeypatch.setenv("JU_NO_GRAPH", "1")              # eager launches == graph replay
     rt3 = R.Runtime(blob, 0, R.DTYPE_BF16)
     eager = [rt3.process_image(f).copy() for f in frames]
