@@ -177,7 +177,7 @@ void Engine::buildWeights(const ModelFile &model) {
 
 void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
     const std::string &wname, Operand in, Operand res, Operand out, int H, int W,
-    bool relu, bool outF32, bool tower) {
+    bool relu, bool outF32, bool tower, bool pool) {
 	auto it = m_Convs.find(wname);
 	if (it == m_Convs.end()) throw std::logic_error("missing conv weights " + wname);
 	const ConvWeights &cw = it->second;
@@ -199,6 +199,10 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 	p.outF32 = outF32 ? 1 : 0;
 	p.nb = cw.nb;
 	p.rw = cw.rw;
+	if (pool) {  // the pooled epilogue pairs the two rows of a wave
+		p.pool = 1;
+		p.rw = 2;
+	}
 	const DType dt = m_DType;
 	Step s;
 	s.tag = tag;
@@ -251,13 +255,16 @@ void Engine::buildProgram(int set) {
 			const std::string n = "flow/block_" + std::to_string(i + 1);
 			const int f = c.flowFilters[i];
 			addConvStep(&prog, "flow", n + "/conv_1", cur, none, Op(n + "/a_1"), h, w, true, false);
-			addConvStep(&prog, "flow", n + "/conv_2", Op(n + "/a_1"), none, Op(n + "/a_2"), h, w,
-			    true, false);
+			const bool fusePool = i < nb && m_FusedPool;
+			addConvStep(&prog, "flow", n + "/conv_2", Op(n + "/a_1"), none,
+			    Op(fusePool ? n + "/resample" : n + "/a_2"), h, w, true, false, false, fusePool);
 			const void *src = T(n + "/a_2");  // dense tensors
 			void *dst = T(n + "/resample");
 			if (i < nb) {
-				prog.push_back({"flow", 0.0,
-				    [=](hipStream_t s) { launchMaxPool2(dt, src, dst, h, w, f, s); }});
+				if (!fusePool) {
+					prog.push_back({"flow", 0.0,
+					    [=](hipStream_t s) { launchMaxPool2(dt, src, dst, h, w, f, s); }});
+				}
 				h /= 2;
 				w /= 2;
 			} else {
@@ -406,6 +413,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 
 	const char *tailMode = std::getenv("JU_TAIL");
 	m_FusedTail = !(tailMode && std::string(tailMode) == "split");
+	const char *poolMode = std::getenv("JU_POOL");
+	m_FusedPool = !(poolMode && std::string(poolMode) == "split");
 
 	buildWeights(model);
 
@@ -749,19 +758,42 @@ std::size_t Engine::readTensor(const std::string &name, float *dst, std::size_t 
 	return outCount;
 }
 
-double Engine::flopsOf(const std::string &tag) const {
+double Engine::flopsOf(const std::string &tagSpec) const {
+	std::string tag = tagSpec;
+	int only = -1;
+	const std::size_t hash = tagSpec.find('#');
+	if (hash != std::string::npos) {
+		tag = tagSpec.substr(0, hash);
+		only = std::atoi(tagSpec.c_str() + hash + 1);
+	}
 	double f = 0.0;
+	int k = 0;
 	for (const Step &s : m_Program[0]) {
-		if (tag.empty() || s.tag == tag) f += s.flops;
+		if (tag.empty() || s.tag == tag) {
+			if (only < 0 || k == only) f += s.flops;
+			++k;
+		}
 	}
 	return f;
 }
 
-double Engine::timeSteps(const std::string &tag, int iters, int *launches) {
+double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
 	DeviceGuard g(m_Device);
+	// "flow#3" = only the 4th step tagged "flow" (per-layer timing)
+	std::string tag = tagSpec;
+	int only = -1;
+	const std::size_t hash = tagSpec.find('#');
+	if (hash != std::string::npos) {
+		tag = tagSpec.substr(0, hash);
+		only = std::atoi(tagSpec.c_str() + hash + 1);
+	}
 	std::vector<const Step *> steps;
+	int k = 0;
 	for (const Step &s : m_Program[m_Idx]) {
-		if (tag.empty() || s.tag == tag) steps.push_back(&s);
+		if (tag.empty() || s.tag == tag) {
+			if (only < 0 || k == only) steps.push_back(&s);
+			++k;
+		}
 	}
 	if (launches) *launches = static_cast<int>(steps.size());
 	if (steps.empty() || iters <= 0) return 0.0;

@@ -35,6 +35,9 @@ struct ConvParams {
 	int taps;    // 9 (3x3 "same") or 1 (1x1)
 	int relu;    // apply max(x, 0)
 	int outF32;  // store f32 instead of the 16-bit type
+	// 2x2 max-pool fused into the epilogue: out is [H/2][W/2][cout] (dense or pitched
+	// in POOLED pixels).  Needs rw == 2, even H and W, no residual, 16-bit output.
+	int pool;
 	// Row pitches in pixels (0 = dense, i.e. W).  The pointers address image
 	// pixel (0,0); a tensor kept in the zero-bordered tower layout (below) is
 	// passed as its interior origin plus its pitch.

@@ -33,6 +33,8 @@
 
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace ju {
 
 namespace {
@@ -93,14 +95,112 @@ __device__ __forceinline__ int swz(int q) {
 	else return (q >> 3) & 1;
 }
 
+// LDS -> register fragments of MFMA step s (tap s / KS, k-step s % KS) of a staged
+// channel chunk: A = kernel-ready weights, B = 32 pixels of each of the wave's rows.
+// asm reads: hipcc sinks plain LDS loads back in front of their MFMA (one LDS round
+// trip per MFMA); the consumer waits with convWait.  wAddr/iAddr are LDS byte
+// addresses of the stage's weights / tile.
 template <typename T, int TAPS, int CK, int NB, int RW>
+__device__ __forceinline__ void convFetch(unsigned wAddr, unsigned iAddr, int s, Vec8<T> (&a)[NB],
+    Vec8<T> (&b)[RW], int wave, int px, int hh) {
+	constexpr int HALO = (TAPS == 9) ? 1 : 0;
+	constexpr int IW = kTW + 2 * HALO;
+	constexpr int P = CK / 8;
+	constexpr int KS = CK / 16;
+	constexpr int COG = 32 * NB;
+	const int tap = s / KS, ks = s % KS;
+	const int dy = (TAPS == 9) ? tap / 3 : 0;
+	const int dx = (TAPS == 9) ? tap % 3 : 0;
+	// weights: one lane base + an immediate offset (two bases: the field is 16 bits)
+#pragma unroll
+	for (int nb = 0; nb < NB; ++nb) {
+		constexpr int kHi = 40960;
+		const int off = (((tap * KS + ks) * 2) * COG + nb * 32) << 4;
+		if (off < 65536) {
+			asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[nb]) : "v"(wAddr), "n"(off));
+		} else {
+			asm volatile("ds_read_b128 %0, %1 offset:%2"
+			             : "=v"(a[nb]) : "v"(wAddr + kHi), "n"(off - kHi));
+		}
+	}
+#pragma unroll
+	for (int rw = 0; rw < RW; ++rw) {
+		const int q = (wave * RW + rw + dy) * IW + px + dx;
+		const int c = ks * 2 + hh;
+		const unsigned addr = iAddr + q * (CK * 2) + ((c ^ swz<P>(q)) << 4);
+		asm volatile("ds_read_b128 %0, %1" : "=v"(b[rw]) : "v"(addr));
+	}
+}
+
+// s_waitcnt lgkmcnt(N) that the fragments' consumers cannot be hoisted over (the
+// registers are tied through the asm).
+template <int N, typename V, int NA, int NBB>
+__device__ __forceinline__ void convWait(V (&a)[NA], V (&b)[NBB]) {
+	static_assert(N >= 0 && N <= 15, "lgkmcnt range");
+#pragma unroll
+	for (int i = 0; i < NA; ++i) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[i]) : "n"(N));
+#pragma unroll
+	for (int i = 0; i < NBB; ++i) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(b[i]) : "n"(N));
+}
+
+// MFMAs of one staged channel chunk, software-pipelined over the TAPS*KS steps: the
+// fragments of step s+1 are read into the other register set before the MFMAs of
+// step s issue, so a wave does not sit out an LDS round trip per MFMA.
+template <typename T, int TAPS, int CK, int NB, int RW>
+__device__ __forceinline__ void convChunkMfma(const unsigned char *smW, const unsigned char *smI,
+    f32x16 (&acc)[NB][RW], int wave, int px, int hh) {
+	constexpr int S = TAPS * (CK / 16);
+	constexpr int COG = 32 * NB;
+	unsigned wAddr = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (const __attribute__((address_space(3))) unsigned char *)smW)) + ((hh * COG + px) << 4);
+	unsigned iAddr = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (const __attribute__((address_space(3))) unsigned char *)smI));
+	// opaque per call: otherwise every read address of every step is computed once,
+	// outside the chunk loop, and parked in ~100 VGPRs
+	asm volatile("" : "+v"(wAddr), "+v"(iAddr));
+	Vec8<T> a0[NB], b0[RW], a1[NB], b1[RW];
+	convFetch<T, TAPS, CK, NB, RW>(wAddr, iAddr, 0, a0, b0, wave, px, hh);
+#pragma unroll
+	for (int s = 0; s < S; s += 2) {
+		if (s + 1 < S) {
+			convFetch<T, TAPS, CK, NB, RW>(wAddr, iAddr, s + 1, a1, b1, wave, px, hh);
+			convWait<NB + RW>(a0, b0);
+		} else {
+			convWait<0>(a0, b0);
+		}
+#pragma unroll
+		for (int rw = 0; rw < RW; ++rw) {
+#pragma unroll
+			for (int nb = 0; nb < NB; ++nb) acc[nb][rw] = mfma32(a0[nb], b0[rw], acc[nb][rw]);
+		}
+		if (s + 1 < S) {
+			if (s + 2 < S) {
+				convFetch<T, TAPS, CK, NB, RW>(wAddr, iAddr, s + 2, a0, b0, wave, px, hh);
+				convWait<NB + RW>(a1, b1);
+			} else {
+				convWait<0>(a1, b1);
+			}
+#pragma unroll
+			for (int rw = 0; rw < RW; ++rw) {
+#pragma unroll
+				for (int nb = 0; nb < NB; ++nb) acc[nb][rw] = mfma32(a1[nb], b1[rw], acc[nb][rw]);
+			}
+		}
+	}
+}
+
+// DBUF (layers with several channel chunks, two stages must fit LDS): the global
+// loads of chunk c+1 are issued into registers before the MFMAs of chunk c and
+// written to the other LDS stage afterwards -- one barrier per chunk, memory
+// latency hidden behind the matrix cores.  Otherwise staging is synchronous and a
+// second resident workgroup provides the overlap.
+template <typename T, int TAPS, int CK, int NB, int RW, bool DBUF>
 __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 	constexpr int HALO = (TAPS == 9) ? 1 : 0;
 	constexpr int TH = 4 * RW;            // tile rows: 4 waves x RW rows each
 	constexpr int IW = kTW + 2 * HALO;    // staged tile incl. halo
 	constexpr int IH = TH + 2 * HALO;
 	constexpr int P = CK / 8;             // 16-B chunks per pixel
-	constexpr int KS = CK / 16;           // MFMA k-steps per tap
 	constexpr int COG = 32 * NB;          // couts per workgroup
 	constexpr int W_BYTES = TAPS * CK * COG * 2;
 
@@ -141,71 +241,159 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 		}
 	}
 
+	if constexpr (DBUF) {
+		constexpr int TILE_BYTES = IH * IW * CK * 2;
+		constexpr int STAGE = W_BYTES + TILE_BYTES;
+		constexpr int WN = W_BYTES / 16;
+		static_assert(WN % kConvThreads == 0, "weight chunk must split evenly over the threads");
+		constexpr int WITER = WN / kConvThreads;
+		constexpr int N = IH * IW * P;
+		constexpr int ITER = (N + kConvThreads - 1) / kConvThreads;
+		// chunk-independent addressing of this thread's tile elements
+		int srcOff[ITER], dstOff[ITER];
+		bool inb[ITER];
+#pragma unroll
+		for (int k = 0; k < ITER; ++k) {
+			const int i = min(tid + k * kConvThreads, N - 1);
+			const int q = i / P;
+			const int c = i % P;
+			const int r = q / IW;
+			const int x = q - r * IW;
+			const int gy = ty0 - HALO + r;
+			const int gx = tx0 - HALO + x;
+			inb[k] = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+			const int cy = min(max(gy, 0), p.H - 1);
+			const int cx = min(max(gx, 0), p.W - 1);
+			srcOff[k] = (cy * inPitch + cx) * p.cin + c * 8;
+			dstOff[k] = (tid + k * kConvThreads < N) ? q * (CK * 2) + ((c ^ swz<P>(q)) << 4) : -1;
+		}
+		// it = -1 is the prologue (load + store chunk 0); iteration it loads chunk
+		// it+1 (clamped, so the loads are unconditional), computes chunk it, then
+		// parks the loaded registers in the other stage.
+		for (int it = -1; it < nCC; ++it) {
+			const int lc = min(it + 1, nCC - 1);
+			// (named scalars, not an array: hipcc leaves a weight-prefetch array in
+			// scratch memory once the asm-scheduled MFMA section sits between its
+			// loads and its LDS stores)
+			static_assert(WITER == 9, "double-buffered staging is written for 64x32 weight chunks");
+			uint4 iv[ITER];
+			const uint4 *wsrc = reinterpret_cast<const uint4 *>(
+			    wgt + (size_t)(cog * nCC + lc) * (TAPS * CK * COG)) + tid;
+			const uint4 w0 = wsrc[0 * kConvThreads], w1 = wsrc[1 * kConvThreads],
+			            w2 = wsrc[2 * kConvThreads], w3 = wsrc[3 * kConvThreads],
+			            w4 = wsrc[4 * kConvThreads], w5 = wsrc[5 * kConvThreads],
+			            w6 = wsrc[6 * kConvThreads], w7 = wsrc[7 * kConvThreads],
+			            w8 = wsrc[8 * kConvThreads];
+#pragma unroll
+			for (int k = 0; k < ITER; ++k) {
+				iv[k] = *reinterpret_cast<const uint4 *>(in + srcOff[k] + lc * CK);
+			}
+			if (it >= 0) {
+				const unsigned char *cw = smem + (it & 1) * STAGE;
+				convChunkMfma<T, TAPS, CK, NB, RW>(cw, cw + W_BYTES, acc, wave, px, hh);
+			}
+			if (it + 1 < nCC) {
+				unsigned char *sw = smem + ((it + 1) & 1) * STAGE;
+				uint4 *wdst = reinterpret_cast<uint4 *>(sw) + tid;
+				wdst[0 * kConvThreads] = w0;
+				wdst[1 * kConvThreads] = w1;
+				wdst[2 * kConvThreads] = w2;
+				wdst[3 * kConvThreads] = w3;
+				wdst[4 * kConvThreads] = w4;
+				wdst[5 * kConvThreads] = w5;
+				wdst[6 * kConvThreads] = w6;
+				wdst[7 * kConvThreads] = w7;
+				wdst[8 * kConvThreads] = w8;
+#pragma unroll
+				for (int k = 0; k < ITER; ++k) {
+					// zero padding applied here, not at the load: a select right after
+					// the load would wait for it in front of the MFMAs
+					if (dstOff[k] >= 0) {
+						*reinterpret_cast<uint4 *>(sw + W_BYTES + dstOff[k]) =
+						    inb[k] ? iv[k] : make_uint4(0, 0, 0, 0);
+					}
+				}
+			}
+			__syncthreads();
+		}
+	} else {
 	for (int cc = 0; cc < nCC; ++cc) {
-		if (cc > 0) __syncthreads();
-		// ---- stage the weight chunk (already in fragment order) ----
-		{
-			const uint4 *src = reinterpret_cast<const uint4 *>(
-			    wgt + (size_t)(cog * nCC + cc) * (TAPS * CK * COG));
-			uint4 *dst = reinterpret_cast<uint4 *>(smW);
+			if (cc > 0) __syncthreads();
+			// ---- stage the weight chunk (already in fragment order) ----
+			{
+				const uint4 *src = reinterpret_cast<const uint4 *>(
+				    wgt + (size_t)(cog * nCC + cc) * (TAPS * CK * COG));
+				uint4 *dst = reinterpret_cast<uint4 *>(smW);
 #pragma unroll 6
-			for (int i = tid; i < W_BYTES / 16; i += kConvThreads) dst[i] = src[i];
-		}
-		// ---- stage the input tile (+halo), zero outside the image ----
-		// Loads are issued unconditionally on clamped coordinates and zeroed by a
-		// select: a load under `if (in bounds)` makes hipcc wait vmcnt(0) per element,
-		// i.e. one serial memory round trip per 16 bytes per thread.
-		{
-			constexpr int N = IH * IW * P;
-			constexpr int ITER = (N + kConvThreads - 1) / kConvThreads;
-			uint4 v[ITER];
-			int dstOff[ITER];
-#pragma unroll
-			for (int k = 0; k < ITER; ++k) {
-				const int i = min(tid + k * kConvThreads, N - 1);
-				const int q = i / P;
-				const int c = i % P;
-				const int r = q / IW;
-				const int x = q - r * IW;
-				const int gy = ty0 - HALO + r;
-				const int gx = tx0 - HALO + x;
-				const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-				const int cy = min(max(gy, 0), p.H - 1);
-				const int cx = min(max(gx, 0), p.W - 1);
-				v[k] = *reinterpret_cast<const uint4 *>(
-				    in + ((size_t)cy * inPitch + cx) * p.cin + cc * CK + c * 8);
-				if (!inb) v[k] = make_uint4(0, 0, 0, 0);
-				dstOff[k] = (tid + k * kConvThreads < N) ? q * (CK * 2) + ((c ^ swz<P>(q)) << 4) : -1;
+				for (int i = tid; i < W_BYTES / 16; i += kConvThreads) dst[i] = src[i];
 			}
+			// ---- stage the input tile (+halo), zero outside the image ----
+			// Loads are issued unconditionally on clamped coordinates and zeroed by a
+			// select: a load under `if (in bounds)` makes hipcc wait vmcnt(0) per element,
+			// i.e. one serial memory round trip per 16 bytes per thread.
+			{
+				constexpr int N = IH * IW * P;
+				constexpr int ITER = (N + kConvThreads - 1) / kConvThreads;
+				uint4 v[ITER];
+				int dstOff[ITER];
 #pragma unroll
-			for (int k = 0; k < ITER; ++k) {
-				if (dstOff[k] >= 0) *reinterpret_cast<uint4 *>(smI + dstOff[k]) = v[k];
-			}
-		}
-		__syncthreads();
-		// ---- MFMA over taps x k-steps ----
-#pragma unroll
-		for (int tap = 0; tap < TAPS; ++tap) {
-			const int dy = (TAPS == 9) ? tap / 3 : 0;
-			const int dx = (TAPS == 9) ? tap % 3 : 0;
-#pragma unroll
-			for (int ks = 0; ks < KS; ++ks) {
-				Vec8<T> a[NB];
-#pragma unroll
-				for (int nb = 0; nb < NB; ++nb) {
-					a[nb] = *reinterpret_cast<const Vec8<T> *>(
-					    smW + ((((tap * KS + ks) * 2 + hh) * COG + nb * 32 + px) << 4));
+				for (int k = 0; k < ITER; ++k) {
+					const int i = min(tid + k * kConvThreads, N - 1);
+					const int q = i / P;
+					const int c = i % P;
+					const int r = q / IW;
+					const int x = q - r * IW;
+					const int gy = ty0 - HALO + r;
+					const int gx = tx0 - HALO + x;
+					const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+					const int cy = min(max(gy, 0), p.H - 1);
+					const int cx = min(max(gx, 0), p.W - 1);
+					v[k] = *reinterpret_cast<const uint4 *>(
+					    in + ((size_t)cy * inPitch + cx) * p.cin + cc * CK + c * 8);
+					if (!inb) v[k] = make_uint4(0, 0, 0, 0);
+					dstOff[k] = (tid + k * kConvThreads < N) ? q * (CK * 2) + ((c ^ swz<P>(q)) << 4) : -1;
 				}
 #pragma unroll
-				for (int rw = 0; rw < RW; ++rw) {
-					const int q = (wave * RW + rw + dy) * IW + px + dx;
-					const int c = ks * 2 + hh;
-					const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(
-					    smI + q * (CK * 2) + ((c ^ swz<P>(q)) << 4));
-#pragma unroll
-					for (int nb = 0; nb < NB; ++nb) acc[nb][rw] = mfma32(a[nb], b, acc[nb][rw]);
+				for (int k = 0; k < ITER; ++k) {
+					if (dstOff[k] >= 0) *reinterpret_cast<uint4 *>(smI + dstOff[k]) = v[k];
 				}
 			}
+			__syncthreads();
+			convChunkMfma<T, TAPS, CK, NB, RW>(smW, smI, acc, wave, px, hh);
+		}
+	}
+
+	// ---- epilogue with the 2x2 max-pool folded in (flow encoder, models.py:377-410):
+	// a wave owns rows 2j, 2j+1 (vertical max inside the lane), the horizontal
+	// partner pixel sits in the neighbouring lane.  ReLU commutes with max.  Both
+	// lanes of a pair end up with the pooled pixel; each stores half its channels.
+	if constexpr (RW == 2) {
+		if (p.pool) {
+			const int gx = tx0 + px;
+			const int gy = ty0 + wave * 2;
+			const bool live = gy < p.H && gx < p.W;  // H, W even: the partner row/pixel exists too
+			const int poolPitch = p.outPitch ? p.outPitch : p.W / 2;
+			T *out = static_cast<T *>(p.out) +
+			         ((size_t)(gy >> 1) * poolPitch + (gx >> 1)) * p.cout + cog * COG;
+#pragma unroll
+			for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					float v[4];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						float m = fmaxf(acc[nb][0][4 * g + i], acc[nb][1][4 * g + i]);
+						m = fmaxf(m, __shfl_xor(m, 1));
+						v[i] = p.relu ? fmaxf(m, 0.0f) : m;
+					}
+					if (live && (g >> 1) == (px & 1)) {
+						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
+						    static_cast<T>(v[3])};
+						*reinterpret_cast<Vec4<T> *>(out + nb * 32 + 8 * g + 4 * hh) = o;
+					}
+				}
+			}
+			return;
 		}
 	}
 
@@ -255,10 +443,11 @@ constexpr int convLdsBytes() {
 	return TAPS * CK * 32 * NB * 2 + (4 * RW + 2 * HALO) * (kTW + 2 * HALO) * CK * 2;
 }
 
-template <typename T, int TAPS, int CK, int NB, int RW>
+template <typename T, int TAPS, int CK, int NB, int RW, bool DBUF = false>
 void launchConvInst(const ConvParams &p, hipStream_t stream) {
-	constexpr int lds = convLdsBytes<TAPS, CK, NB, RW>();
-	auto kern = conv_mfma_kernel<T, TAPS, CK, NB, RW>;
+	constexpr int lds = convLdsBytes<TAPS, CK, NB, RW>() * (DBUF ? 2 : 1);
+	static_assert(lds <= 160 * 1024, "conv stages do not fit LDS");
+	auto kern = conv_mfma_kernel<T, TAPS, CK, NB, RW, DBUF>;
 	static bool attrSet = false;  // first launch happens before any graph capture
 	if (!attrSet) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -280,6 +469,31 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 	if (p.cin % 16 != 0 || p.cout % 32 != 0 || (p.nb != 1 && p.nb != 2) ||
 	    (p.rw != 1 && p.rw != 2) || p.cout % (32 * p.nb) != 0) {
 		throw std::invalid_argument("conv: cin must be a multiple of 16, cout of 32*nb");
+	}
+	if (p.pool && (p.rw != 2 || p.H % 2 || p.W % 2 || p.res != nullptr || p.outF32)) {
+		throw std::invalid_argument("conv: fused max-pool needs rw = 2, even H and W, 16-bit output");
+	}
+	// Several 64-channel chunks and a launch that leaves at most one workgroup per CU
+	// (the coarsest flow levels): double-buffered staging, the only way such a
+	// workgroup overlaps its loads with its MFMAs.  Larger launches keep the
+	// single-stage kernel: two co-resident workgroups hide each other's latency and
+	// the doubled LDS would cost a second round of workgroups.  (JU_CONV_DBUF=0/1
+	// forces it off/on for A/B timing.)
+	static const char *dbufEnv = std::getenv("JU_CONV_DBUF");
+	static const int cus = [] {
+		int dev = 0, n = 256;
+		if (hipGetDevice(&dev) == hipSuccess) {
+			(void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+		}
+		return n;
+	}();
+	const long wgs = (long)((p.W + kTW - 1) / kTW) * ((p.H + 4 * p.rw - 1) / (4 * p.rw)) *
+	                 (p.cout / (32 * p.nb));
+	bool dbuf = ck == 64 && p.cin > 64 && p.nb == 1 && p.taps == 9 && wgs <= cus;
+	if (dbufEnv) dbuf = ck == 64 && p.cin > 64 && p.nb == 1 && p.taps == 9 && dbufEnv[0] == '1';
+	if (dbuf) {
+		if (p.rw == 2) return launchConvInst<T, 9, 64, 1, 2, true>(p, stream);
+		return launchConvInst<T, 9, 64, 1, 1, true>(p, stream);
 	}
 #define JU_CONV_CASE(TAPS_, CK_)                                                   \
 	if (p.taps == TAPS_ && ck == CK_) {                                            \

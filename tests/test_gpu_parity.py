@@ -190,6 +190,12 @@ def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
     assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(first, split))
     rt5.close()
     monkeypatch.delenv("JU_TAIL")
+    monkeypatch.setenv("JU_POOL", "split")              # separate max-pool launches: rounding is
+    rt6 = R.Runtime(blob, 0, R.DTYPE_BF16)               # monotonic, so fusing it is bit-exact
+    unfused = [rt6.process_image(f).copy() for f in frames]
+    assert all(np.array_equal(a, b) for a, b in zip(first, unfused))
+    rt6.close()
+    monkeypatch.delenv("JU_POOL")
     monkeypatch.setenv("JU_NO_GRAPH", "1")              # eager launches == graph replay
     rt3 = R.Runtime(blob, 0, R.DTYPE_BF16)
     eager = [rt3.process_image(f).copy() for f in frames]
