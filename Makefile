@@ -14,11 +14,15 @@ OBJS       := $(addprefix $(OBJ)/,$(SRCS_CPP:.cpp=.o)) $(OBJ)/kernels.o
 
 all: $(OUT)/libJoshUpscale.so
 
-$(OBJ)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs.  The epilogues
+# consume every accumulator with VALU ops; in AGPR form each value first costs a
+# v_accvgpr_read (128 per layer and lane in the tower kernel, ~2 % of its time).
+KERNELFLAGS := -mllvm -amdgpu-mfma-vgpr-form
+$(OBJ)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h Makefile
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) -c $< -o $@
 
-$(OBJ)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/joshupscale_amd.h include/JoshUpscale/core.h
+$(OBJ)/%.o: $(CSRC)/%.cpp Makefile $(wildcard $(CSRC)/*.h) include/joshupscale_amd.h include/JoshUpscale/core.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) -x hip $(HIPFLAGS) -c $< -o $@
 

@@ -49,6 +49,10 @@ class JoshUpscaleError(RuntimeError):
 
 
 def library_path() -> str:
+    """In-tree HIP library; ``JU_LIBRARY`` points at another build of it (A/B timing)."""
+    override = os.environ.get("JU_LIBRARY")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
 
 

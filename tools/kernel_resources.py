@@ -12,7 +12,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "joshupscale_amd/
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
        f"-I{root}/include", f"-I{root}/joshupscale_amd/csrc", "-c", src, "-o", "/dev/null",
-       "-Rpass-analysis=kernel-resource-usage"]
+       "-Rpass-analysis=kernel-resource-usage", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in out.splitlines():
