@@ -112,6 +112,16 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     elapsed = jdist.max_over_ranks(elapsed, device)
 
+    # per-frame latency of the synchronous boundary call (outside the timed region):
+    # what a caller blocked in processImage sees; SURVEY 8d config 3 asks for p50/p99
+    lat = []
+    if rank == 0:
+        for i in range(min(args.steps, 200)):
+            t1 = time.perf_counter()
+            step(i)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+
     result = None
     if rank == 0:
         fps = world * args.steps / elapsed
@@ -142,6 +152,8 @@ def main() -> int:
                 "weights": "seeded random-init (seed 42), reference default architecture",
                 "streams": world, "parallelism": f"replicas x{world}",
                 "boundary": "ju_process (synchronous processImage)",
+                "latency_ms": {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
+                               "max": lat[-1], "frames": len(lat)},
                 "gflop_per_frame": total_flops / 1e9,
                 "whole_frame_tflops": total_flops * fps / world / 1e12,
             },

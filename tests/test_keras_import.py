@@ -1,0 +1,72 @@
+"""Keras-variable -> container mapping (joshupscale_amd/keras_import.py): pure numpy,
+no Keras needed.  The Keras-facing shim (tools/export_jupw_from_keras.py) only
+collects ``layer.get_weights()`` by layer name and calls this mapping."""
+import numpy as np
+import pytest
+
+from joshupscale_amd import keras_import as K
+from joshupscale_amd import model_file as M
+
+
+def small(flow_arch="autoencoder"):
+    if flow_arch == "autoencoder":
+        return M.ModelConfig(frame_height=30, frame_width=48, flow_filters=(32, 64, 32),
+                             gen_blocks=2, flow_pad_factor=2)
+    return M.ModelConfig(frame_height=30, frame_width=48, flow_arch="resnet", flow_res_blocks=2,
+                         flow_res_filters=32, gen_blocks=3, flow_pad_factor=0)
+
+
+def test_name_map_follows_the_reference_layer_names():
+    assert K.container_name("generator", "block_12_conv_2") == "generator/block_12/conv_2"
+    assert K.container_name("generator", "conv_trans_1") == "generator/conv_trans_1"
+    assert K.container_name("flow", "block_3_bn_1") == "flow/block_3/bn_1"
+    assert K.container_name("flow", "conv_2") == "flow/conv_2"
+    assert K.keras_layer_name("generator/block_7/bn_2") == ("generator", "block_7_bn_2")
+
+
+@pytest.mark.parametrize("arch", ["autoencoder", "resnet"])
+def test_round_trip_through_keras_layer_dicts(arch):
+    cfg = small(arch)
+    w = M.make_seeded_weights(cfg, seed=5)
+    gen, flow = K.layers_from_container(w)
+    # Keras order: Conv2D [kernel(, bias)], BatchNormalization [gamma, beta, mean, variance]
+    assert [a.shape for a in gen["block_1_bn_1"]] == [(64,)] * 4
+    assert np.array_equal(gen["block_1_bn_1"][2], w["generator/block_1/bn_1/moving_mean"])
+    assert len(gen["conv_1"]) == 1 and len(gen["conv_trans_2"]) == 2 and len(flow["conv_2"]) == 2
+    base = M.ModelConfig(frame_height=30, frame_width=48, flow_pad_factor=cfg.flow_pad_factor)
+    cfg2, w2 = K.container_weights(gen, flow, base)
+    assert cfg2 == cfg                       # architecture recovered from the shapes
+    assert set(w2) == set(w)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+    # and the container built from it is byte-identical
+    assert M.serialize(cfg2, {k: w2[k] for k in w}) == M.serialize(cfg, w)
+
+
+def test_default_architecture_is_recognised():
+    cfg = M.PRESETS["psp-quality"]
+    w = M.make_seeded_weights(cfg)
+    gen, flow = K.layers_from_container(w)
+    cfg2, _ = K.container_weights(gen, flow, M.ModelConfig())
+    assert cfg2.flow_filters == (32, 64, 128, 256, 128, 64, 32) and cfg2.gen_blocks == 24
+    assert cfg2.num_flow_inputs == 4 and cfg2.flow_arch == "autoencoder"
+
+
+def test_errors_name_the_offending_layer():
+    cfg = small()
+    gen, flow = K.layers_from_container(M.make_seeded_weights(cfg))
+    bad = dict(gen)
+    bad["block_2_bn_1"] = bad["block_2_bn_1"][:2]            # BN without moving statistics
+    with pytest.raises(ValueError, match="block_2/bn_1"):
+        K.container_weights(bad, flow, cfg)
+    bad = dict(gen)
+    bad["conv_trans_1"] = [np.transpose(gen["conv_trans_1"][0], (0, 1, 3, 2))]   # [kh,kw,cin,cout]
+    with pytest.raises(ValueError, match="conv_trans_1"):
+        K.container_weights(bad, flow, cfg)
+    bad = dict(flow)
+    del bad["block_2_conv_2"]
+    with pytest.raises(KeyError, match="block_2_conv_2"):
+        K.container_weights(gen, bad, cfg)
+    bad = dict(gen)
+    bad["conv_1"] = list(gen["conv_1"]) + [np.zeros(64, np.float32)]            # use_bias=True
+    with pytest.raises(ValueError, match="generator/conv_1"):
+        K.container_weights(bad, flow, cfg)
