@@ -297,9 +297,10 @@ void Engine::buildProgram(int set) {
 	{
 		const float *flow = static_cast<const float *>(T("flow"));
 		void *genIn = T("gen_in");
+		void *preWarp = c.temporalStrength > 0.0f ? T("pre_warp") : nullptr;
 		prog.push_back({"warp", 0.0, [=](hipStream_t s) {
 			                launchWarpPack(dt, stateIn, flow, io->in, io->inStride, genIn, H, W, PW,
-			                    padTop, padLeft, sums, s);
+			                    padTop, padLeft, sums, preWarp, s);
 		                }});
 	}
 	// ---- generator ----
@@ -374,6 +375,17 @@ void Engine::buildProgram(int set) {
 		prog.push_back({"tail", 2.0 * (2 * H) * (2 * W) * 4 * 32 * 3, [=](hipStream_t s) {
 			                launchTail(dt, y, w2, b2, io->in, io->inStride, stateOut, io->out,
 			                    io->outStride, H, W, sums, s);
+		                }});
+	}
+	// ---- optional output filter (frame_moving_avg.py): replaces the clip output for
+	// both of its consumers, the u8 frame and the fed-back state ----
+	if (c.temporalStrength > 0.0f) {
+		const void *preWarp = T("pre_warp");
+		unsigned long long *acc = m_TemporalAcc.as<unsigned long long>();
+		const float strength = c.temporalStrength, threshold = c.temporalThreshold;
+		prog.push_back({"temporal", 0.0, [=](hipStream_t s) {
+			                launchTemporalFilter(stateOut, preWarp, io->out, io->outStride, H, W, sums,
+			                    acc, strength, threshold, s);
 		                }});
 	}
 }
@@ -471,6 +483,10 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	}
 	addTensor("flow", plr * 32, true);
 	addTensor("gen_in", lr * 64);
+	if (c.temporalStrength > 0.0f) {
+		addTensor("pre_warp", lr * 16 * 4);  // f16 [4H][4W][4]
+		m_TemporalAcc = DeviceBuffer(8);
+	}
 	addTowerTensor("trunk_a", H, W, c.genFilters);
 	addTowerTensor("trunk_b", H, W, c.genFilters);
 	addTowerTensor("trunk_t", H, W, c.genFilters);

@@ -142,6 +142,7 @@ private:
 	std::map<std::string, Tensor> m_Tensors;
 	std::map<std::string, ConvWeights> m_Convs;
 	DeviceBuffer m_TailW2, m_TailB2, m_TailW2Frag;
+	DeviceBuffer m_TemporalAcc;  // 32.32 fixed-point sum of |gen - pre_warp| (temporal filter)
 	bool m_FusedPool = true;  // max-pool folded into the flow encoder's conv epilogues
 	bool m_FusedTail = true;  // JU_TAIL=split: convT1 as a conv launch + the VALU tail kernel
 	DeviceBuffer m_InStage, m_OutStage, m_RawStage;

@@ -166,9 +166,19 @@ void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C,
 // out   : generator input NHWC [H][W][64] in the packed channel order
 //         ch = i*16 + j*3 + c for the warped HR pixel (4h+i, 4w+j, c),
 //         ch 12,13,14 = current LR frame B,G,R, other spare slots zero.
+// preWarpOut (may be null): the warped previous output itself, f16 [4H][4W][4], for
+// the temporal filter below.
 void launchWarpPack(DType dt, const void *state, const float *flow,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *out, int H, int W, int PW,
-    int padTop, int padLeft, const unsigned *sums, hipStream_t stream);
+    int padTop, int padLeft, const unsigned *sums, void *preWarpOut, hipStream_t stream);
+
+// Temporal moving-average output filter with the global scene-cut gate of
+// scripts/inference/onnx/frame_moving_avg.py:146-302 (default mode).  state: the new
+// HR state written by the tail (f16 [4H][4W][4], generator output minus brightness),
+// rewritten in place together with the u8 frame; acc: 8 bytes of scratch.
+void launchTemporalFilter(void *state, const void *preWarp, std::uint8_t *outU8,
+    std::ptrdiff_t outStride, int H, int W, const unsigned *sums, unsigned long long *acc,
+    float strength, float threshold, hipStream_t stream);
 
 // ---- generator tail ---------------------------------------------------------
 // y     : [H][W][128] 16-bit = relu(BN(convT1)) with channel (a*2+b)*32 + o

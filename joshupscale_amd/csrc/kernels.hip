@@ -1603,7 +1603,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ state,
     const float *__restrict__ flow, const std::uint8_t *__restrict__ frame,
     std::ptrdiff_t frameStride, T *__restrict__ out, int H, int W, int PW, int padTop,
-    int padLeft, const unsigned *__restrict__ sums) {
+    int padLeft, const unsigned *__restrict__ sums, f16 *__restrict__ preWarpOut) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= H * W * 4) return;
 	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));  // pre_warp += b (models.py:803)
@@ -1619,6 +1619,7 @@ __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ 
 	const f32x4 f1 = *reinterpret_cast<const f32x4 *>(fp + 4);
 	const float fl[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
 	T o[16];
+	Vec4<f16> pw[4];  // the same 4 HR pixels in [4H][4W][4] f16 for the temporal filter
 	const int Y = 4 * h + i;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
@@ -1643,8 +1644,16 @@ __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ 
 			const float d = static_cast<float>(bl[c]), e = static_cast<float>(br[c]);
 			const float top = ax * (b - a) + a;
 			const float bot = ax * (e - d) + d;
-			o[j * 3 + c] = static_cast<T>(ay * (bot - top) + top + bright);
+			const float v = ay * (bot - top) + top + bright;
+			o[j * 3 + c] = static_cast<T>(v);
+			pw[j][c] = static_cast<f16>(v);
 		}
+		pw[j][3] = static_cast<f16>(0.f);
+	}
+	if (preWarpOut != nullptr) {
+		f16 *d = preWarpOut + ((size_t)Y * WW + 4 * w) * 4;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) *reinterpret_cast<Vec4<f16> *>(d + 4 * j) = pw[j];
 	}
 	float l0 = 0.f, l1 = 0.f, l2 = 0.f;
 	if (i == 0) {
@@ -1668,6 +1677,69 @@ __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ 
 	T *dst = out + (size_t)pix * 64 + i * 16;
 	*reinterpret_cast<Vec8<T> *>(dst) = o0;
 	*reinterpret_cast<Vec8<T> *>(dst + 8) = o1;
+}
+
+// ---------------------------------------------------------------------------
+// temporal moving-average output filter (scripts/inference/onnx/frame_moving_avg.py
+// :146-302, its default mode: global L1 scene-cut gate with a sign function)
+// ---------------------------------------------------------------------------
+// Runs after the tail: `state` holds gen - b (f16, b = brightness scalar or 0),
+// `preWarp` the warped previous output (+ b).  Pass 1 sums |gen - pre_warp| over
+// every element into a 32.32 fixed-point accumulator (integer atomics: the result
+// does not depend on the order, so the gate is deterministic); pass 2 blends and
+// rewrites the state and the u8 frame unless the gate says "scene cut" (then the
+// generator output written by the tail already is the result).
+constexpr double kTemporalScale = 4294967296.0;  // 2^32
+
+__global__ __launch_bounds__(256) void temporal_reduce_kernel(const f16 *__restrict__ state,
+    const f16 *__restrict__ preWarp, size_t nPix, int lrPixels, const unsigned *__restrict__ sums,
+    unsigned long long *__restrict__ acc) {
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(lrPixels));
+	float s = 0.f;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nPix; i += (size_t)gridDim.x * 256) {
+		const Vec4<f16> g = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
+		const Vec4<f16> q = *reinterpret_cast<const Vec4<f16> *>(preWarp + i * 4);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			s += fabsf(static_cast<float>(g[c]) + bright - static_cast<float>(q[c]));
+		}
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+	if ((threadIdx.x & 63) == 0) {
+		atomicAdd(acc, static_cast<unsigned long long>(static_cast<double>(s) * kTemporalScale + 0.5));
+	}
+}
+
+__global__ __launch_bounds__(256) void temporal_blend_kernel(f16 *__restrict__ state,
+    const f16 *__restrict__ preWarp, std::uint8_t *__restrict__ outU8, std::ptrdiff_t outStride,
+    int HH, int WW, int lrPixels, const unsigned *__restrict__ sums,
+    const unsigned long long *__restrict__ acc, float strength, float threshold) {
+	const double mean = static_cast<double>(*acc) / kTemporalScale / (3.0 * HH * WW);
+	const double d = mean - static_cast<double>(threshold);
+	const float c = d > 0.0 ? 1.0f : (d < 0.0 ? -1.0f : 0.0f);  // Sign (:229-232)
+	if (c > 0.0f) return;                                        // scene cut: out = gen
+	const float half = 0.5f * strength;
+	const float m1 = half - c * half;         // weight of pre_warp (:272-279)
+	const float m2 = c * half + 1.0f - half;  // weight of the generator output (:280-285)
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(lrPixels));
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= (size_t)HH * WW) return;
+	const int y = static_cast<int>(i / WW), x = static_cast<int>(i - (size_t)y * WW);
+	const Vec4<f16> g = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
+	const Vec4<f16> q = *reinterpret_cast<const Vec4<f16> *>(preWarp + i * 4);
+	Vec4<f16> st;
+	unsigned packed = 0;
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		const float r = static_cast<float>(q[ch]) * m1 + (static_cast<float>(g[ch]) + bright) * m2;
+		st[ch] = static_cast<f16>(r - bright);
+		const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);  // postprocess, truncating
+		packed |= (u & 0xff) << (8 * ch);
+	}
+	st[3] = static_cast<f16>(0.f);
+	*reinterpret_cast<Vec4<f16> *>(state + i * 4) = st;
+	*reinterpret_cast<unsigned *>(outU8 + y * outStride + (std::ptrdiff_t)x * 4) = packed;
 }
 
 // ---------------------------------------------------------------------------
@@ -2130,18 +2202,34 @@ void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, h
 
 void launchWarpPack(DType dt, const void *state, const float *flow, const std::uint8_t *frame,
     std::ptrdiff_t frameStride, void *out, int H, int W, int PW, int padTop, int padLeft,
-    const unsigned *sums, hipStream_t stream) {
+    const unsigned *sums, void *preWarpOut, hipStream_t stream) {
 	const unsigned nb = blocksFor((size_t)H * W * 4);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(warp_pack_kernel<f16>, dim3(nb), dim3(256), 0, stream,
 		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<f16 *>(out), H,
-		    W, PW, padTop, padLeft, sums);
+		    W, PW, padTop, padLeft, sums, static_cast<f16 *>(preWarpOut));
 	} else {
 		hipLaunchKernelGGL(warp_pack_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
 		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<bf16 *>(out), H,
-		    W, PW, padTop, padLeft, sums);
+		    W, PW, padTop, padLeft, sums, static_cast<f16 *>(preWarpOut));
 	}
 	hipCheckLaunch("warp_pack");
+}
+
+void launchTemporalFilter(void *state, const void *preWarp, std::uint8_t *outU8,
+    std::ptrdiff_t outStride, int H, int W, const unsigned *sums, unsigned long long *acc,
+    float strength, float threshold, hipStream_t stream) {
+	const int HH = 4 * H, WW = 4 * W;
+	const size_t nPix = (size_t)HH * WW;
+	hipError_t e = hipMemsetAsync(acc, 0, sizeof(unsigned long long), stream);
+	if (e != hipSuccess) throw std::runtime_error(std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+	hipLaunchKernelGGL(temporal_reduce_kernel, dim3(2048), dim3(256), 0, stream,
+	    static_cast<const f16 *>(state), static_cast<const f16 *>(preWarp), nPix, H * W, sums, acc);
+	hipCheckLaunch("temporal_reduce");
+	hipLaunchKernelGGL(temporal_blend_kernel, dim3(blocksFor(nPix)), dim3(256), 0, stream,
+	    static_cast<f16 *>(state), static_cast<const f16 *>(preWarp), outU8, outStride, HH, WW,
+	    H * W, sums, acc, strength, threshold);
+	hipCheckLaunch("temporal_blend");
 }
 
 void launchTail(DType dt, const void *y, const float *w2, const float *b2,

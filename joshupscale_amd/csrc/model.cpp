@@ -61,6 +61,12 @@ ModelFile::ModelFile(const void *blob, std::size_t size) {
 	c.bnEps = readLE<float>(b + 96);
 	c.computeDtype = u32(100);
 	const int nTensors = u32(104);
+	c.temporalStrength = readLE<float>(b + 108);
+	c.temporalThreshold = readLE<float>(b + 112);
+	if (!(c.temporalStrength >= 0.0f && c.temporalStrength <= 1.0f) ||
+	    !(c.temporalThreshold >= 0.0f && c.temporalThreshold <= 1.0f)) {
+		throw std::invalid_argument("Invalid model: temporal filter strength/threshold must be in [0, 1]");
+	}
 	if (scale != 4) throw std::invalid_argument("Invalid model: scale must be 4");
 	if (c.frameHeight < 2 || c.frameWidth < 2 || c.frameHeight > 8192 || c.frameWidth > 8192) {
 		throw std::invalid_argument("Invalid model: unsupported frame size");

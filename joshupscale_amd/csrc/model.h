@@ -29,6 +29,9 @@ struct ModelConfig {
 	std::vector<int> flowFilters;
 	float bnEps = 1e-3f;
 	int computeDtype = kBF16;
+	// temporal moving-average output filter (frame_moving_avg.py); strength 0 = off
+	float temporalStrength = 0.0f;
+	float temporalThreshold = 0.1f;
 
 	// reference scripts/training/models.py:735-744
 	int paddedHeight() const {

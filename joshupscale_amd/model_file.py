@@ -25,7 +25,8 @@ Layout (all little endian):
     96  f32      bn_eps
     100 u32      compute_dtype hint (0 fp16, 1 bf16)
     104 u32      n_tensors
-    108 u32      reserved[5]                        -> header_bytes = 128
+    108 f32      temporal_strength (0 = filter off), temporal_threshold
+    116 u32      reserved[3]                        -> header_bytes = 128
     table: n_tensors x { char name[92]; u32 ndim; u32 dims[4]; u64 offset;
                          u64 count }                (128 bytes each)
     data:  float32, each tensor 64-byte aligned, offsets from file start
@@ -66,6 +67,12 @@ class ModelConfig:
     normalize_brightness: bool = False
     bn_eps: float = 1e-3
     compute_dtype: int = DTYPE_BF16
+    # Temporal moving-average output filter with a global scene-cut gate, the default
+    # mode (window 0, sign gate, L1) of scripts/inference/onnx/frame_moving_avg.py:
+    # out = pre_warp*(s/2)(1-c) + gen*(1 - s/2 + c*s/2), c = sign(mean|gen-pre_warp| - t).
+    # strength 0 = off (the plain model).
+    temporal_strength: float = 0.0
+    temporal_threshold: float = 0.1
 
     @property
     def padded_height(self) -> int:
@@ -178,13 +185,16 @@ def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray]) -> bytes:
     if len(cfg.flow_filters) > 8:
         raise ValueError("at most 8 flow filters")
     hdr = MAGIC + struct.pack(
-        "<2I4I4I4I8IfII5I", VERSION, HEADER_BYTES,
+        "<2I4I4I4I8IfIIff3I", VERSION, HEADER_BYTES,
         cfg.frame_height, cfg.frame_width, 4, cfg.num_flow_inputs,
         FLOW_ARCH[cfg.flow_arch], cfg.flow_pad_factor,
         int(cfg.normalize_brightness), cfg.gen_filters,
         cfg.gen_blocks, cfg.flow_res_filters, cfg.flow_res_blocks,
         len(cfg.flow_filters), *ff, cfg.bn_eps, cfg.compute_dtype, len(names),
-        0, 0, 0, 0, 0)
+        # (filter off: both words stay zero, the file is byte-identical to one written
+        # before the filter existed)
+        cfg.temporal_strength, cfg.temporal_threshold if cfg.temporal_strength > 0 else 0.0,
+        0, 0, 0)
     assert len(hdr) == HEADER_BYTES, len(hdr)
     off = HEADER_BYTES + ENTRY_BYTES * len(names)
     off = (off + 63) // 64 * 64
@@ -210,17 +220,18 @@ def deserialize(blob: bytes) -> Tuple[ModelConfig, Dict[str, np.ndarray]]:
     """Parse container bytes (the Python twin of csrc/model.cpp)."""
     if len(blob) < HEADER_BYTES or blob[:8] != MAGIC:
         raise ValueError("not a JoshUpscale-AMD model container")
-    vals = struct.unpack_from("<2I4I4I4I8IfII", blob, 8)
+    vals = struct.unpack_from("<2I4I4I4I8IfIIff", blob, 8)
     version, header_bytes = vals[0], vals[1]
     if version != VERSION:
         raise ValueError(f"unsupported container version {version}")
     (fh, fw, scale, nfi, arch, pad, nb, gf, gb, frf, frb, nff) = vals[2:14]
     ff = vals[14:22]
-    eps, cdt, nt = vals[22:25]
+    eps, cdt, nt, ts, tt = vals[22:27]
     if scale != 4:
         raise ValueError("scale must be 4")
     cfg = ModelConfig(fh, fw, nfi, FLOW_ARCH_INV[arch], tuple(ff[:nff]), frf,
-                      frb, pad, gf, gb, bool(nb), eps, cdt)
+                      frb, pad, gf, gb, bool(nb), eps, cdt, ts,
+                      tt if ts > 0 else ModelConfig.temporal_threshold)
     w = {}
     for i in range(nt):
         name, ndim, d0, d1, d2, d3, off, cnt = struct.unpack_from(

@@ -61,6 +61,10 @@ class ModelConfig:
     gen_blocks: int = 24
     normalize_brightness: bool = False
     bn_eps: float = 1e-3                    # keras BatchNormalization default
+    # output filter of scripts/inference/onnx/frame_moving_avg.py (defaults of that
+    # script: window 0, gain 0, L1, no limit, no luma weighting); strength 0 = absent
+    temporal_strength: float = 0.0
+    temporal_threshold: float = 0.1
 
     @property
     def padded_height(self) -> int:
@@ -367,6 +371,26 @@ class StepOutputs:
     state: State = field(repr=False, default=None)
 
 
+def temporal_filter(gen: np.ndarray, pre_warp: np.ndarray, strength: float,
+                    threshold: float) -> np.ndarray:
+    """Moving-average output filter with a global scene-cut gate: the graph that
+    scripts/inference/onnx/frame_moving_avg.py:146-302 splices in place of the
+    generator's clip output (its consumers -- postprocess AND the fed-back
+    ``output_raw`` -- see the filtered tensor), in that script's default mode
+    (``--window 0 --gain 0 --norm L1``, :163-206, :229-236, :272-296):
+
+        m     = mean(|gen - pre_warp|)                 over every element
+        c     = sign(m - threshold)                    -1 still scene, +1 scene cut
+        out   = pre_warp * (s/2 - c*s/2) + gen * (c*s/2 + 1 - s/2)
+
+    so a still scene blends ``s`` of the warped previous output into the new frame
+    and a scene cut passes the generator output through."""
+    m = np.mean(np.abs(gen - pre_warp))
+    c = np.sign(m - threshold)
+    half = strength / 2
+    return pre_warp * (half - c * half) + gen * (c * half + 1 - half)
+
+
 def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
                    cfg: ModelConfig, dtype=np.float64,
                    trace: Optional[dict] = None) -> StepOutputs:
@@ -402,6 +426,10 @@ def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
         pre_warp = pre_warp + brightness                          # :802-803
     _rec(trace, "flow_in", np.concatenate(frames, axis=2))
     output_raw = generator(cur, pre_warp, wts, cfg, trace)        # :804
+    if cfg.temporal_strength > 0:
+        _rec(trace, "temporal_mean", np.mean(np.abs(output_raw - pre_warp)))
+        output_raw = temporal_filter(output_raw, pre_warp, cfg.temporal_strength,
+                                     cfg.temporal_threshold)
     output = postprocess(output_raw)                              # :805-807
     if cfg.normalize_brightness:
         output_raw = output_raw - brightness                      # :809-810

@@ -331,7 +331,7 @@ void *juo_create(const void *blob, size_t size) {
 	for (int i = 0; i < m->n_ff && i < 8; ++i) m->ff[i] = (int)rd32(b + 64 + 4 * i);
 	memcpy(&m->eps, b + 96, 4);
 	m->n_tensors = (int)rd32(b + 104);
-	if (rd32(b + 40) != 0 || m->n_tensors > MAX_TENSORS) { /* normalize_brightness unsupported */
+	if (rd32(b + 40) != 0 || rd32(b + 108) != 0 || m->n_tensors > MAX_TENSORS) { /* normalize_brightness, temporal filter: unsupported */
 		free(m->blob);
 		free(m);
 		return NULL;

@@ -23,7 +23,9 @@ def oracle_config(cfg: M.ModelConfig) -> O.ModelConfig:
         flow_res_blocks=cfg.flow_res_blocks, flow_pad_factor=cfg.flow_pad_factor,
         gen_filters=cfg.gen_filters, gen_blocks=cfg.gen_blocks,
         normalize_brightness=cfg.normalize_brightness,
-        bn_eps=float(np.float32(cfg.bn_eps)))
+        bn_eps=float(np.float32(cfg.bn_eps)),
+        temporal_strength=float(np.float32(cfg.temporal_strength)),
+        temporal_threshold=float(np.float32(cfg.temporal_threshold)))
 
 
 def small_config(**kw) -> M.ModelConfig:

@@ -359,3 +359,44 @@ def test_normalize_brightness_branch(dtype):
         differs |= not np.array_equal(ref, plain.run(frames[t]))
     assert differs, "the brightness branch must change the result on this clip"
     rt.close()
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
+def test_temporal_filter_variant(dtype):
+    """Moving-average output filter with the global scene-cut gate (reference
+    scripts/inference/onnx/frame_moving_avg.py:146-302, default mode).  The clip is
+    still for 3 frames, cuts to unrelated content, and is still again, and the
+    threshold sits between the two regimes, so both sides of the gate run; the
+    filtered tensor is also the fed-back state."""
+    probe_cfg = small_config(temporal_strength=0.25, temporal_threshold=0.5)
+    wts = M.make_seeded_weights(probe_cfg)
+    a = M.synthetic_frames(3, 30, 48, seed=21, kind="smooth")
+    b = M.synthetic_frames(3, 30, 48, seed=22, kind="noise")
+    frames = np.concatenate([a[:1], a[:1], a[:1], b[:1], b[:1], b[:1]])
+    # gate statistics of this clip from the oracle (threshold 0.5 = never cut)
+    probe = O.Session(wts, oracle_config(probe_cfg))
+    means = []
+    for f in frames:
+        tr = {}
+        probe.run(f, trace=tr)
+        means.append(float(tr["temporal_mean"]))
+    still, cuts = sorted(means[1:3] + means[4:]), sorted([means[0], means[3]])
+    assert still[-1] * 1.3 < cuts[0], means          # the two regimes are well separated
+    thr = float(np.float32(0.5 * (still[-1] + cuts[0])))
+    cfg = small_config(temporal_strength=0.25, temporal_threshold=thr)
+    _, blob, rt = make(cfg, dtype)
+    sess = O.Session(wts, oracle_config(cfg))
+    plain = O.Session(wts, oracle_config(small_config()))
+    gate, differs = [], False
+    for t, f in enumerate(frames):
+        tr = {}
+        ref = sess.run(f, trace=tr)
+        gate.append(tr["temporal_mean"] > thr)
+        out = rt.process_image(f)
+        check_u8(out, ref, dtype, ("temporal", t))
+        state = rt.read_tensor("state").reshape(120, 192, 4)[..., :3]
+        assert err(state, sess.state.pre_gen)["max_abs"] <= TOL[dtype]["raw"]
+        differs |= not np.array_equal(ref, plain.run(f))
+    assert gate == [True, False, False, True, False, False], (gate, means, thr)
+    assert differs, "the filter must change the result on the still frames"
+    rt.close()

@@ -13,10 +13,22 @@ def test_roundtrip_all_presets():
         small = M.ModelConfig(**{**cfg.__dict__, "gen_blocks": 1, "flow_res_blocks": 1})
         w = M.make_seeded_weights(small)
         cfg2, w2 = M.deserialize(M.serialize(small, w))
-        assert cfg2.__dict__ | {"bn_eps": 0} == small.__dict__ | {"bn_eps": 0}, name
+        floats = {"bn_eps": 0, "temporal_strength": 0, "temporal_threshold": 0}  # f32 in the header
+        assert cfg2.__dict__ | floats == small.__dict__ | floats, name
         assert cfg2.bn_eps == pytest.approx(small.bn_eps)
+        assert cfg2.temporal_threshold == pytest.approx(small.temporal_threshold)
         assert list(w) == list(w2)
         assert all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+def test_temporal_filter_fields_live_in_the_reserved_words():
+    cfg = M.ModelConfig(gen_blocks=1, temporal_strength=0.25, temporal_threshold=0.05)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    assert struct.unpack_from("<2f3I", blob, 108) == (0.25, pytest.approx(0.05), 0, 0, 0)
+    cfg2, _ = M.deserialize(blob)
+    assert cfg2.temporal_strength == 0.25 and cfg2.temporal_threshold == pytest.approx(0.05)
+    plain = M.serialize(M.ModelConfig(gen_blocks=1), M.make_seeded_weights(cfg))
+    assert struct.unpack_from("<f", plain, 108) == (0.0,)      # filter off = a version-1 file as before
 
 
 def test_header_layout_and_alignment():

@@ -143,3 +143,21 @@ def test_state_shift_register_and_padding():
 def test_macs_match_survey():
     m = O.macs_per_frame(O.ModelConfig())
     assert m["generator"] == 234391449600 and m["flow"] == 17898209280
+
+
+def test_temporal_filter_gate_and_weights():
+    """frame_moving_avg.py default mode: still scene blends `strength` of the warped
+    previous output in, a scene cut passes the generator output through."""
+    rng = np.random.default_rng(3)
+    gen = rng.uniform(-0.5, 0.5, (8, 12, 3))
+    near = gen + rng.uniform(-0.02, 0.02, gen.shape)          # mean |diff| = 0.01
+    far = gen + np.where(rng.random(gen.shape) < 0.5, 0.4, -0.4)  # mean |diff| = 0.4
+    s = 0.25
+    still = O.temporal_filter(gen, near, s, 0.1)
+    assert np.allclose(still, s * near + (1 - s) * gen, atol=1e-15)
+    cut = O.temporal_filter(gen, far, s, 0.1)
+    assert np.array_equal(cut, gen)
+    # exactly at the threshold the sign is 0: weights s/2 and 1 - s/2
+    pw = gen + 0.125
+    edge = O.temporal_filter(gen, pw, s, float(np.mean(np.abs(gen - pw))))
+    assert np.allclose(edge, (s / 2) * pw + (1 - s / 2) * gen, atol=1e-15)
