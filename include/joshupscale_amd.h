@@ -78,6 +78,15 @@ JU_API int ju_create(int device_id, const char *model_path, ju_runtime **out_run
 JU_API int ju_create_from_memory(int device_id, const void *model_bytes, size_t model_size,
     int dtype, ju_runtime **out_runtime);
 
+/* Parses and checks a model container WITHOUT touching a device: header ranges,
+ * tensor table bounds, presence and shape of every layer's variables, the channel
+ * chain of the graph, BatchNorm folding.  The same code runs first inside
+ * ju_create*; this entry point lets a caller (or a CI job on a box without a GPU)
+ * reject a bad or hostile file early.  No reference counterpart: TensorRT's
+ * deserializeCudaEngine is the validator there (core/src/tensorrt_backend.cc:145-148).
+ * JU_OK, or JU_ERR_INVALID_ARGUMENT with the reason in ju_last_error(). */
+JU_API int ju_validate_model(const void *model_bytes, size_t model_size);
+
 /* Replaces Runtime::~Runtime via delete (core.h:65-66). NULL is a no-op. */
 JU_API void ju_destroy(ju_runtime *runtime);
 

@@ -14,6 +14,7 @@
 
 #include "engine.h"
 #include "log.h"
+#include "model.h"
 
 struct ju_runtime {
 	std::unique_ptr<ju::Engine> engine;
@@ -104,6 +105,13 @@ int ju_create(int device_id, const char *model_path, ju_runtime **out_runtime) {
 int ju_create_from_memory(int device_id, const void *model_bytes, size_t model_size, int dtype,
     ju_runtime **out_runtime) {
 	return createFromBytes(device_id, model_bytes, model_size, dtype, out_runtime);
+}
+
+int ju_validate_model(const void *model_bytes, size_t model_size) {
+	return guarded([&] {
+		const ju::ModelFile model(model_bytes, model_size);
+		(void)ju::foldModel(model);
+	});
 }
 
 void ju_destroy(ju_runtime *runtime) {

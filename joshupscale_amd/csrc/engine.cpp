@@ -10,35 +10,6 @@
 
 namespace ju {
 
-namespace {
-
-std::vector<int> identityMap(int cin, int cinP) {
-	std::vector<int> m(cinP, -1);
-	for (int i = 0; i < cin; ++i) m[i] = i;
-	return m;
-}
-
-int roundUp(int v, int m) { return (v + m - 1) / m * m; }
-
-// Packed channel order of the generator input record written by warp_pack_kernel:
-// ch = i*16 + j*3 + c  <- reference channel 3 + (i*4+j)*3 + c   (space_to_depth,
-// keras_layers.py:129, concatenated after the 3 LR channels, models.py:523-530)
-// ch 12,13,14          <- reference channels 0,1,2 (the LR frame)
-std::vector<int> generatorInputMap() {
-	std::vector<int> m(64, -1);
-	for (int i = 0; i < 4; ++i) {
-		for (int j = 0; j < 4; ++j) {
-			for (int c = 0; c < 3; ++c) m[i * 16 + j * 3 + c] = 3 + (i * 4 + j) * 3 + c;
-		}
-	}
-	m[12] = 0;
-	m[13] = 1;
-	m[14] = 2;
-	return m;
-}
-
-}  // namespace
-
 Engine::Tensor &Engine::addTensor(
     const std::string &name, std::size_t count, bool f32, bool state) {
 	Tensor t;
@@ -100,69 +71,9 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 }
 
 void Engine::buildWeights(const ModelFile &model) {
-	const ModelConfig &c = m_Config;
-	const int H = c.frameHeight, W = c.frameWidth;
-	auto plain = [&](const std::string &conv, const std::string &bn, bool bias, int h, int w) {
-		FoldedConv f = foldConv(model, conv, bn, bias);
-		addConv(conv, f, identityMap(f.cin, roundUp(f.cin, 16)), h, w);
-		return f.cout;
-	};
-	// ---- flow ----
-	const int flowCin = 3 * c.numFlowInputs;
-	int h = c.paddedHeight(), w = c.paddedWidth();
-	if (c.flowArch == 0) {
-		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
-		int cin = flowCin;
-		for (int i = 0; i < 2 * nb; ++i) {
-			const std::string n = "flow/block_" + std::to_string(i + 1);
-			const TensorView &k = model.tensor(n + "/conv_1/kernel");
-			if (k.dims.size() != 4 || k.dims[2] != cin || k.dims[3] != c.flowFilters[i]) {
-				throw std::invalid_argument("Invalid model: flow filter mismatch at " + n);
-			}
-			plain(n + "/conv_1", n + "/bn_1", false, h, w);
-			cin = plain(n + "/conv_2", n + "/bn_2", false, h, w);
-			if (i < nb) {
-				h /= 2;
-				w /= 2;
-			} else {
-				h *= 2;
-				w *= 2;
-			}
-		}
-		if (c.flowFilters.size() % 2) plain("flow/conv_1", "flow/bn_1", false, h, w);
-		if (plain("flow/conv_2", "", true, h, w) != 32) {
-			throw std::invalid_argument("Invalid model: flow head must have 32 channels");
-		}
-	} else {
-		plain("flow/conv_1", "flow/bn_1", false, h, w);
-		for (int i = 0; i < c.flowResBlocks; ++i) {
-			const std::string n = "flow/block_" + std::to_string(i + 1);
-			plain(n + "/conv_1", n + "/bn_1", false, h, w);
-			plain(n + "/conv_2", n + "/bn_2", false, h, w);
-		}
-		if (plain("flow/conv_2", "", true, h, w) != 32) {
-			throw std::invalid_argument("Invalid model: flow head must have 32 channels");
-		}
-	}
-	// ---- generator ----
+	// fold + check on the host (model.cpp), then tile, pack and upload layer by layer
+	for (const ConvSpec &s : foldModel(model)) addConv(s.name, s.conv, s.cinMap, s.H, s.W);
 	{
-		FoldedConv f = foldConv(model, "generator/conv_1", "generator/bn_1", false);
-		if (f.cin != 51 || f.cout != c.genFilters) {
-			throw std::invalid_argument("Invalid model: generator/conv_1 must be 51 -> gen_filters");
-		}
-		addConv("generator/conv_1", f, generatorInputMap(), H, W);
-	}
-	for (int i = 0; i < c.genBlocks; ++i) {
-		const std::string n = "generator/block_" + std::to_string(i + 1);
-		plain(n + "/conv_1", n + "/bn_1", false, H, W);
-		plain(n + "/conv_2", n + "/bn_2", false, H, W);
-	}
-	{
-		FoldedConv f = foldConvTranspose2x2(model, "generator/conv_trans_1", "generator/bn_2");
-		if (f.cout != 128 || f.cin != c.genFilters) {
-			throw std::invalid_argument("Invalid model: conv_trans_1 must be gen_filters -> 32");
-		}
-		addConv("generator/conv_trans_1", f, identityMap(f.cin, roundUp(f.cin, 16)), H, W);
 		const TensorView &k2 = model.tensor("generator/conv_trans_2/kernel", {2, 2, 3, 32});
 		const TensorView &b2 = model.tensor("generator/conv_trans_2/bias", {3});
 		m_TailW2 = DeviceBuffer(k2.count * 4);
@@ -403,25 +314,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	int dt = dtypeOverride >= 0 ? dtypeOverride : c.computeDtype;
 	if (dt != kF16 && dt != kBF16) throw std::invalid_argument("Unsupported compute dtype");
 	m_DType = static_cast<DType>(dt);
-	if (c.genFilters % 32 != 0 || c.genFilters <= 0 || c.genBlocks < 0) {
-		throw std::invalid_argument("Unsupported model: gen_filters must be a multiple of 32");
-	}
 	const int H = c.frameHeight, W = c.frameWidth;
 	const int PH = c.paddedHeight(), PW = c.paddedWidth();
-	if (c.flowArch == 0) {
-		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
-		if (nb < 1 || PH % (1 << nb) != 0 || PW % (1 << nb) != 0) {
-			throw std::invalid_argument(
-			    "Unsupported model: padded frame size must be divisible by 2^(flow depth)");
-		}
-		for (int f : c.flowFilters) {
-			if (f % 32 != 0 || f <= 0) {
-				throw std::invalid_argument("Unsupported model: flow filters must be multiples of 32");
-			}
-		}
-	} else if (c.flowResFilters % 32 != 0) {
-		throw std::invalid_argument("Unsupported model: flow filters must be multiples of 32");
-	}
 
 	const char *tailMode = std::getenv("JU_TAIL");
 	m_FusedTail = !(tailMode && std::string(tailMode) == "split");

@@ -63,23 +63,7 @@ ModelFile::ModelFile(const void *blob, std::size_t size) {
 	const int nTensors = u32(104);
 	c.temporalStrength = readLE<float>(b + 108);
 	c.temporalThreshold = readLE<float>(b + 112);
-	if (!(c.temporalStrength >= 0.0f && c.temporalStrength <= 1.0f) ||
-	    !(c.temporalThreshold >= 0.0f && c.temporalThreshold <= 1.0f)) {
-		throw std::invalid_argument("Invalid model: temporal filter strength/threshold must be in [0, 1]");
-	}
 	if (scale != 4) throw std::invalid_argument("Invalid model: scale must be 4");
-	if (c.frameHeight < 2 || c.frameWidth < 2 || c.frameHeight > 8192 || c.frameWidth > 8192) {
-		throw std::invalid_argument("Invalid model: unsupported frame size");
-	}
-	if (c.numFlowInputs < 1 || c.numFlowInputs > 5) {
-		throw std::invalid_argument("Invalid model: 1..5 flow inputs supported");
-	}
-	if (c.flowArch != 0 && c.flowArch != 1) {
-		throw std::invalid_argument("Invalid model: unknown flow architecture");
-	}
-	if (c.computeDtype != kF16 && c.computeDtype != kBF16) {
-		throw std::invalid_argument("Invalid model: unknown compute dtype");
-	}
 	if (nTensors < 0 || headerBytes + static_cast<std::size_t>(nTensors) * kEntryBytes > size) {
 		throw std::invalid_argument("Invalid model: truncated tensor table");
 	}
@@ -94,8 +78,13 @@ ModelFile::ModelFile(const void *blob, std::size_t size) {
 		std::size_t count = 1;
 		for (std::uint32_t d = 0; d < ndim; ++d) {
 			const auto dim = readLE<std::uint32_t>(e + 96 + 4 * d);
+			// (bounded per dimension: the product below cannot wrap, dims fit an int)
+			if (dim == 0 || dim > 65536) {
+				throw std::invalid_argument(std::string("Invalid model: bad dimension in ") + name);
+			}
 			t.dims.push_back(static_cast<int>(dim));
 			count *= dim;
+			if (count > size) throw std::invalid_argument(std::string("Invalid model: bad tensor entry ") + name);
 		}
 		const auto off = readLE<std::uint64_t>(e + 112);
 		const auto cnt = readLE<std::uint64_t>(e + 120);
@@ -104,7 +93,45 @@ ModelFile::ModelFile(const void *blob, std::size_t size) {
 		}
 		t.count = count;
 		t.data = reinterpret_cast<const float *>(b + off);
-		m_Tensors.emplace(name, std::move(t));
+		if (!m_Tensors.emplace(name, std::move(t)).second) {
+			throw std::invalid_argument(std::string("Invalid model: duplicate tensor ") + name);
+		}
+	}
+	validateConfig(m_Config);
+}
+
+void validateConfig(const ModelConfig &c) {
+	auto bad = [](const std::string &what) { throw std::invalid_argument("Invalid model: " + what); };
+	if (c.frameHeight < 2 || c.frameWidth < 2 || c.frameHeight > 8192 || c.frameWidth > 8192) {
+		bad("unsupported frame size");
+	}
+	if (c.numFlowInputs < 1 || c.numFlowInputs > 5) bad("1..5 flow inputs supported");
+	if (c.flowArch != 0 && c.flowArch != 1) bad("unknown flow architecture");
+	if (c.computeDtype != kF16 && c.computeDtype != kBF16) bad("unknown compute dtype");
+	if (c.flowPadFactor < 0 || c.flowPadFactor > 256) bad("flow_pad_factor must be in 0..256");
+	if (c.genFilters <= 0 || c.genFilters > 1024 || c.genFilters % 32 != 0) {
+		bad("gen_filters must be a multiple of 32 (at most 1024)");
+	}
+	if (c.genBlocks < 0 || c.genBlocks > 256) bad("gen_blocks must be in 0..256");
+	if (!(c.bnEps > 0.0f) || !std::isfinite(c.bnEps)) bad("bn_eps must be positive and finite");
+	if (!(c.temporalStrength >= 0.0f && c.temporalStrength <= 1.0f) ||
+	    !(c.temporalThreshold >= 0.0f && c.temporalThreshold <= 1.0f)) {
+		bad("temporal filter strength/threshold must be in [0, 1]");
+	}
+	if (c.flowArch == 0) {
+		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+		const int PH = c.paddedHeight(), PW = c.paddedWidth();
+		if (nb < 1 || PH % (1 << nb) != 0 || PW % (1 << nb) != 0) {
+			bad("padded frame size must be divisible by 2^(flow depth)");
+		}
+		for (int f : c.flowFilters) {
+			if (f <= 0 || f > 1024 || f % 32 != 0) bad("flow filters must be multiples of 32 (at most 1024)");
+		}
+	} else {
+		if (c.flowResFilters <= 0 || c.flowResFilters > 1024 || c.flowResFilters % 32 != 0) {
+			bad("flow filters must be multiples of 32 (at most 1024)");
+		}
+		if (c.flowResBlocks < 0 || c.flowResBlocks > 256) bad("flow_res_blocks must be in 0..256");
 	}
 }
 
@@ -244,6 +271,113 @@ std::vector<std::uint16_t> packTailWeights(const float *k2, DType dt) {
 			}
 		}
 	}
+	return out;
+}
+
+namespace {
+
+std::vector<int> identityMap(int cin, int cinP) {
+	std::vector<int> m(cinP, -1);
+	for (int i = 0; i < cin; ++i) m[i] = i;
+	return m;
+}
+
+int roundUp16(int v) { return (v + 15) / 16 * 16; }
+
+// Packed generator-input record (see warp_pack_kernel) -> reference channel order
+// [LR frame (3), space_to_depth(pre_warp) (48)]  (models.py:523-530).
+std::vector<int> generatorInputMap() {
+	std::vector<int> m(64, -1);
+	for (int i = 0; i < 4; ++i) {
+		for (int j = 0; j < 4; ++j) {
+			for (int c = 0; c < 3; ++c) m[i * 16 + j * 3 + c] = 3 + (i * 4 + j) * 3 + c;
+		}
+	}
+	m[12] = 0;
+	m[13] = 1;
+	m[14] = 2;
+	return m;
+}
+
+}  // namespace
+
+std::vector<ConvSpec> foldModel(const ModelFile &model) {
+	const ModelConfig &c = model.config();
+	std::vector<ConvSpec> out;
+	// one layer: fold, check it against what the graph feeds it and expects of it
+	auto add = [&](const std::string &conv, const std::string &bn, bool bias, int h, int w, int taps,
+	               int cin, int cout) {
+		ConvSpec s;
+		s.name = conv;
+		s.conv = foldConv(model, conv, bn, bias);
+		if (s.conv.taps != taps || s.conv.cin != cin || s.conv.cout != cout) {
+			throw std::invalid_argument("Invalid model: " + conv + " is " +
+			    std::to_string(s.conv.cin) + " -> " + std::to_string(s.conv.cout) + " (" +
+			    std::to_string(s.conv.taps) + " taps), the graph needs " + std::to_string(cin) +
+			    " -> " + std::to_string(cout) + " (" + std::to_string(taps) + " taps)");
+		}
+		s.cinMap = identityMap(cin, roundUp16(cin));
+		s.H = h;
+		s.W = w;
+		out.push_back(std::move(s));
+	};
+	const int H = c.frameHeight, W = c.frameWidth;
+	// ---- flow (models.py:257-331, 334-481) ----
+	int cin = 3 * c.numFlowInputs;
+	int h = c.paddedHeight(), w = c.paddedWidth();
+	if (c.flowArch == 0) {
+		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+		for (int i = 0; i < 2 * nb; ++i) {
+			const std::string n = "flow/block_" + std::to_string(i + 1);
+			const int f = c.flowFilters[i];
+			add(n + "/conv_1", n + "/bn_1", false, h, w, 9, cin, f);
+			add(n + "/conv_2", n + "/bn_2", false, h, w, 9, f, f);
+			cin = f;
+			if (i < nb) {
+				h /= 2;
+				w /= 2;
+			} else {
+				h *= 2;
+				w *= 2;
+			}
+		}
+		if (c.flowFilters.size() % 2) {
+			add("flow/conv_1", "flow/bn_1", false, h, w, 9, cin, c.flowFilters.back());
+			cin = c.flowFilters.back();
+		}
+		add("flow/conv_2", "", true, h, w, 9, cin, 32);
+	} else {
+		const int n = c.flowResFilters;
+		add("flow/conv_1", "flow/bn_1", false, h, w, 9, cin, n);
+		for (int i = 0; i < c.flowResBlocks; ++i) {
+			const std::string b = "flow/block_" + std::to_string(i + 1);
+			add(b + "/conv_1", b + "/bn_1", false, h, w, 9, n, n);
+			add(b + "/conv_2", b + "/bn_2", false, h, w, 9, n, n);
+		}
+		add("flow/conv_2", "", true, h, w, 1, n, 32);
+	}
+	// ---- generator (models.py:484-595) ----
+	add("generator/conv_1", "generator/bn_1", false, H, W, 9, 51, c.genFilters);
+	out.back().cinMap = generatorInputMap();
+	for (int i = 0; i < c.genBlocks; ++i) {
+		const std::string b = "generator/block_" + std::to_string(i + 1);
+		add(b + "/conv_1", b + "/bn_1", false, H, W, 9, c.genFilters, c.genFilters);
+		add(b + "/conv_2", b + "/bn_2", false, H, W, 9, c.genFilters, c.genFilters);
+	}
+	{
+		ConvSpec s;
+		s.name = "generator/conv_trans_1";
+		s.conv = foldConvTranspose2x2(model, s.name, "generator/bn_2");
+		if (s.conv.cout != 128 || s.conv.cin != c.genFilters) {
+			throw std::invalid_argument("Invalid model: conv_trans_1 must be gen_filters -> 32");
+		}
+		s.cinMap = identityMap(s.conv.cin, roundUp16(s.conv.cin));
+		s.H = H;
+		s.W = W;
+		out.push_back(std::move(s));
+	}
+	(void)model.tensor("generator/conv_trans_2/kernel", {2, 2, 3, 32});
+	(void)model.tensor("generator/conv_trans_2/bias", {3});
 	return out;
 }
 

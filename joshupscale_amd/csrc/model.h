@@ -87,6 +87,25 @@ FoldedConv foldConv(const ModelFile &m, const std::string &convName,
 FoldedConv foldConvTranspose2x2(
     const ModelFile &m, const std::string &convName, const std::string &bnPrefix);
 
+// Every convolution of the model, folded and checked, in execution order.  Host
+// only (no device): this is what ju_validate_model runs and what the engine uploads.
+struct ConvSpec {
+	std::string name;         // container layer name, e.g. "generator/block_3/conv_1"
+	FoldedConv conv;
+	std::vector<int> cinMap;  // packed input channel -> source channel (-1 = zero), see packConvWeights
+	int H = 0, W = 0;         // resolution the layer runs at
+};
+
+// Range checks on the header fields (sizes, filter counts, divisibility of the padded
+// frame by the auto-encoder depth, ...).  Throws std::invalid_argument.
+void validateConfig(const ModelConfig &c);
+
+// Folds every layer and checks the whole channel chain (each layer's cin is the
+// previous layer's cout, kernel sizes, head widths).  Throws std::invalid_argument
+// naming the offending layer.  Also returns the raw convT2 kernel/bias views through
+// the ModelFile (generator/conv_trans_2/{kernel,bias}, shapes checked).
+std::vector<ConvSpec> foldModel(const ModelFile &m);
+
 // Kernel-ready 16-bit weights for conv_mfma_kernel:
 // [cout/COG][cinP/CK][tap][CK/16][2][COG][8] with COG = 32*nb (the cout block the
 // launch will use, see convTiling), CK = convCK(cinP).  `cinMap[k]` = source input

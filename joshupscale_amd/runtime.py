@@ -73,6 +73,7 @@ def load_library() -> C.CDLL:
         "ju_create": (C.c_int, [C.c_int, C.c_char_p, P(C.c_void_p)]),
         "ju_create_from_memory": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int,
                                             P(C.c_void_p)]),
+        "ju_validate_model": (C.c_int, [C.c_void_p, C.c_size_t]),
         "ju_destroy": (None, [C.c_void_p]),
         "ju_process": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage)]),
         "ju_enqueue": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage)]),
@@ -102,6 +103,14 @@ def load_library() -> C.CDLL:
 def _check(lib: C.CDLL, rc: int) -> None:
     if rc != 0:
         raise JoshUpscaleError(rc, lib.ju_last_error().decode(errors="replace"))
+
+
+def validate_model(model: bytes) -> None:
+    """Check a container with the C++ loader (``ju_validate_model``): no GPU needed.
+    Raises :class:`JoshUpscaleError` with the loader's message."""
+    lib = load_library()
+    buf = bytes(model)
+    _check(lib, lib.ju_validate_model(buf, len(buf)))
 
 
 class Runtime:
