@@ -88,7 +88,7 @@ void Engine::buildWeights(const ModelFile &model) {
 
 void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
     const std::string &wname, Operand in, Operand res, Operand out, int H, int W,
-    bool relu, bool outF32, bool tower, bool pool) {
+    bool relu, bool outF32, bool tower, bool pool, bool upsample) {
 	auto it = m_Convs.find(wname);
 	if (it == m_Convs.end()) throw std::logic_error("missing conv weights " + wname);
 	const ConvWeights &cw = it->second;
@@ -113,6 +113,12 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 	if (pool) {  // the pooled epilogue pairs the two rows of a wave
 		p.pool = 1;
 		p.rw = 2;
+	}
+	p.upsample = upsample ? 1 : 0;
+	if (upsample) {
+		// + the low-resolution patch: with rw = 2 the workgroup needs 96 KB of LDS and
+		// only one fits a CU (measured 21 us against 16 us); 4-row tiles (74 KB) keep two
+		p.rw = 1;
 	}
 	const DType dt = m_DType;
 	Step s;
@@ -162,10 +168,22 @@ void Engine::buildProgram(int set) {
 	int h = PH, w = PW;
 	if (c.flowArch == 0) {
 		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+		// the decoder's bilinear x2 is folded into the staging of the conv that follows
+		// when that conv stages its input once (cout = 32: every cout-group workgroup
+		// would repeat the expansion; measured: a loss already with two groups) and
+		// reads 64-channel chunks
+		auto fusesUpsample = [&](const std::string &next, int cin) {
+			auto it = m_Convs.find(next);
+			return m_FusedUpsample && it != m_Convs.end() && cin % 64 == 0 && it->second.nb == 1 &&
+			       it->second.cout <= 32;
+		};
+		bool upsampleNext = false;  // `cur` is half resolution: the next conv upsamples it
 		for (int i = 0; i < 2 * nb; ++i) {
 			const std::string n = "flow/block_" + std::to_string(i + 1);
 			const int f = c.flowFilters[i];
-			addConvStep(&prog, "flow", n + "/conv_1", cur, none, Op(n + "/a_1"), h, w, true, false);
+			addConvStep(&prog, "flow", n + "/conv_1", cur, none, Op(n + "/a_1"), h, w, true, false,
+			    false, false, upsampleNext);
+			upsampleNext = false;
 			const bool fusePool = i < nb && m_FusedPool;
 			addConvStep(&prog, "flow", n + "/conv_2", Op(n + "/a_1"), none,
 			    Op(fusePool ? n + "/resample" : n + "/a_2"), h, w, true, false, false, fusePool);
@@ -178,18 +196,29 @@ void Engine::buildProgram(int set) {
 				}
 				h /= 2;
 				w /= 2;
+				cur = Operand{dst, 0};
 			} else {
-				prog.push_back({"flow", 0.0,
-				    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
+				const std::string next = i + 1 < 2 * nb ? "flow/block_" + std::to_string(i + 2) + "/conv_1"
+				                         : (c.flowFilters.size() % 2 ? "flow/conv_1" : "");  // not the head
+				if (fusesUpsample(next, f)) {
+					upsampleNext = true;
+					cur = Op(n + "/a_2");
+				} else {
+					prog.push_back({"flow", 0.0,
+					    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
+					cur = Operand{dst, 0};
+				}
 				h *= 2;
 				w *= 2;
 			}
-			cur = Operand{dst, 0};
 		}
 		if (c.flowFilters.size() % 2) {
-			addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/a_1"), h, w, true, false);
+			addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/a_1"), h, w, true, false,
+			    false, false, upsampleNext);
+			upsampleNext = false;
 			cur = Op("flow/a_1");
 		}
+		if (upsampleNext) throw std::logic_error("flow head cannot take a half-resolution input");
 	} else {
 		addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/x0"), h, w, true, false);
 		const char *xs[2] = {"flow/x0", "flow/x1"};
@@ -321,6 +350,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_FusedTail = !(tailMode && std::string(tailMode) == "split");
 	const char *poolMode = std::getenv("JU_POOL");
 	m_FusedPool = !(poolMode && std::string(poolMode) == "split");
+	const char *upMode = std::getenv("JU_UPSAMPLE");
+	m_FusedUpsample = !(upMode && std::string(upMode) == "split");
 
 	buildWeights(model);
 

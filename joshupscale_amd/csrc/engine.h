@@ -109,7 +109,7 @@ private:
 	    const std::vector<int> &cinMap, int H, int W);
 	void addConvStep(std::vector<Step> *prog, const std::string &tag, const std::string &wname,
 	    Operand in, Operand res, Operand out, int H, int W, bool relu, bool outF32,
-	    bool tower = false, bool pool = false);
+	    bool tower = false, bool pool = false, bool upsample = false);
 	Operand operand(const std::string &name);
 	Tensor &addTowerTensor(const std::string &name, int H, int W, int C);
 	void buildWeights(const ModelFile &model);
@@ -143,6 +143,7 @@ private:
 	std::map<std::string, ConvWeights> m_Convs;
 	DeviceBuffer m_TailW2, m_TailB2, m_TailW2Frag;
 	DeviceBuffer m_TemporalAcc;  // 32.32 fixed-point sum of |gen - pre_warp| (temporal filter)
+	bool m_FusedUpsample = true;  // flow decoder: bilinear x2 folded into the next conv's staging
 	bool m_FusedPool = true;  // max-pool folded into the flow encoder's conv epilogues
 	bool m_FusedTail = true;  // JU_TAIL=split: convT1 as a conv launch + the VALU tail kernel
 	DeviceBuffer m_InStage, m_OutStage, m_RawStage;

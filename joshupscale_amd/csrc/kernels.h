@@ -38,6 +38,10 @@ struct ConvParams {
 	// 2x2 max-pool fused into the epilogue: out is [H/2][W/2][cout] (dense or pitched
 	// in POOLED pixels).  Needs rw == 2, even H and W, no residual, 16-bit output.
 	int pool;
+	// TF1 bilinear x2 upsampling fused into the tile staging: `in` is the
+	// half-resolution tensor [H/2][W/2][cin] (inPitch in its pixels), H and W are the
+	// layer's (full) resolution.  Needs 3x3, cin a multiple of 64, nb == 1, even H, W.
+	int upsample;
 	// Row pitches in pixels (0 = dense, i.e. W).  The pointers address image
 	// pixel (0,0); a tensor kept in the zero-bordered tower layout (below) is
 	// passed as its interior origin plus its pitch.

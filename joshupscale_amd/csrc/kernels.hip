@@ -203,7 +203,15 @@ __device__ __forceinline__ void convChunkMfma(const unsigned char *smW, const un
 // written to the other LDS stage afterwards -- one barrier per chunk, memory
 // latency hidden behind the matrix cores.  Otherwise staging is synchronous and a
 // second resident workgroup provides the overlap.
-template <typename T, int TAPS, int CK, int NB, int RW, bool DBUF>
+//
+// UPS (flow decoder, models.py:412-447): the input tensor is the HALF-resolution
+// activation [H/2][W/2][cin] and the TF1 bilinear x2 upsampling (keras_layers.py:12-61,
+// src = dst/2, edge clamp) happens while the tile is staged: the low-resolution
+// patch under the tile goes to LDS once, then every thread builds its tile elements
+// from 4 LDS reads with the arithmetic of upsample2_kernel (same rounding: the
+// fused and the two-kernel paths are bit-identical).  No 4x larger tensor in HBM,
+// no upsample launch.
+template <typename T, int TAPS, int CK, int NB, int RW, bool DBUF, bool UPS = false>
 __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 	constexpr int HALO = (TAPS == 9) ? 1 : 0;
 	constexpr int TH = 4 * RW;            // tile rows: 4 waves x RW rows each
@@ -336,35 +344,124 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll 6
 				for (int i = tid; i < W_BYTES / 16; i += kConvThreads) dst[i] = src[i];
 			}
-			// ---- stage the input tile (+halo), zero outside the image ----
-			// Loads are issued unconditionally on clamped coordinates and zeroed by a
-			// select: a load under `if (in bounds)` makes hipcc wait vmcnt(0) per element,
-			// i.e. one serial memory round trip per 16 bytes per thread.
-			{
-				constexpr int N = IH * IW * P;
-				constexpr int ITER = (N + kConvThreads - 1) / kConvThreads;
-				uint4 v[ITER];
-				int dstOff[ITER];
+			if constexpr (UPS) {
+				// ---- low-resolution patch -> LDS (rows/cols clamped into the tensor) ----
+				constexpr int LH = IH / 2 + 2, LW = IW / 2 + 2;
+				constexpr int LN = LH * LW * P;
+				constexpr int LITER = (LN + kConvThreads - 1) / kConvThreads;
+				unsigned char *smL = smI + IH * IW * CK * 2;
+				const int lh = p.H >> 1, lw = p.W >> 1;
+				const int lowPitch = p.inPitch ? p.inPitch : lw;  // (inPitch defaults to the HI-res W)
+				const int ly0 = (ty0 >> 1) - 1, lx0 = (tx0 >> 1) - 1;  // patch origin (may be -1)
+				uint4 lv[LITER];
 #pragma unroll
-				for (int k = 0; k < ITER; ++k) {
-					const int i = min(tid + k * kConvThreads, N - 1);
-					const int q = i / P;
-					const int c = i % P;
-					const int r = q / IW;
-					const int x = q - r * IW;
-					const int gy = ty0 - HALO + r;
-					const int gx = tx0 - HALO + x;
-					const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-					const int cy = min(max(gy, 0), p.H - 1);
-					const int cx = min(max(gx, 0), p.W - 1);
-					v[k] = *reinterpret_cast<const uint4 *>(
-					    in + ((size_t)cy * inPitch + cx) * p.cin + cc * CK + c * 8);
-					if (!inb) v[k] = make_uint4(0, 0, 0, 0);
-					dstOff[k] = (tid + k * kConvThreads < N) ? q * (CK * 2) + ((c ^ swz<P>(q)) << 4) : -1;
+				for (int k = 0; k < LITER; ++k) {
+					const int i = min(tid + k * kConvThreads, LN - 1);
+					const int q = i / P, c = i % P;
+					const int r = q / LW, x = q - r * LW;
+					const int cy = min(max(ly0 + r, 0), lh - 1);
+					const int cx = min(max(lx0 + x, 0), lw - 1);
+					lv[k] = *reinterpret_cast<const uint4 *>(
+					    in + ((size_t)cy * lowPitch + cx) * p.cin + cc * CK + c * 8);
 				}
 #pragma unroll
-				for (int k = 0; k < ITER; ++k) {
-					if (dstOff[k] >= 0) *reinterpret_cast<uint4 *>(smI + dstOff[k]) = v[k];
+				for (int k = 0; k < LITER; ++k) {
+					const int i = tid + k * kConvThreads;
+					if (i < LN) reinterpret_cast<uint4 *>(smL)[i] = lv[k];
+				}
+				__syncthreads();
+				// ---- expand: tile element (hi-res pixel, 8 channels) from its sources ----
+				// One pass per parity class of (row, column): src = dst/2 makes the lerp
+				// weights 0 or 1/2, so a class is a copy, a 2-tap or a 4-tap average and
+				// each pass is straight-line code without divergence.  The expressions
+				// are upsample2_kernel's with the zero-weight terms dropped (a + (b-a)*0
+				// == a exactly), so the result is bit-identical.
+				constexpr int CH = IH / 2, CW = IW / 2, CN = CH * CW * P;  // per class
+				static_assert(IH % 2 == 0 && IW % 2 == 0, "tile must split into parity classes");
+#pragma unroll
+				for (int cls = 0; cls < 4; ++cls) {
+					// tile row r has gy = ty0 - 1 + r: odd r <=> even gy (ty0 is even)
+					const int oddY = cls >> 1, oddX = cls & 1;  // parity of gy, gx
+					for (int i = tid; i < CN; i += kConvThreads) {
+						const int c = i % P, q2 = i / P;
+						const int r = 2 * (q2 / CW) + 1 - oddY, x = 2 * (q2 % CW) + 1 - oddX;
+						const int q = r * IW + x;
+						const int gy = ty0 - HALO + r;
+						const int gx = tx0 - HALO + x;
+						Vec8<T> o;
+						if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+							const int y0 = gy >> 1, x0 = gx >> 1;
+							const int y1 = min(y0 + 1, lh - 1), x1 = min(x0 + 1, lw - 1);
+							auto at = [&](int yy, int xx) {
+								return *reinterpret_cast<const Vec8<T> *>(
+								    smL + (((yy - ly0) * LW + (xx - lx0)) * P + c) * 16);
+							};
+							const Vec8<T> tl = at(y0, x0);
+							if (!oddY && !oddX) {
+								o = tl;
+							} else if (!oddY) {
+								const Vec8<T> tr = at(y0, x1);
+#pragma unroll
+								for (int j = 0; j < 8; ++j) {
+									const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
+									o[j] = static_cast<T>(a + (b2 - a) * 0.5f);
+								}
+							} else if (!oddX) {
+								const Vec8<T> bl = at(y1, x0);
+#pragma unroll
+								for (int j = 0; j < 8; ++j) {
+									const float a = static_cast<float>(tl[j]), d = static_cast<float>(bl[j]);
+									o[j] = static_cast<T>(a + (d - a) * 0.5f);
+								}
+							} else {
+								const Vec8<T> tr = at(y0, x1), bl = at(y1, x0), br = at(y1, x1);
+#pragma unroll
+								for (int j = 0; j < 8; ++j) {
+									const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
+									const float d = static_cast<float>(bl[j]), e = static_cast<float>(br[j]);
+									const float top = a + (b2 - a) * 0.5f;
+									const float bot = d + (e - d) * 0.5f;
+									o[j] = static_cast<T>(top + (bot - top) * 0.5f);
+								}
+							}
+						} else {
+#pragma unroll
+							for (int j = 0; j < 8; ++j) o[j] = static_cast<T>(0.f);
+						}
+						*reinterpret_cast<Vec8<T> *>(smI + q * (CK * 2) + ((c ^ swz<P>(q)) << 4)) = o;
+					}
+				}
+			} else {
+				// ---- stage the input tile (+halo), zero outside the image ----
+				// Loads are issued unconditionally on clamped coordinates and zeroed by a
+				// select: a load under `if (in bounds)` makes hipcc wait vmcnt(0) per element,
+				// i.e. one serial memory round trip per 16 bytes per thread.
+				{
+					constexpr int N = IH * IW * P;
+					constexpr int ITER = (N + kConvThreads - 1) / kConvThreads;
+					uint4 v[ITER];
+					int dstOff[ITER];
+#pragma unroll
+					for (int k = 0; k < ITER; ++k) {
+						const int i = min(tid + k * kConvThreads, N - 1);
+						const int q = i / P;
+						const int c = i % P;
+						const int r = q / IW;
+						const int x = q - r * IW;
+						const int gy = ty0 - HALO + r;
+						const int gx = tx0 - HALO + x;
+						const bool inb = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+						const int cy = min(max(gy, 0), p.H - 1);
+						const int cx = min(max(gx, 0), p.W - 1);
+						v[k] = *reinterpret_cast<const uint4 *>(
+						    in + ((size_t)cy * inPitch + cx) * p.cin + cc * CK + c * 8);
+						if (!inb) v[k] = make_uint4(0, 0, 0, 0);
+						dstOff[k] = (tid + k * kConvThreads < N) ? q * (CK * 2) + ((c ^ swz<P>(q)) << 4) : -1;
+					}
+#pragma unroll
+					for (int k = 0; k < ITER; ++k) {
+						if (dstOff[k] >= 0) *reinterpret_cast<uint4 *>(smI + dstOff[k]) = v[k];
+					}
 				}
 			}
 			__syncthreads();
@@ -452,11 +549,13 @@ constexpr int convLdsBytes() {
 	return TAPS * CK * 32 * NB * 2 + (4 * RW + 2 * HALO) * (kTW + 2 * HALO) * CK * 2;
 }
 
-template <typename T, int TAPS, int CK, int NB, int RW, bool DBUF = false>
+template <typename T, int TAPS, int CK, int NB, int RW, bool DBUF = false, bool UPS = false>
 void launchConvInst(const ConvParams &p, hipStream_t stream) {
-	constexpr int lds = convLdsBytes<TAPS, CK, NB, RW>() * (DBUF ? 2 : 1);
+	// UPS: + the low-resolution patch (IH/2+2) x (IW/2+2) pixels
+	constexpr int lds = convLdsBytes<TAPS, CK, NB, RW>() * (DBUF ? 2 : 1) +
+	                    (UPS ? ((4 * RW + 2) / 2 + 2) * ((kTW + 2) / 2 + 2) * CK * 2 : 0);
 	static_assert(lds <= 160 * 1024, "conv stages do not fit LDS");
-	auto kern = conv_mfma_kernel<T, TAPS, CK, NB, RW, DBUF>;
+	auto kern = conv_mfma_kernel<T, TAPS, CK, NB, RW, DBUF, UPS>;
 	static bool attrSet = false;  // first launch happens before any graph capture
 	if (!attrSet) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -500,6 +599,13 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 	                 (p.cout / (32 * p.nb));
 	bool dbuf = ck == 64 && p.cin > 64 && p.nb == 1 && p.taps == 9 && wgs <= cus;
 	if (dbufEnv) dbuf = ck == 64 && p.cin > 64 && p.nb == 1 && p.taps == 9 && dbufEnv[0] == '1';
+	if (p.upsample) {
+		if (p.taps != 9 || ck != 64 || p.nb != 1 || p.H % 2 || p.W % 2 || p.pool) {
+			throw std::invalid_argument("conv: fused upsampling needs 3x3, cin % 64 == 0, nb = 1, even H and W");
+		}
+		if (p.rw == 2) return launchConvInst<T, 9, 64, 1, 2, false, true>(p, stream);
+		return launchConvInst<T, 9, 64, 1, 1, false, true>(p, stream);
+	}
 	if (dbuf) {
 		if (p.rw == 2) return launchConvInst<T, 9, 64, 1, 2, true>(p, stream);
 		return launchConvInst<T, 9, 64, 1, 1, true>(p, stream);

@@ -196,6 +196,12 @@ def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
     assert all(np.array_equal(a, b) for a, b in zip(first, unfused))
     rt6.close()
     monkeypatch.delenv("JU_POOL")
+    monkeypatch.setenv("JU_UPSAMPLE", "split")          # separate bilinear x2 launches: the fused
+    rt7 = R.Runtime(blob, 0, R.DTYPE_BF16)               # staging uses the same arithmetic
+    unfused = [rt7.process_image(f).copy() for f in frames]
+    assert all(np.array_equal(a, b) for a, b in zip(first, unfused))
+    rt7.close()
+    monkeypatch.delenv("JU_UPSAMPLE")
     monkeypatch.setenv("JU_NO_GRAPH", "1")              # eager launches == graph replay
     rt3 = R.Runtime(blob, 0, R.DTYPE_BF16)
     eager = [rt3.process_image(f).copy() for f in frames]
