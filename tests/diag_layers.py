@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Layer-by-layer comparison of the HIP engine with the float64 oracle on a small
-model (developer tool; needs a GPU).  Prints one line per tensor."""
+model (developer tool; needs a GPU).  Prints one line per tensor.  Lives under
+tests/ because it uses the oracle, which is test infrastructure."""
 
 import argparse
 import os
@@ -8,7 +9,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from helpers import (M, O, err, gen_in_to_reference, oracle_config, small_config,  # noqa: E402
                      tail_y_to_reference, u8_stats)
 from joshupscale_amd import runtime as R  # noqa: E402
