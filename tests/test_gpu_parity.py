@@ -406,3 +406,22 @@ def test_temporal_filter_variant(dtype):
     assert gate == [True, False, False, True, False, False], (gate, means, thr)
     assert differs, "the filter must change the result on the still frames"
     rt.close()
+
+
+def test_long_sequence_does_not_drift():
+    """The engine is recurrent: 16-bit rounding of the state could accumulate.  48
+    frames of a moving scene against the float64 oracle: the error of the last
+    frames must stay where it was after the first few (bf16, the looser dtype)."""
+    cfg = small_config()
+    wts, blob, rt = make(cfg, R.DTYPE_BF16)
+    sess = O.Session(wts, oracle_config(cfg))
+    frames = M.synthetic_frames(48, 30, 48, seed=31, kind="smooth")
+    psnr = []
+    for t in range(48):
+        ref = sess.run(frames[t])
+        out = rt.process_image(frames[t])
+        check_u8(out, ref, R.DTYPE_BF16, ("long", t))
+        psnr.append(u8_stats(out, ref)["psnr"])
+    early, late = float(np.mean(psnr[2:8])), float(np.mean(psnr[-6:]))
+    assert late >= early - 3.0, (early, late, psnr)
+    rt.close()
