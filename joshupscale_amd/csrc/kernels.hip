@@ -1234,24 +1234,39 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			}
 			const u64 tu1 = stamp();
 			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
+			// (row ra + r <= rhv always: units are whole pairs, or the odd last row)
+			if (px < rwv) {
+				// The residual is read-modify-write in place.  All reads of the unit
+				// first, then the arithmetic and the writes: left to the compiler every
+				// group is read -> wait -> write -> next read (it cannot prove the groups
+				// do not alias), i.e. 8 exposed LDS round trips per unit.
+				Vec4<T> rv[ROWS][4];
+				if (residual) {
 #pragma unroll
-			for (int r = 0; r < ROWS; ++r) {
-				const int rr = ra + r;
-				if (rr <= rhv && px < rwv) {
+					for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+						for (int g = 0; g < 4; ++g) {
+							rv[r][g] = *reinterpret_cast<const Vec4<T> *>(
+							    smem + outOff + (ra + r) * kResRowBytes + outsw[g]);
+						}
+					}
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				}
+#pragma unroll
+				for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
 					for (int g = 0; g < 4; ++g) {
 						float v[4];
 #pragma unroll
 						for (int i = 0; i < 4; ++i) v[i] = acc[r][4 * g + i];
-						unsigned char *dst = smem + outOff + rr * kResRowBytes + outsw[g];
-						if (residual) {  // block input sits at the same place: read, add, overwrite
-							const Vec4<T> rv = *reinterpret_cast<const Vec4<T> *>(dst);
+						if (residual) {
 #pragma unroll
-							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[i]);
+							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[r][g][i]);
 						}
 						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
 						    static_cast<T>(v[3])};
-						*reinterpret_cast<Vec4<T> *>(dst) = reluPacked<T>(o);
+						*reinterpret_cast<Vec4<T> *>(smem + outOff + (ra + r) * kResRowBytes + outsw[g]) =
+						    reluPacked<T>(o);
 					}
 				}
 			}
