@@ -337,13 +337,34 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 	for (int cc = 0; cc < nCC; ++cc) {
 			if (cc > 0) __syncthreads();
 			// ---- stage the weight chunk (already in fragment order) ----
+			// Up to 9 x 16 B per thread: the loads are issued here and written to LDS
+			// together with the input tile below -- ONE memory round trip per chunk
+			// instead of one for the weights (two for more than 6 x 16 B) plus one for
+			// the tile.  Larger chunks (nb = 2 with 64 channels) keep the copy loop.
+			constexpr int WN = W_BYTES / 16;
+			constexpr int WITER = (WN + kConvThreads - 1) / kConvThreads;
+			constexpr bool W_IN_REGS = WITER <= 9;
+			uint4 wv[W_IN_REGS ? WITER : 1];
 			{
 				const uint4 *src = reinterpret_cast<const uint4 *>(
 				    wgt + (size_t)(cog * nCC + cc) * (TAPS * CK * COG));
-				uint4 *dst = reinterpret_cast<uint4 *>(smW);
+				if constexpr (W_IN_REGS) {
+#pragma unroll
+					for (int k = 0; k < WITER; ++k) wv[k] = src[min(tid + k * kConvThreads, WN - 1)];
+				} else {
+					uint4 *dst = reinterpret_cast<uint4 *>(smW);
 #pragma unroll 6
-				for (int i = tid; i < W_BYTES / 16; i += kConvThreads) dst[i] = src[i];
+					for (int i = tid; i < WN; i += kConvThreads) dst[i] = src[i];
+				}
 			}
+// (a macro, not a lambda: capturing wv[] makes hipcc keep the array in scratch memory)
+#define JU_STORE_WEIGHTS()                                                                   \
+	if constexpr (W_IN_REGS) {                                                               \
+		_Pragma("unroll") for (int k = 0; k < WITER; ++k) {                                  \
+			if (tid + k * kConvThreads < WN)                                                 \
+				reinterpret_cast<uint4 *>(smW)[tid + k * kConvThreads] = wv[k];              \
+		}                                                                                    \
+	}
 			if constexpr (UPS) {
 				// ---- low-resolution patch -> LDS (rows/cols clamped into the tensor) ----
 				constexpr int LH = IH / 2 + 2, LW = IW / 2 + 2;
@@ -364,6 +385,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 					lv[k] = *reinterpret_cast<const uint4 *>(
 					    in + ((size_t)cy * lowPitch + cx) * p.cin + cc * CK + c * 8);
 				}
+				JU_STORE_WEIGHTS()
 #pragma unroll
 				for (int k = 0; k < LITER; ++k) {
 					const int i = tid + k * kConvThreads;
@@ -458,6 +480,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 						if (!inb) v[k] = make_uint4(0, 0, 0, 0);
 						dstOff[k] = (tid + k * kConvThreads < N) ? q * (CK * 2) + ((c ^ swz<P>(q)) << 4) : -1;
 					}
+					JU_STORE_WEIGHTS()
 #pragma unroll
 					for (int k = 0; k < ITER; ++k) {
 						if (dstOff[k] >= 0) *reinterpret_cast<uint4 *>(smI + dstOff[k]) = v[k];
@@ -467,6 +490,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 			__syncthreads();
 			convChunkMfma<T, TAPS, CK, NB, RW>(smW, smI, acc, wave, px, hh);
 		}
+#undef JU_STORE_WEIGHTS
 	}
 
 	// ---- epilogue with the 2x2 max-pool folded in (flow encoder, models.py:377-410):
