@@ -42,6 +42,8 @@ struct ConvParams {
 	// half-resolution tensor [H/2][W/2][cin] (inPitch in its pixels), H and W are the
 	// layer's (full) resolution.  Needs 3x3, cin a multiple of 64, nb == 1, even H, W.
 	int upsample;
+	// multi-chunk register-prefetch path (set by launchConv): 2 = two LDS stages, 1 = one
+	int stages;
 	// Row pitches in pixels (0 = dense, i.e. W).  The pointers address image
 	// pixel (0,0); a tensor kept in the zero-bordered tower layout (below) is
 	// passed as its interior origin plus its pitch.

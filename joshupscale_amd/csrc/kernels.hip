@@ -286,7 +286,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 		}
 		// it = -1 is the prologue (load + store chunk 0); iteration it loads chunk
 		// it+1 (clamped, so the loads are unconditional), computes chunk it, then
-		// parks the loaded registers in the other stage.
+		// parks the loaded registers in the other stage.  With ONE stage (launches with
+		// more workgroups than CUs: two co-resident workgroups matter more than the
+		// second stage) the registers wait for a barrier after the MFMAs instead.
+		const int stageStride = p.stages == 2 ? STAGE : 0;
 		for (int it = -1; it < nCC; ++it) {
 			const int lc = min(it + 1, nCC - 1);
 			// (named scalars, not an array: hipcc leaves a weight-prefetch array in
@@ -306,11 +309,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 				iv[k] = *reinterpret_cast<const uint4 *>(in + srcOff[k] + lc * CK);
 			}
 			if (it >= 0) {
-				const unsigned char *cw = smem + (it & 1) * STAGE;
+				const unsigned char *cw = smem + (it & 1) * stageStride;
 				convChunkMfma<T, TAPS, CK, NB, RW>(cw, cw + W_BYTES, acc, wave, px, hh);
+				if (stageStride == 0) __syncthreads();  // everyone is done reading the only stage
 			}
 			if (it + 1 < nCC) {
-				unsigned char *sw = smem + ((it + 1) & 1) * STAGE;
+				unsigned char *sw = smem + ((it + 1) & 1) * stageStride;
 				uint4 *wdst = reinterpret_cast<uint4 *>(sw) + tid;
 				wdst[0 * kConvThreads] = w0;
 				wdst[1 * kConvThreads] = w1;
@@ -576,14 +580,15 @@ constexpr int convLdsBytes() {
 template <typename T, int TAPS, int CK, int NB, int RW, bool DBUF = false, bool UPS = false>
 void launchConvInst(const ConvParams &p, hipStream_t stream) {
 	// UPS: + the low-resolution patch (IH/2+2) x (IW/2+2) pixels
-	constexpr int lds = convLdsBytes<TAPS, CK, NB, RW>() * (DBUF ? 2 : 1) +
-	                    (UPS ? ((4 * RW + 2) / 2 + 2) * ((kTW + 2) / 2 + 2) * CK * 2 : 0);
-	static_assert(lds <= 160 * 1024, "conv stages do not fit LDS");
+	constexpr int ldsMax = convLdsBytes<TAPS, CK, NB, RW>() * (DBUF ? 2 : 1) +
+	                       (UPS ? ((4 * RW + 2) / 2 + 2) * ((kTW + 2) / 2 + 2) * CK * 2 : 0);
+	static_assert(ldsMax <= 160 * 1024, "conv stages do not fit LDS");
+	const int lds = (DBUF && p.stages == 1) ? ldsMax / 2 : ldsMax;
 	auto kern = conv_mfma_kernel<T, TAPS, CK, NB, RW, DBUF, UPS>;
 	static bool attrSet = false;  // first launch happens before any graph capture
 	if (!attrSet) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-		    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		    hipFuncAttributeMaxDynamicSharedMemorySize, ldsMax);
 		if (e != hipSuccess) {
 			throw std::runtime_error(
 			    std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(e));
@@ -621,8 +626,13 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 	}();
 	const long wgs = (long)((p.W + kTW - 1) / kTW) * ((p.H + 4 * p.rw - 1) / (4 * p.rw)) *
 	                 (p.cout / (32 * p.nb));
-	bool dbuf = ck == 64 && p.cin > 64 && p.nb == 1 && p.taps == 9 && wgs <= cus;
-	if (dbufEnv) dbuf = ck == 64 && p.cin > 64 && p.nb == 1 && p.taps == 9 && dbufEnv[0] == '1';
+	// several 64-channel chunks: the loads of chunk c+1 travel behind the MFMAs of chunk
+	// c (register prefetch).  Two LDS stages when the launch has at most one workgroup
+	// per CU anyway, one stage (and a second barrier) when two can be co-resident.
+	const bool multi = ck == 64 && p.cin > 64 && p.nb == 1 && p.taps == 9;
+	int stages = multi ? (wgs <= cus ? 2 : 1) : 0;
+	if (dbufEnv && multi) stages = dbufEnv[0] - '0';  // A/B: 0 = plain staging, 1, 2
+	const bool dbuf = stages > 0;
 	if (p.upsample) {
 		if (p.taps != 9 || ck != 64 || p.nb != 1 || p.H % 2 || p.W % 2 || p.pool) {
 			throw std::invalid_argument("conv: fused upsampling needs 3x3, cin % 64 == 0, nb = 1, even H and W");
@@ -631,8 +641,10 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 		return launchConvInst<T, 9, 64, 1, 1, false, true>(p, stream);
 	}
 	if (dbuf) {
-		if (p.rw == 2) return launchConvInst<T, 9, 64, 1, 2, true>(p, stream);
-		return launchConvInst<T, 9, 64, 1, 1, true>(p, stream);
+		ConvParams q = p;
+		q.stages = stages;
+		if (p.rw == 2) return launchConvInst<T, 9, 64, 1, 2, true>(q, stream);
+		return launchConvInst<T, 9, 64, 1, 1, true>(q, stream);
 	}
 #define JU_CONV_CASE(TAPS_, CK_)                                                   \
 	if (p.taps == TAPS_ && ck == CK_) {                                            \
