@@ -147,8 +147,9 @@ JU_API int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, siz
 JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_per_launch,
     int *launches, double *flops);
 
-/* Developer switches (timing ablations; never needed by a caller).  Keys:
- * "tower_variant" 0..4 (0 = product kernel). */
+/* Developer switches (timing ablations and fault injection; never needed by a
+ * caller).  Keys: "tower_variant" 0..4 (0 = product kernel); "resident_fault" n
+ * (launch the resident tower n workgroups short: tests the fallback). */
 JU_API int ju_debug_set(const char *key, int value);
 
 /* Library version string, e.g. "joshupscale-amd 0.1 (gfx950)". */

@@ -431,7 +431,16 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		for (const Step &st : m_Program[s]) st.run(m_Stream);
 	}
 	m_Stream.synchronize();
-	checkResidentError();
+	if (const unsigned code = takeResidentError()) {
+		const bool graph = m_UseGraph;
+		m_UseGraph = false;  // (graphs are captured below)
+		fallbackToLayers(code);
+		m_UseGraph = graph;
+		for (int s = 0; s < 2; ++s) {
+			for (const Step &st : m_Program[s]) st.run(m_Stream);
+		}
+		m_Stream.synchronize();
+	}
 	reset();
 
 	const char *direct = std::getenv("JU_DIRECT");
@@ -463,15 +472,38 @@ Engine::~Engine() {
 	}
 }
 
-void Engine::checkResidentError() {
-	if (m_ResErrorHost && *m_ResErrorHost != 0) {
-		const unsigned code = *m_ResErrorHost;
-		*m_ResErrorHost = 0;
-		std::ostringstream ss;
-		ss << "resident tower kernel: a bounded wait on a neighbouring workgroup expired (code 0x"
-		   << std::hex << code << "); are all " << std::dec << m_ResGX * m_ResGY
-		   << " workgroups co-resident? Set JU_TOWER=layers to use the per-layer path";
-		throw std::runtime_error(ss.str());
+unsigned Engine::takeResidentError() {
+	if (m_ResErrorHost == nullptr || *m_ResErrorHost == 0) return 0;
+	const unsigned code = *m_ResErrorHost;
+	*m_ResErrorHost = 0;
+	return code;
+}
+
+// The resident tower needs every workgroup co-resident (one per CU).  When a bounded
+// neighbour wait expires -- CUs masked off or taken by another process -- the engine
+// does not stay broken: it switches to the per-layer tower kernels for good.
+void Engine::fallbackToLayers(unsigned code) {
+	std::ostringstream ss;
+	ss << "resident tower kernel: a bounded wait on a neighbouring workgroup expired (code 0x"
+	   << std::hex << code << std::dec << "); " << m_ResGX * m_ResGY
+	   << " workgroups are not all co-resident on this device. Switching to the per-layer tower "
+	      "kernels (slower) for the rest of this runtime's life";
+	logMessage(LogLevel::Warning, "Engine", ss.str());
+	m_Resident = false;
+	for (int s = 0; s < 2; ++s) {
+		m_Graph[s] = GraphExec();
+		buildProgram(s);
+	}
+	if (m_UseGraph) {
+		// one eager pass sets the per-layer kernels' attributes before capture; it
+		// writes only scratch tensors and the binding sets' OUTPUT halves, which the
+		// caller's re-run (or the next frame) overwrites
+		for (int s = 0; s < 2; ++s) {
+			m_Graph[s] = GraphExec::capture(m_Stream, [&] {
+				for (const Step &st : m_Program[s]) st.run(m_Stream);
+			});
+		}
+		m_Stream.synchronize();
 	}
 }
 
@@ -636,13 +668,26 @@ void Engine::process(const Frame &in, const Frame &out) {
 	DeviceGuard g(m_Device);
 	submit(in, out);
 	m_Stream.synchronize();
-	checkResidentError();
+	if (const unsigned code = takeResidentError()) {
+		// the frame's inputs (previous state, frame history) are intact: the step only
+		// wrote the other half of the ping-pong -- run it again on the per-layer path
+		fallbackToLayers(code);
+		m_Idx ^= 1;
+		submit(in, out);
+		m_Stream.synchronize();
+	}
 }
 
 void Engine::synchronize() {
 	DeviceGuard g(m_Device);
 	m_Stream.synchronize();
-	checkResidentError();
+	if (const unsigned code = takeResidentError()) {
+		fallbackToLayers(code);
+		throw std::runtime_error(
+		    "resident tower kernel failed (workgroups not co-resident); the frames enqueued since "
+		    "the last ju_synchronize are invalid. The runtime now uses the per-layer path: "
+		    "ju_reset and continue");
+	}
 }
 
 std::vector<std::string> Engine::tensorNames() const {

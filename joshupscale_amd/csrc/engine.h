@@ -156,7 +156,8 @@ private:
 	DeviceBuffer m_TowerW, m_TowerB, m_ResMail, m_ResFlags;
 	unsigned *m_ResErrorHost = nullptr;  // pinned, device-visible
 	unsigned *m_ResErrorDev = nullptr;
-	void checkResidentError();
+	unsigned takeResidentError();        // 0 = none; clears it
+	void fallbackToLayers(unsigned code);
 	std::vector<Step> m_Program[2];
 	GraphExec m_Graph[2];
 };

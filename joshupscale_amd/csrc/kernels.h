@@ -143,6 +143,9 @@ void launchResidentTower(DType dt, const ResidentTowerParams &p, hipStream_t str
 
 // Timing-only ablation switch of the tower kernel (0 = product kernel).
 void setTowerVariant(int variant);
+// Test hook: launch the resident tower `n` workgroups short, so that the bounded
+// neighbour waits expire (exercises the engine's fallback to the per-layer path).
+void setResidentFault(int n);
 
 // ---- flow-net helpers -------------------------------------------------------
 // cur frame (u8 BGRX, signed row stride) + previous packed history ->

@@ -959,6 +959,7 @@ __global__ __launch_bounds__(kTowerThreads, 1) void conv_tower_kernel(TowerParam
 }
 
 int g_TowerVariant = 0;
+int g_ResidentFault = 0;  // test hook: launch the resident tower this many workgroups short
 
 template <typename T, int VARIANT>
 void launchTowerT(const ConvParams &p, hipStream_t stream) {
@@ -1597,7 +1598,10 @@ void launchResidentT(const ResidentParams &p, hipStream_t stream) {
 		hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream,
 		    const_cast<unsigned *>(p.gen));
 	}
-	hipLaunchKernelGGL(kern, dim3(p.GX * p.GY), dim3(256), kResLds, stream, p);
+	// (g_ResidentFault > 0, tests only: some regions are never computed, their neighbours'
+	// bounded waits expire and the error path runs)
+	const int grid = p.GX * p.GY - (g_ResidentFault < p.GX * p.GY ? g_ResidentFault : 0);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kResLds, stream, p);
 	hipCheckLaunch("tower_resident");
 }
 
@@ -2269,6 +2273,7 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 }
 
 void setTowerVariant(int v) { g_TowerVariant = v; }
+void setResidentFault(int n) { g_ResidentFault = n; }
 
 void launchBumpGeneration(unsigned *generation, hipStream_t stream) {
 	hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream, generation);

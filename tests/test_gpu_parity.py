@@ -425,3 +425,33 @@ def test_long_sequence_does_not_drift():
     early, late = float(np.mean(psnr[2:8])), float(np.mean(psnr[-6:]))
     assert late >= early - 3.0, (early, late, psnr)
     rt.close()
+
+
+def test_resident_tower_failure_falls_back_to_the_per_layer_path(monkeypatch):
+    """The resident tower needs all its workgroups co-resident.  Launch it one
+    workgroup short (debug hook): the neighbours' bounded waits expire, the engine
+    logs a warning, switches to the per-layer kernels and RE-RUNS the frame -- the
+    caller sees correct frames, not an error."""
+    cfg = small_config()
+    monkeypatch.setenv("JU_NO_GRAPH", "1")   # eager launches: the hook acts on new launches,
+    wts, blob, rt = make(cfg, R.DTYPE_BF16)  # a captured graph has its grid baked in
+    monkeypatch.delenv("JU_NO_GRAPH")
+    ref_rt = R.Runtime(blob, 0, R.DTYPE_BF16)
+    frames = M.synthetic_frames(4, 30, 48, seed=41, kind="smooth")
+    want = [ref_rt.process_image(f).copy() for f in frames]
+    ref_rt.close()
+    lib = R.load_library()
+    seen = []
+    cb = R.LOG_CALLBACK(lambda tag, lvl, msg, user: seen.append((lvl, msg)))
+    lib.ju_set_log_callback(cb, None)
+    got = [rt.process_image(frames[0]).copy()]           # resident path, fine
+    assert lib.ju_debug_set(b"resident_fault", 1) == 0
+    try:
+        got.append(rt.process_image(frames[1]).copy())    # fails inside, falls back, re-runs
+    finally:
+        lib.ju_debug_set(b"resident_fault", 0)
+        lib.ju_set_log_callback(R.LOG_CALLBACK(0), None)
+    got += [rt.process_image(f).copy() for f in frames[2:]]
+    assert any(lvl == 1 and b"per-layer" in msg for lvl, msg in seen), seen
+    assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(want, got))
+    rt.close()
