@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -77,6 +78,23 @@ __device__ __forceinline__ Vec4<T> reluPacked(Vec4<T> v) {
 __device__ __forceinline__ float fastTanh(float x) {
 	const float t = __builtin_amdgcn_exp2f(x * 2.885390081777927f);  // 2 * log2(e)
 	return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
+// Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE:
+// a process may hold runtimes on several GPUs, so "done" is tracked per device (one
+// mask per kernel instantiation, passed in by the launcher).  The first launch on a
+// device happens in the engine's constructor, before any graph capture.
+inline void ensureDynamicLds(const void *kern, int bytes, std::atomic<std::uint64_t> *doneMask,
+    const char *what) {
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+	const std::uint64_t bit = 1ull << dev;
+	if (doneMask->load(std::memory_order_acquire) & bit) return;
+	const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+	if (e != hipSuccess) {
+		throw std::runtime_error(std::string("hipFuncSetAttribute(") + what + " LDS): " + hipGetErrorString(e));
+	}
+	doneMask->fetch_or(bit, std::memory_order_release);
 }
 
 inline void hipCheckLaunch(const char *what) {
@@ -585,16 +603,8 @@ void launchConvInst(const ConvParams &p, hipStream_t stream) {
 	static_assert(ldsMax <= 160 * 1024, "conv stages do not fit LDS");
 	const int lds = (DBUF && p.stages == 1) ? ldsMax / 2 : ldsMax;
 	auto kern = conv_mfma_kernel<T, TAPS, CK, NB, RW, DBUF, UPS>;
-	static bool attrSet = false;  // first launch happens before any graph capture
-	if (!attrSet) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-		    hipFuncAttributeMaxDynamicSharedMemorySize, ldsMax);
-		if (e != hipSuccess) {
-			throw std::runtime_error(
-			    std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(e));
-		}
-		attrSet = true;
-	}
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), ldsMax, &ldsDone, "conv");
 	dim3 grid((p.W + kTW - 1) / kTW, (p.H + 4 * RW - 1) / (4 * RW), p.cout / (32 * NB));
 	hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, p);
 	hipCheckLaunch("conv_mfma");
@@ -964,16 +974,8 @@ int g_ResidentFault = 0;  // test hook: launch the resident tower this many work
 template <typename T, int VARIANT>
 void launchTowerT(const ConvParams &p, hipStream_t stream) {
 	auto kern = conv_tower_kernel<T, VARIANT>;
-	static bool attrSet = false;
-	if (!attrSet) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-		    hipFuncAttributeMaxDynamicSharedMemorySize, kTowerLds);
-		if (e != hipSuccess) {
-			throw std::runtime_error(
-			    std::string("hipFuncSetAttribute(tower LDS): ") + hipGetErrorString(e));
-		}
-		attrSet = true;
-	}
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kTowerLds, &ldsDone, "tower");
 	const int pitch = towerPitch(p.W);
 	const size_t origin = towerOrigin(p.W) * 64 * 2;  // bytes from allocation start to pixel (0,0)
 	TowerParams t{};
@@ -1584,16 +1586,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 template <typename T, int VARIANT, bool HEAD>
 void launchResidentT(const ResidentParams &p, hipStream_t stream) {
 	auto kern = tower_resident_kernel<T, VARIANT, HEAD>;
-	static bool attrSet = false;
-	if (!attrSet) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-		    hipFuncAttributeMaxDynamicSharedMemorySize, kResLds);
-		if (e != hipSuccess) {
-			throw std::runtime_error(
-			    std::string("hipFuncSetAttribute(resident tower LDS): ") + hipGetErrorString(e));
-		}
-		attrSet = true;
-	}
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kResLds, &ldsDone, "resident tower");
 	if (p.bumpGeneration) {
 		hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream,
 		    const_cast<unsigned *>(p.gen));
@@ -2202,15 +2196,8 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 template <typename T>
 void launchTailFusedT(const TailFusedParams &p, hipStream_t stream) {
 	auto kern = tail_fused_kernel<T>;
-	static bool attrSet = false;
-	if (!attrSet) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-		    hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds);
-		if (e != hipSuccess) {
-			throw std::runtime_error(std::string("hipFuncSetAttribute(tail LDS): ") + hipGetErrorString(e));
-		}
-		attrSet = true;
-	}
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kTailLds, &ldsDone, "tail");
 	dim3 grid((p.W + 31) / 32, (p.H + 7) / 8);
 	hipLaunchKernelGGL(kern, grid, dim3(256), kTailLds, stream, p);
 	hipCheckLaunch("tail_fused");
