@@ -6,7 +6,7 @@
 // bytes on the current device, `process(in, out)` = stage-in, one execution of
 // the inference graph against binding set `idx`, stage-out, synchronise, flip
 // `idx` — but the graph is this engine's own schedule of hand-written HIP
-// kernels (kernels.hip) captured into two hipGraphs instead of a TensorRT
+// kernels (*_kernels.hip) captured into two hipGraphs instead of a TensorRT
 // execution context.
 #pragma once
 

@@ -1,0 +1,785 @@
+// gfx950 (CDNA4, MI355X): the frame-level kernels around the convolutions.
+//
+//  * pack_frames        u8 BGRX frame + frame history -> 16-channel flow input
+//  * frame_sums         normalize_brightness scalar
+//  * maxpool2/upsample2 flow auto-encoder resampling (TF1 asymmetric bilinear)
+//  * warp_pack          dense bilinear warp of the previous HR output fused with
+//                       space-to-depth(4), the concat with the LR frame and the
+//                       16-bit pack (reference models.py:799-801, 523-530)
+//  * tail_fused         ConvT1 + ConvT2 on the matrix cores, bias, tanh, bilinear x4
+//                       skip, clip, HR state write and truncating BGRX u8 pack
+//                       (reference models.py:552-593, keras_layers.py:211-230,
+//                       core/src/cuda_convert.cc.cu:95-108); tail = two-kernel form
+//  * temporal_*         moving-average output filter (frame_moving_avg.py)
+//  * copy_rows/to_float staging and introspection helpers
+#include "kernel_common.h"
+
+namespace ju {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// flow input packing
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float preprocessU8(unsigned v) {
+	// PreprocessLayer: x / 255 - 0.5 (reference keras_layers.py:208).  Multiply by the
+	// f32 reciprocal: at most 1 ulp (6e-8) from the correctly rounded quotient, far below
+	// the 16-bit activations and the 1/255 output step, and one op instead of the ~10 of
+	// an IEEE division (the tail evaluates 12 per lane); 0 and 255 map to -0.5 and 0.5
+	// exactly.
+	return static_cast<float>(v) * (1.0f / 255.0f) - 0.5f;
+}
+
+// normalize_brightness (reference models.py:772-779, utils.py:151): the scalar
+// b = mean(x * BGR_LUMA * 3) over H, W, C of the preprocessed frame
+//   = sum_c luma_c * (S_c / (255 N) - 0.5)
+// from the three exact integer channel sums S_c (order-independent, so the
+// reduction is deterministic).  sums == nullptr: feature off, b = 0.
+__device__ __forceinline__ float brightnessOf(const unsigned *__restrict__ sums, float invN) {
+	if (sums == nullptr) return 0.0f;
+	const float mb = static_cast<float>(sums[0]) * invN / 255.0f - 0.5f;
+	const float mg = static_cast<float>(sums[1]) * invN / 255.0f - 0.5f;
+	const float mr = static_cast<float>(sums[2]) * invN / 255.0f - 0.5f;
+	return 0.114f * mb + 0.587f * mg + 0.2989f * mr;
+}
+
+__global__ __launch_bounds__(1024) void frame_sums_kernel(const std::uint8_t *__restrict__ frame,
+    std::ptrdiff_t frameStride, int H, int W, unsigned *__restrict__ sums) {
+	__shared__ unsigned part[3][16];
+	unsigned s0 = 0, s1 = 0, s2 = 0;
+	for (int i = threadIdx.x; i < H * W; i += 1024) {
+		const int y = i / W, x = i - y * W;
+		const unsigned v = *reinterpret_cast<const unsigned *>(frame + y * frameStride + x * 4);
+		s0 += v & 0xff;
+		s1 += (v >> 8) & 0xff;
+		s2 += (v >> 16) & 0xff;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		s0 += __shfl_down(s0, o);
+		s1 += __shfl_down(s1, o);
+		s2 += __shfl_down(s2, o);
+	}
+	const int wv = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0) {
+		part[0][wv] = s0;
+		part[1][wv] = s1;
+		part[2][wv] = s2;
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) {
+		unsigned t = 0;
+		for (int k = 0; k < 16; ++k) t += part[threadIdx.x][k];
+		sums[threadIdx.x] = t;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_frames_kernel(const std::uint8_t *__restrict__ frame,
+    std::ptrdiff_t frameStride, const T *__restrict__ prev, T *__restrict__ cur, int H, int W,
+    int PH, int PW, int padTop, int padLeft, int numInputs, const unsigned *__restrict__ sums,
+    unsigned *generation) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	// first kernel of every frame: bump the launch generation the resident tower tags
+	// its halo slots with (saves a 1-thread launch)
+	if (idx == 0 && generation != nullptr) *generation = *generation + 1;
+	if (idx >= PH * PW) return;
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));
+	const int py = idx / PW;
+	const int pxx = idx - py * PW;
+	const int y = py - padTop;
+	const int x = pxx - padLeft;
+	float c0 = 0.f, c1 = 0.f, c2 = 0.f;  // ZeroPadding2D after preprocess: 0.0 in the border
+	if (y >= 0 && y < H && x >= 0 && x < W) {
+		const unsigned v = *reinterpret_cast<const unsigned *>(frame + y * frameStride + x * 4);
+		// the flow net sees the brightness-normalised frame (models.py:779); the pad
+		// border stays exactly zero (ZeroPadding2D comes after the subtraction)
+		c0 = preprocessU8(v & 0xff) - bright;
+		c1 = preprocessU8((v >> 8) & 0xff) - bright;
+		c2 = preprocessU8((v >> 16) & 0xff) - bright;
+	}
+	const Vec8<T> p0 = *reinterpret_cast<const Vec8<T> *>(prev + (size_t)idx * 16);
+	const Vec8<T> p1 = *reinterpret_cast<const Vec8<T> *>(prev + (size_t)idx * 16 + 8);
+	T pv[16];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		pv[i] = p0[i];
+		pv[8 + i] = p1[i];
+	}
+	const int nch = 3 * numInputs;
+	T o[16];
+	o[0] = static_cast<T>(c0);
+	o[1] = static_cast<T>(c1);
+	o[2] = static_cast<T>(c2);
+#pragma unroll
+	for (int k = 3; k < 16; ++k) o[k] = (k < nch) ? pv[k - 3] : static_cast<T>(0.f);
+	Vec8<T> o0, o1;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		o0[i] = o[i];
+		o1[i] = o[8 + i];
+	}
+	*reinterpret_cast<Vec8<T> *>(cur + (size_t)idx * 16) = o0;
+	*reinterpret_cast<Vec8<T> *>(cur + (size_t)idx * 16 + 8) = o1;
+}
+
+// ---------------------------------------------------------------------------
+// 2x2 max-pool and TF1 bilinear x2 (8 channels = 16 B per thread)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_kernel(
+    const T *__restrict__ in, T *__restrict__ out, int H, int W, int C) {
+	const int OH = H / 2, OW = W / 2, CC = C / 8;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= OH * OW * CC) return;
+	const int c = idx % CC;
+	const int pix = idx / CC;
+	const int ox = pix % OW;
+	const int oy = pix / OW;
+	const T *base = in + ((size_t)(2 * oy) * W + 2 * ox) * C + c * 8;
+	const Vec8<T> a = *reinterpret_cast<const Vec8<T> *>(base);
+	const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(base + C);
+	const Vec8<T> d = *reinterpret_cast<const Vec8<T> *>(base + (size_t)W * C);
+	const Vec8<T> e = *reinterpret_cast<const Vec8<T> *>(base + (size_t)W * C + C);
+	Vec8<T> o;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const float m = fmaxf(fmaxf(static_cast<float>(a[i]), static_cast<float>(b[i])),
+		    fmaxf(static_cast<float>(d[i]), static_cast<float>(e[i])));
+		o[i] = static_cast<T>(m);
+	}
+	*reinterpret_cast<Vec8<T> *>(out + (size_t)pix * C + c * 8) = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_kernel(
+    const T *__restrict__ in, T *__restrict__ out, int H, int W, int C) {
+	// tf.compat.v1.image.resize_bilinear(align_corners=False,
+	// half_pixel_centers=False): src = dst / 2 (reference keras_layers.py:46-52)
+	const int OH = H * 2, OW = W * 2, CC = C / 8;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= OH * OW * CC) return;
+	const int c = idx % CC;
+	const int pix = idx / CC;
+	const int ox = pix % OW;
+	const int oy = pix / OW;
+	const int y0 = oy >> 1, x0 = ox >> 1;
+	const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+	const float fy = (oy & 1) * 0.5f, fx = (ox & 1) * 0.5f;
+	const Vec8<T> tl = *reinterpret_cast<const Vec8<T> *>(in + ((size_t)y0 * W + x0) * C + c * 8);
+	const Vec8<T> tr = *reinterpret_cast<const Vec8<T> *>(in + ((size_t)y0 * W + x1) * C + c * 8);
+	const Vec8<T> bl = *reinterpret_cast<const Vec8<T> *>(in + ((size_t)y1 * W + x0) * C + c * 8);
+	const Vec8<T> br = *reinterpret_cast<const Vec8<T> *>(in + ((size_t)y1 * W + x1) * C + c * 8);
+	Vec8<T> o;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const float a = static_cast<float>(tl[i]), b = static_cast<float>(tr[i]);
+		const float d = static_cast<float>(bl[i]), e = static_cast<float>(br[i]);
+		const float top = a + (b - a) * fx;
+		const float bot = d + (e - d) * fx;
+		o[i] = static_cast<T>(top + (bot - top) * fy);
+	}
+	*reinterpret_cast<Vec8<T> *>(out + (size_t)pix * C + c * 8) = o;
+}
+
+// ---------------------------------------------------------------------------
+// dense warp + space-to-depth + concat + pack
+// ---------------------------------------------------------------------------
+// One thread per (LR pixel, HR row i of its 4x4 block): 4 warped HR pixels x 3
+// channels plus 4 spare slots = one 32-byte quarter of the pixel's 128-byte
+// generator-input record.  Four consecutive lanes fill one record, a wavefront
+// writes 2 KiB contiguously.
+template <typename T>
+__global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ state,
+    const float *__restrict__ flow, const std::uint8_t *__restrict__ frame,
+    std::ptrdiff_t frameStride, T *__restrict__ out, int H, int W, int PW, int padTop,
+    int padLeft, const unsigned *__restrict__ sums, f16 *__restrict__ preWarpOut) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= H * W * 4) return;
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));  // pre_warp += b (models.py:803)
+	const int i = idx & 3;
+	const int pix = idx >> 2;
+	const int w = pix % W;
+	const int h = pix / W;
+	const int HH = H * 4, WW = W * 4;
+	// depth-to-space(4) of the flow head is just this channel addressing:
+	// flow[4h+i, 4w+j, k] = head[h, w, (i*4+j)*2 + k]  (keras_layers.py:175)
+	const float *fp = flow + ((size_t)(h + padTop) * PW + (w + padLeft)) * 32 + i * 8;
+	const f32x4 f0 = *reinterpret_cast<const f32x4 *>(fp);
+	const f32x4 f1 = *reinterpret_cast<const f32x4 *>(fp + 4);
+	const float fl[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+	T o[16];
+	Vec4<f16> pw[4];  // the same 4 HR pixels in [4H][4W][4] f16 for the temporal filter
+	const int Y = 4 * h + i;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int X = 4 * w + j;
+		// tfa/dense_image_warp.py:232-245, 116-171
+		const float qy = static_cast<float>(Y) - fl[2 * j];
+		const float qx = static_cast<float>(X) - fl[2 * j + 1];
+		const float fy = fminf(fmaxf(0.0f, floorf(qy)), static_cast<float>(HH - 2));
+		const float fx = fminf(fmaxf(0.0f, floorf(qx)), static_cast<float>(WW - 2));
+		const float ay = fminf(fmaxf(0.0f, qy - fy), 1.0f);
+		const float ax = fminf(fmaxf(0.0f, qx - fx), 1.0f);
+		const int y0 = static_cast<int>(fy), x0 = static_cast<int>(fx);
+		const f16 *s0 = state + ((size_t)y0 * WW + x0) * 4;
+		const f16 *s1 = s0 + (size_t)WW * 4;
+		const Vec4<f16> tl = *reinterpret_cast<const Vec4<f16> *>(s0);
+		const Vec4<f16> tr = *reinterpret_cast<const Vec4<f16> *>(s0 + 4);
+		const Vec4<f16> bl = *reinterpret_cast<const Vec4<f16> *>(s1);
+		const Vec4<f16> br = *reinterpret_cast<const Vec4<f16> *>(s1 + 4);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const float a = static_cast<float>(tl[c]), b = static_cast<float>(tr[c]);
+			const float d = static_cast<float>(bl[c]), e = static_cast<float>(br[c]);
+			const float top = ax * (b - a) + a;
+			const float bot = ax * (e - d) + d;
+			const float v = ay * (bot - top) + top + bright;
+			o[j * 3 + c] = static_cast<T>(v);
+			pw[j][c] = static_cast<f16>(v);
+		}
+		pw[j][3] = static_cast<f16>(0.f);
+	}
+	if (preWarpOut != nullptr) {
+		f16 *d = preWarpOut + ((size_t)Y * WW + 4 * w) * 4;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) *reinterpret_cast<Vec4<f16> *>(d + 4 * j) = pw[j];
+	}
+	float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+	if (i == 0) {
+		const unsigned v = *reinterpret_cast<const unsigned *>(frame + h * frameStride + w * 4);
+		l0 = preprocessU8(v & 0xff);
+		l1 = preprocessU8((v >> 8) & 0xff);
+		l2 = preprocessU8((v >> 16) & 0xff);
+	}
+	// spare slots: the LR frame rides in quarter 0, zeros elsewhere (x/255-0.5 of
+	// a real pixel is never needed for i != 0, and 0.0 weights nothing)
+	o[12] = static_cast<T>(l0);
+	o[13] = static_cast<T>(l1);
+	o[14] = static_cast<T>(l2);
+	o[15] = static_cast<T>(0.f);
+	Vec8<T> o0, o1;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		o0[k] = o[k];
+		o1[k] = o[8 + k];
+	}
+	T *dst = out + (size_t)pix * 64 + i * 16;
+	*reinterpret_cast<Vec8<T> *>(dst) = o0;
+	*reinterpret_cast<Vec8<T> *>(dst + 8) = o1;
+}
+
+// ---------------------------------------------------------------------------
+// temporal moving-average output filter (scripts/inference/onnx/frame_moving_avg.py
+// :146-302, its default mode: global L1 scene-cut gate with a sign function)
+// ---------------------------------------------------------------------------
+// Runs after the tail: `state` holds gen - b (f16, b = brightness scalar or 0),
+// `preWarp` the warped previous output (+ b).  Pass 1 sums |gen - pre_warp| over
+// every element into a 32.32 fixed-point accumulator (integer atomics: the result
+// does not depend on the order, so the gate is deterministic); pass 2 blends and
+// rewrites the state and the u8 frame unless the gate says "scene cut" (then the
+// generator output written by the tail already is the result).
+constexpr double kTemporalScale = 4294967296.0;  // 2^32
+
+__global__ __launch_bounds__(256) void temporal_reduce_kernel(const f16 *__restrict__ state,
+    const f16 *__restrict__ preWarp, size_t nPix, int lrPixels, const unsigned *__restrict__ sums,
+    unsigned long long *__restrict__ acc) {
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(lrPixels));
+	float s = 0.f;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nPix; i += (size_t)gridDim.x * 256) {
+		const Vec4<f16> g = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
+		const Vec4<f16> q = *reinterpret_cast<const Vec4<f16> *>(preWarp + i * 4);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			s += fabsf(static_cast<float>(g[c]) + bright - static_cast<float>(q[c]));
+		}
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+	if ((threadIdx.x & 63) == 0) {
+		atomicAdd(acc, static_cast<unsigned long long>(static_cast<double>(s) * kTemporalScale + 0.5));
+	}
+}
+
+__global__ __launch_bounds__(256) void temporal_blend_kernel(f16 *__restrict__ state,
+    const f16 *__restrict__ preWarp, std::uint8_t *__restrict__ outU8, std::ptrdiff_t outStride,
+    int HH, int WW, int lrPixels, const unsigned *__restrict__ sums,
+    const unsigned long long *__restrict__ acc, float strength, float threshold) {
+	const double mean = static_cast<double>(*acc) / kTemporalScale / (3.0 * HH * WW);
+	const double d = mean - static_cast<double>(threshold);
+	const float c = d > 0.0 ? 1.0f : (d < 0.0 ? -1.0f : 0.0f);  // Sign (:229-232)
+	if (c > 0.0f) return;                                        // scene cut: out = gen
+	const float half = 0.5f * strength;
+	const float m1 = half - c * half;         // weight of pre_warp (:272-279)
+	const float m2 = c * half + 1.0f - half;  // weight of the generator output (:280-285)
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(lrPixels));
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= (size_t)HH * WW) return;
+	const int y = static_cast<int>(i / WW), x = static_cast<int>(i - (size_t)y * WW);
+	const Vec4<f16> g = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
+	const Vec4<f16> q = *reinterpret_cast<const Vec4<f16> *>(preWarp + i * 4);
+	Vec4<f16> st;
+	unsigned packed = 0;
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		const float r = static_cast<float>(q[ch]) * m1 + (static_cast<float>(g[ch]) + bright) * m2;
+		st[ch] = static_cast<f16>(r - bright);
+		const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);  // postprocess, truncating
+		packed |= (u & 0xff) << (8 * ch);
+	}
+	st[3] = static_cast<f16>(0.f);
+	*reinterpret_cast<Vec4<f16> *>(state + i * 4) = st;
+	*reinterpret_cast<unsigned *>(outU8 + y * outStride + (std::ptrdiff_t)x * 4) = packed;
+}
+
+// ---------------------------------------------------------------------------
+// generator tail
+// ---------------------------------------------------------------------------
+// One thread per mid-resolution pixel (2h+a, 2w+b): 32 channels in, 2x2 HR
+// pixels x 3 channels out.
+template <typename T>
+__global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
+    const float *__restrict__ w2, const float *__restrict__ b2,
+    const std::uint8_t *__restrict__ frame, std::ptrdiff_t frameStride,
+    f16 *__restrict__ stateOut, std::uint8_t *__restrict__ outU8, std::ptrdiff_t outStride,
+    int H, int W, const unsigned *__restrict__ sums) {
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));
+	const int MW = 2 * W, MH = 2 * H;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= MW * MH) return;
+	const int mx = idx % MW;
+	const int my = idx / MW;
+	const int h = my >> 1, a = my & 1;
+	const int w = mx >> 1, b = mx & 1;
+	const T *src = y + ((size_t)h * W + w) * 128 + (a * 2 + b) * 32;
+	float in[32];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const Vec8<T> v = *reinterpret_cast<const Vec8<T> *>(src + k * 8);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) in[k * 8 + i] = static_cast<float>(v[i]);
+	}
+	// LR neighbourhood for the bilinear x4 skip (UpscaleLayer, keras_layers.py:46-52)
+	const int h1 = min(h + 1, H - 1), w1 = min(w + 1, W - 1);
+	float lr[2][2][3];
+#pragma unroll
+	for (int yy = 0; yy < 2; ++yy) {
+#pragma unroll
+		for (int xx = 0; xx < 2; ++xx) {
+			const unsigned v = *reinterpret_cast<const unsigned *>(
+			    frame + (yy ? h1 : h) * frameStride + (xx ? w1 : w) * 4);
+			lr[yy][xx][0] = preprocessU8(v & 0xff);
+			lr[yy][xx][1] = preprocessU8((v >> 8) & 0xff);
+			lr[yy][xx][2] = preprocessU8((v >> 16) & 0xff);
+		}
+	}
+	const int WW = 4 * W;
+#pragma unroll
+	for (int a2 = 0; a2 < 2; ++a2) {
+		const int Y = 2 * my + a2;
+		const float fy = static_cast<float>(Y & 3) * 0.25f;
+		Vec8<f16> st;
+		unsigned pk[2];
+#pragma unroll
+		for (int b2i = 0; b2i < 2; ++b2i) {
+			const int X = 2 * mx + b2i;
+			const float fx = static_cast<float>(X & 3) * 0.25f;
+			unsigned packed = 0;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				// ConvT 2x2 s2: y[2h+a,2w+b,o] = sum_c x[h,w,c] K[a,b,o,c] (+bias)
+				float acc = b2[c];
+				const float *wk = w2 + ((a2 * 2 + b2i) * 3 + c) * 32;
+#pragma unroll
+				for (int k = 0; k < 32; ++k) acc = fmaf(in[k], wk[k], acc);
+				const float top = lr[0][0][c] + (lr[0][1][c] - lr[0][0][c]) * fx;
+				const float bot = lr[1][0][c] + (lr[1][1][c] - lr[1][0][c]) * fx;
+				const float skip = top + (bot - top) * fy;
+				float r = fastTanh(acc) + skip;
+				r = fminf(fmaxf(r, -0.5f), 0.5f);  // ClipLayer
+				st[b2i * 4 + c] = static_cast<f16>(r - bright);  // fed-back state: output_raw - b (models.py:810)
+				// PostprocessLayer + truncating cast (cuda_convert.cc.cu:76-81)
+				const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);
+				packed |= (u & 0xff) << (8 * c);
+			}
+			st[b2i * 4 + 3] = static_cast<f16>(0.f);
+			pk[b2i] = packed;  // X byte = 0
+		}
+		*reinterpret_cast<Vec8<f16> *>(stateOut + ((size_t)Y * WW + 2 * mx) * 4) = st;
+		*reinterpret_cast<uint2 *>(outU8 + Y * outStride + 2 * mx * 4) = make_uint2(pk[0], pk[1]);
+	}
+}
+
+
+// ---------------------------------------------------------------------------
+// fused generator tail on the matrix cores
+// ---------------------------------------------------------------------------
+// trunk [H][W][64] -> ConvT(2x2,s2,64->32)+BN+ReLU -> ConvT(2x2,s2,32->3)+bias -> tanh
+// -> + bilinear x4 of the LR frame -> clip -> HR state (f16) and BGRX u8, in ONE
+// pass (reference models.py:559-593, keras_layers.py:211-230, cuda_convert.cc.cu:76-81).
+// The two-kernel form wrote and re-read a [H][W][128] tensor (66 MB per frame).
+//   stage 1  D1[128][32 px] = W1[128][64] x X[64][32 px]: 4 cout blocks x 4 k-steps.
+//            Cout block nb = (a*2+b) IS the mid-resolution pixel (2h+a, 2w+b)'s 32
+//            channels, so after bias + ReLU each block goes to LDS pixel-major
+//            (64 B per mid pixel) and is directly the B operand of
+//   stage 2  D2[16][32 mid px] = W2[16][32] x Y[32][32 mid px], rows m = 4*(a'*2+b') + c:
+//            lane (mid px, hh), register group g2 then holds the 3 channels of ONE HR
+//            pixel (a' = g2, b' = hh).
+// One workgroup = 8 LR rows x 32 px (4 waves x 2 rows); outputs are staged in LDS
+// and written as whole rows, 16 B per lane.
+constexpr int kTailLdsIn = 8 * 32 * 128;          // 32 KiB input tile
+constexpr int kTailLdsW1 = 64 * 128 * 2;          // 16 KiB convT1 weights (fragment order)
+constexpr int kTailLdsMid = 4 * 4 * 32 * 64;      // per wave: 4 mid-pixel groups x 32 px x 64 B = 8 KiB
+constexpr int kTailLdsOut = 4 * (4 * 128 * 8 + 4 * 128 * 4);  // per wave: 4 HR rows x 128 px x (8 + 4) B
+constexpr int kTailLds = kTailLdsIn + kTailLdsW1 + kTailLdsMid + kTailLdsOut;
+
+struct TailFusedParams {
+	const void *x;        // trunk, addressed at image pixel (0,0)
+	int xPitch;           // row pitch in pixels
+	const void *w1;       // convT1 as 1x1 conv 64->128, packConvWeights order with nb = 2
+	const float *b1;      // [128]
+	const void *w2;       // A fragments of convT2: [2 ks][64 lanes][8] 16-bit
+	const float *b2;      // [3]
+	const std::uint8_t *frame;
+	std::ptrdiff_t frameStride;
+	void *state;          // f16 [4H][4W][4]
+	std::uint8_t *outU8;
+	std::ptrdiff_t outStride;
+	const unsigned *sums;
+	int H, W;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	unsigned char *smI = smem;
+	unsigned char *smW = smem + kTailLdsIn;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
+	unsigned char *smMid = smem + kTailLdsIn + kTailLdsW1 + wave * (kTailLdsMid / 4);
+	unsigned char *smOut = smem + kTailLdsIn + kTailLdsW1 + kTailLdsMid + wave * (kTailLdsOut / 4);
+	const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
+	const T *__restrict__ x = static_cast<const T *>(p.x);
+	const float bright = brightnessOf(p.sums, 1.0f / static_cast<float>(p.H * p.W));
+
+	// ---- stage weights (linear) and the 8 x 32 input tile (swizzled chunks, zero outside) ----
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(p.w1);
+		uint4 *dst = reinterpret_cast<uint4 *>(smW);
+#pragma unroll
+		for (int k = 0; k < kTailLdsW1 / 16 / 256; ++k) dst[tid + k * 256] = src[tid + k * 256];
+		uint4 v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const int i = tid + k * 256;  // 8 rows x 32 px x 8 chunks = 2048
+			const int q = i >> 3, c = i & 7;
+			const int r = q >> 5, xx = q & 31;
+			const int gy = min(ty0 + r, p.H - 1), gx = min(tx0 + xx, p.W - 1);
+			v[k] = *reinterpret_cast<const uint4 *>(x + ((size_t)gy * p.xPitch + gx) * 64 + c * 8);
+		}
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const int i = tid + k * 256;
+			const int q = i >> 3, c = i & 7;
+			*reinterpret_cast<uint4 *>(smI + q * 128 + ((c ^ ((q >> 1) & 7)) << 4)) = v[k];
+		}
+	}
+	// convT2 A fragments (2 k-steps) and biases in registers
+	Vec8<T> a2[2];
+	a2[0] = reinterpret_cast<const Vec8<T> *>(p.w2)[lane];
+	a2[1] = reinterpret_cast<const Vec8<T> *>(p.w2)[64 + lane];
+	const float b2v[3] = {p.b2[0], p.b2[1], p.b2[2]};
+	__syncthreads();
+
+	for (int rw = 0; rw < 2; ++rw) {
+		const int lr = wave * 2 + rw;  // LR row inside the tile
+		const int h = ty0 + lr;
+		// ---- stage 1: 128 couts x 32 px ----
+		f32x16 acc[4];
+#pragma unroll
+		for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const f32x4 b = *reinterpret_cast<const f32x4 *>(p.b1 + nb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) acc[nb][4 * g + i] = b[i];
+			}
+		}
+#pragma unroll
+		for (int ks = 0; ks < 4; ++ks) {
+			const int q = lr * 32 + px;
+			const int c = ks * 2 + hh;
+			const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(smI + q * 128 + ((c ^ ((q >> 1) & 7)) << 4));
+#pragma unroll
+			for (int nb = 0; nb < 4; ++nb) {
+				// weights: [cog = nb>>1][tap 0][ks][h][n = 64][8]
+				const Vec8<T> a = *reinterpret_cast<const Vec8<T> *>(
+				    smW + (nb >> 1) * (64 * 64 * 2) + (((ks * 2 + hh) * 64 + (nb & 1) * 32 + px) << 4));
+				acc[nb] = mfma32(a, b, acc[nb]);
+			}
+		}
+		// ReLU, 16-bit, to LDS as mid pixels: group nb, pixel px, 64 B (4 chunks, P = 4 swizzle)
+#pragma unroll
+		for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				Vec4<T> o = {static_cast<T>(acc[nb][4 * g + 0]), static_cast<T>(acc[nb][4 * g + 1]),
+				    static_cast<T>(acc[nb][4 * g + 2]), static_cast<T>(acc[nb][4 * g + 3])};
+				*reinterpret_cast<Vec4<T> *>(smMid + nb * 2048 + px * 64 +
+				                             ((g ^ ((px >> 2) & 3)) << 4) + hh * 8) = reluPacked<T>(o);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// LR neighbourhood for the bilinear x4 skip of this lane's LR pixel (px)
+		const int w = tx0 + px;
+		const int hc = min(h, p.H - 1), wc = min(w, p.W - 1);
+		const int h1 = min(hc + 1, p.H - 1), w1 = min(wc + 1, p.W - 1);
+		float lrv[2][2][3];
+#pragma unroll
+		for (int yy = 0; yy < 2; ++yy) {
+#pragma unroll
+			for (int xx = 0; xx < 2; ++xx) {
+				const unsigned v = *reinterpret_cast<const unsigned *>(
+				    p.frame + (yy ? h1 : hc) * p.frameStride + (xx ? w1 : wc) * 4);
+				lrv[yy][xx][0] = preprocessU8(v & 0xff);
+				lrv[yy][xx][1] = preprocessU8((v >> 8) & 0xff);
+				lrv[yy][xx][2] = preprocessU8((v >> 16) & 0xff);
+			}
+		}
+		// ---- stage 2 per mid-pixel group (a, b) ----
+#pragma unroll
+		for (int nb = 0; nb < 4; ++nb) {
+			const int a = nb >> 1, bb = nb & 1;
+			f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks) {
+				const int c = ks * 2 + hh;
+				const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(
+				    smMid + nb * 2048 + px * 64 + ((c ^ ((px >> 2) & 3)) << 4));
+				d = mfma32(a2[ks], b, d);
+			}
+			// lane (px, hh), g2: HR pixel (4h + 2a + g2, 4w + 2b + hh), channels d[4*g2 + 0..2]
+#pragma unroll
+			for (int g2 = 0; g2 < 2; ++g2) {
+				const int yq = 2 * a + g2, xq = 2 * bb + hh;  // position inside the 4x4 HR block
+				const float fy = yq * 0.25f, fx = xq * 0.25f;
+				Vec4<f16> st;
+				unsigned packed = 0;
+#pragma unroll
+				for (int c = 0; c < 3; ++c) {
+					const float top = lrv[0][0][c] + (lrv[0][1][c] - lrv[0][0][c]) * fx;
+					const float bot = lrv[1][0][c] + (lrv[1][1][c] - lrv[1][0][c]) * fx;
+					const float skip = top + (bot - top) * fy;
+					float r = fastTanh(d[4 * g2 + c] + b2v[c]) + skip;
+					r = fminf(fmaxf(r, -0.5f), 0.5f);
+					st[c] = static_cast<f16>(r - bright);
+					const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);
+					packed |= (u & 0xff) << (8 * c);
+				}
+				st[3] = static_cast<f16>(0.f);
+				const int xcol = 4 * px + xq;  // HR column inside the 128-px row segment
+				*reinterpret_cast<Vec4<f16> *>(smOut + yq * 1024 + xcol * 8) = st;
+				*reinterpret_cast<unsigned *>(smOut + 4096 + yq * 512 + xcol * 4) = packed;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// ---- coalesced output: 4 HR rows x 128 px ----
+		if (h < p.H) {
+			const int WW = 4 * p.W;
+			const int nValidPx = min(128, 4 * (p.W - tx0));
+			f16 *stateOut = static_cast<f16 *>(p.state);
+#pragma unroll
+			for (int yq = 0; yq < 4; ++yq) {
+				const int Y = 4 * h + yq;
+				// state: 1024 B per row = 64 lanes x 16 B (2 px per lane)
+				if (2 * lane < nValidPx) {
+					const uint4 v = *reinterpret_cast<const uint4 *>(smOut + yq * 1024 + lane * 16);
+					*reinterpret_cast<uint4 *>(stateOut + ((size_t)Y * WW + 4 * tx0 + 2 * lane) * 4) = v;
+				}
+				// u8: 512 B per row = 64 lanes x 8 B (2 px per lane)
+				if (2 * lane < nValidPx) {
+					const uint2 v = *reinterpret_cast<const uint2 *>(smOut + 4096 + yq * 512 + lane * 8);
+					*reinterpret_cast<uint2 *>(p.outU8 + Y * p.outStride + (4 * tx0 + 2 * lane) * 4) = v;
+				}
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+template <typename T>
+void launchTailFusedT(const TailFusedParams &p, hipStream_t stream) {
+	auto kern = tail_fused_kernel<T>;
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kTailLds, &ldsDone, "tail");
+	dim3 grid((p.W + 31) / 32, (p.H + 7) / 8);
+	hipLaunchKernelGGL(kern, grid, dim3(256), kTailLds, stream, p);
+	hipCheckLaunch("tail_fused");
+}
+
+// ---------------------------------------------------------------------------
+// staging helpers
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_rows_kernel(const std::uint8_t *__restrict__ src,
+    std::ptrdiff_t srcStride, std::uint8_t *__restrict__ dst, std::ptrdiff_t dstStride,
+    unsigned wordsPerRow, unsigned rows) {
+	const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= wordsPerRow * rows) return;
+	const unsigned r = idx / wordsPerRow;
+	const unsigned c = idx - r * wordsPerRow;
+	const unsigned v = *reinterpret_cast<const unsigned *>(
+	    src + static_cast<std::ptrdiff_t>(r) * srcStride + c * 4);
+	*reinterpret_cast<unsigned *>(dst + static_cast<std::ptrdiff_t>(r) * dstStride + c * 4) = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_float_kernel(
+    const T *__restrict__ in, float *__restrict__ out, size_t n) {
+	const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (idx < n) out[idx] = static_cast<float>(in[idx]);
+}
+
+}  // namespace
+
+void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
+    const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
+    int padLeft, int numInputs, const unsigned *sums, unsigned *generation,
+    hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)PH * PW);
+	if (dt == kF16) {
+		hipLaunchKernelGGL(pack_frames_kernel<f16>, dim3(nb), dim3(256), 0, stream, frame,
+		    frameStride, static_cast<const f16 *>(prevPacked), static_cast<f16 *>(curPacked), H, W,
+		    PH, PW, padTop, padLeft, numInputs, sums, generation);
+	} else {
+		hipLaunchKernelGGL(pack_frames_kernel<bf16>, dim3(nb), dim3(256), 0, stream, frame,
+		    frameStride, static_cast<const bf16 *>(prevPacked), static_cast<bf16 *>(curPacked), H,
+		    W, PH, PW, padTop, padLeft, numInputs, sums, generation);
+	}
+	hipCheckLaunch("pack_frames");
+}
+
+void launchMaxPool2(DType dt, const void *in, void *out, int H, int W, int C, hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)(H / 2) * (W / 2) * (C / 8));
+	if (dt == kF16) {
+		hipLaunchKernelGGL(maxpool2_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(in), static_cast<f16 *>(out), H, W, C);
+	} else {
+		hipLaunchKernelGGL(maxpool2_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(in), static_cast<bf16 *>(out), H, W, C);
+	}
+	hipCheckLaunch("maxpool2");
+}
+
+void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)(H * 2) * (W * 2) * (C / 8));
+	if (dt == kF16) {
+		hipLaunchKernelGGL(upsample2_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(in), static_cast<f16 *>(out), H, W, C);
+	} else {
+		hipLaunchKernelGGL(upsample2_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(in), static_cast<bf16 *>(out), H, W, C);
+	}
+	hipCheckLaunch("upsample2");
+}
+
+void launchWarpPack(DType dt, const void *state, const float *flow, const std::uint8_t *frame,
+    std::ptrdiff_t frameStride, void *out, int H, int W, int PW, int padTop, int padLeft,
+    const unsigned *sums, void *preWarpOut, hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)H * W * 4);
+	if (dt == kF16) {
+		hipLaunchKernelGGL(warp_pack_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<f16 *>(out), H,
+		    W, PW, padTop, padLeft, sums, static_cast<f16 *>(preWarpOut));
+	} else {
+		hipLaunchKernelGGL(warp_pack_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<bf16 *>(out), H,
+		    W, PW, padTop, padLeft, sums, static_cast<f16 *>(preWarpOut));
+	}
+	hipCheckLaunch("warp_pack");
+}
+
+void launchTemporalFilter(void *state, const void *preWarp, std::uint8_t *outU8,
+    std::ptrdiff_t outStride, int H, int W, const unsigned *sums, unsigned long long *acc,
+    float strength, float threshold, hipStream_t stream) {
+	const int HH = 4 * H, WW = 4 * W;
+	const size_t nPix = (size_t)HH * WW;
+	hipError_t e = hipMemsetAsync(acc, 0, sizeof(unsigned long long), stream);
+	if (e != hipSuccess) throw std::runtime_error(std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+	hipLaunchKernelGGL(temporal_reduce_kernel, dim3(2048), dim3(256), 0, stream,
+	    static_cast<const f16 *>(state), static_cast<const f16 *>(preWarp), nPix, H * W, sums, acc);
+	hipCheckLaunch("temporal_reduce");
+	hipLaunchKernelGGL(temporal_blend_kernel, dim3(blocksFor(nPix)), dim3(256), 0, stream,
+	    static_cast<f16 *>(state), static_cast<const f16 *>(preWarp), outU8, outStride, HH, WW,
+	    H * W, sums, acc, strength, threshold);
+	hipCheckLaunch("temporal_blend");
+}
+
+void launchTail(DType dt, const void *y, const float *w2, const float *b2,
+    const std::uint8_t *frame, std::ptrdiff_t frameStride, void *stateOut, std::uint8_t *outU8,
+    std::ptrdiff_t outStride, int H, int W, const unsigned *sums, hipStream_t stream) {
+	const unsigned nb = blocksFor((size_t)4 * H * W);
+	if (dt == kF16) {
+		hipLaunchKernelGGL(tail_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const f16 *>(y), w2, b2, frame, frameStride, static_cast<f16 *>(stateOut),
+		    outU8, outStride, H, W, sums);
+	} else {
+		hipLaunchKernelGGL(tail_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(y), w2, b2, frame, frameStride, static_cast<f16 *>(stateOut),
+		    outU8, outStride, H, W, sums);
+	}
+	hipCheckLaunch("tail");
+}
+
+void launchTailFused(DType dt, const TailFusedLaunch &q, hipStream_t stream) {
+	TailFusedParams p{};
+	p.x = q.x;
+	p.xPitch = q.xPitch ? q.xPitch : q.W;
+	p.w1 = q.w1;
+	p.b1 = q.b1;
+	p.w2 = q.w2;
+	p.b2 = q.b2;
+	p.frame = q.frame;
+	p.frameStride = q.frameStride;
+	p.state = q.state;
+	p.outU8 = q.outU8;
+	p.outStride = q.outStride;
+	p.sums = q.sums;
+	p.H = q.H;
+	p.W = q.W;
+	if (dt == kF16) launchTailFusedT<f16>(p, stream);
+	else launchTailFusedT<bf16>(p, stream);
+}
+
+void launchFrameSums(const std::uint8_t *frame, std::ptrdiff_t frameStride, int H, int W,
+    unsigned *sums, hipStream_t stream) {
+	hipLaunchKernelGGL(frame_sums_kernel, dim3(1), dim3(1024), 0, stream, frame, frameStride, H, W,
+	    sums);
+	hipCheckLaunch("frame_sums");
+}
+
+void launchCopyRows(const std::uint8_t *src, std::ptrdiff_t srcStride, std::uint8_t *dst,
+    std::ptrdiff_t dstStride, std::size_t rowBytes, std::size_t rows, hipStream_t stream) {
+	const unsigned words = static_cast<unsigned>(rowBytes / 4);
+	hipLaunchKernelGGL(copy_rows_kernel, dim3(blocksFor((size_t)words * rows)), dim3(256), 0,
+	    stream, src, srcStride, dst, dstStride, words, static_cast<unsigned>(rows));
+	hipCheckLaunch("copy_rows");
+}
+
+void launchToFloat(DType dt, const void *in, float *out, std::size_t n, hipStream_t stream) {
+	if (dt == kF16) {
+		hipLaunchKernelGGL(to_float_kernel<f16>, dim3(blocksFor(n)), dim3(256), 0, stream,
+		    static_cast<const f16 *>(in), out, n);
+	} else {
+		hipLaunchKernelGGL(to_float_kernel<bf16>, dim3(blocksFor(n)), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(in), out, n);
+	}
+	hipCheckLaunch("to_float");
+}
+
+
+}  // namespace ju

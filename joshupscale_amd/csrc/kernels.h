@@ -1,4 +1,4 @@
-// Host-side launch interface of the gfx950 kernels (kernels.hip).
+// Host-side launch interface of the gfx950 kernels ({conv,tower,frame}_kernels.hip).
 //
 // Every launcher enqueues on the given stream and returns immediately; none of
 // them allocates, synchronises or touches the host heap, so the whole per-frame

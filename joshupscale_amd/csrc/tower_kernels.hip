@@ -1,0 +1,1031 @@
+// gfx950 (CDNA4, MI355X): the generator's residual tower (reference
+// scripts/training/models.py:193-254, 531-550).
+//
+//  * tower_resident_kernel  conv_1 + all 48 3x3 64->64 convolutions in ONE launch,
+//                           activations resident in LDS, halo exchange through a
+//                           global mailbox of self-validating slots (the product path)
+//  * conv_tower_kernel      one 64->64 layer per launch, persistent, LDS-DMA staged
+//                           (fallback: more regions than CUs, JU_TOWER=layers)
+#include "kernel_common.h"
+
+namespace ju {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// persistent 3x3 64->64 convolution of the generator's residual tower
+// ---------------------------------------------------------------------------
+// One workgroup per CU (grid = min(#tiles, 256)), 4 waves, one per SIMD.  The
+// 72 KiB of kernel-ready weights are DMA'd into LDS once per workgroup; input
+// tiles (8 rows x 32 px + halo = 10 x 34 px x 128 B) are double-buffered and
+// fetched with global_load_lds (no VGPR round trip) while the previous tile is on
+// the matrix cores.  Activations live in the zero-bordered tower layout, so tile
+// staging has no bounds checks.  LDS: 73728 + 2 * 43520 = 160768 B of 163840.
+//
+// LDS-DMA writes lane-linear (base + lane*16), so the bank-conflict swizzle is
+// applied to each lane's SOURCE chunk and again on the fragment read.
+constexpr int kTowerThreads = 256;
+constexpr int kTowerWBytes = 9 * 64 * 64 * 2;
+constexpr int kTowerTileBytes = 10 * 34 * 128;
+constexpr int kTowerLds = kTowerWBytes + 2 * kTowerTileBytes;
+
+__device__ __forceinline__ void glds16(const void *g, void *l) {
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+	    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+struct TowerParams {
+	const void *in;    // tower-layout allocation start (row -1, col -1 of the image)
+	const void *wgt;
+	const float *bias;
+	const void *res;   // allocation start or nullptr
+	void *out;         // allocation start
+	int H, W, pitch;   // pitch in pixels
+	int tilesX, numTiles;
+	int relu;
+};
+
+// VARIANT is a timing-only ablation switch (tools/tower_ablation.py); 0 is the
+// product kernel.  1: no MFMA loop, 2: no epilogue loads/stores, 3: no tile
+// staging, 4: no weight staging.  Variants != 0 compute garbage by design.
+template <typename T, int VARIANT>
+__global__ __launch_bounds__(kTowerThreads, 1) void conv_tower_kernel(TowerParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	unsigned char *smW = smem;
+	unsigned char *smT = smem + kTowerWBytes;
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6;
+	const int lane = tid & 63;
+	const int px = lane & 31;
+	const int hh = lane >> 5;
+	const T *__restrict__ in = static_cast<const T *>(p.in);
+
+	// XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2);
+	// give each XCD a contiguous run of tiles so vertically adjacent tiles find
+	// their shared halo rows in L2.
+	const int nwg = gridDim.x;
+	const int bid = blockIdx.x;
+	const int perX = (nwg + 7) >> 3;
+	const int slot = (bid & 7) * perX + (bid >> 3);  // may exceed nwg-1 when nwg % 8 != 0
+
+	auto stageTile = [&](int tile, int buf) {
+		const int ty = tile / p.tilesX;
+		const int tx = tile - ty * p.tilesX;
+		const T *base = in + ((size_t)(ty * 8) * p.pitch + tx * 32) * 64;
+		unsigned char *dst = smT + buf * kTowerTileBytes;
+#pragma unroll
+		for (int k = 0; k < (VARIANT == 3 ? 0 : 11); ++k) {
+			const int i = wave + 4 * k;          // wave-instruction index: 8 pixels each
+			const int q = i * 8 + (lane >> 3);   // pixel index inside the 10 x 34 tile
+			if (i < 43 && q < 340) {
+				const int r = q / 34;
+				const int x = q - r * 34;
+				const int c = (lane & 7) ^ ((q >> 1) & 7);
+				glds16(base + ((size_t)r * p.pitch + x) * 64 + c * 8, dst + i * 1024);
+			}
+		}
+	};
+
+	// ---- prologue: weights + first tile in flight together ----
+	{
+		const unsigned char *wsrc = static_cast<const unsigned char *>(p.wgt);
+#pragma unroll
+		for (int k = 0; k < (VARIANT == 4 ? 0 : 18); ++k) {
+			const int i = wave + 4 * k;
+			glds16(wsrc + (size_t)i * 1024 + lane * 16, smW + i * 1024);
+		}
+	}
+	int tile = slot;
+	if (tile < p.numTiles) stageTile(tile, 0);
+
+	f32x4 biasv[2][4];
+#pragma unroll
+	for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			biasv[nb][g] = *reinterpret_cast<const f32x4 *>(p.bias + nb * 32 + 8 * g + 4 * hh);
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+
+	// LDS byte addresses for the hand-issued fragment reads
+	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (__attribute__((address_space(3))) unsigned char *)smem));
+	const unsigned wAddr = ldsBase + hh * 1024 + px * 16;
+	const unsigned wAddrHi = wAddr + 40960;
+	const int q0 = (wave * 2) * 34 + px;
+
+	int buf = 0;
+	const int stride = perX * 8;
+	for (; tile < p.numTiles; tile += stride, buf ^= 1) {
+		const int next = tile + stride;
+		if (next < p.numTiles) stageTile(next, buf ^ 1);  // async, lands during the MFMAs
+
+		const int ty = tile / p.tilesX;
+		const int tx = tile - ty * p.tilesX;
+		f32x16 acc[2][2];
+#pragma unroll
+		for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+#pragma unroll
+				for (int rw = 0; rw < 2; ++rw) {
+					acc[nb][rw][4 * g + 0] = biasv[nb][g][0];
+					acc[nb][rw][4 * g + 1] = biasv[nb][g][1];
+					acc[nb][rw][4 * g + 2] = biasv[nb][g][2];
+					acc[nb][rw][4 * g + 3] = biasv[nb][g][3];
+				}
+			}
+		}
+		// residual prefetch (second conv of a block): issued now, consumed after the
+		// K loop, so its latency hides behind the MFMAs
+		Vec4<T> resv[2][2][4];
+		if (VARIANT != 2 && p.res != nullptr) {
+			const int gxr = tx * 32 + px;
+#pragma unroll
+			for (int rw = 0; rw < 2; ++rw) {
+				const int gyr = ty * 8 + wave * 2 + rw;  // rows beyond H read the zero border
+				const T *rp = static_cast<const T *>(p.res) +
+				              ((size_t)(gyr + 1) * p.pitch + gxr + 1) * 64 + 4 * hh;
+#pragma unroll
+				for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						resv[rw][nb][g] = *reinterpret_cast<const Vec4<T> *>(rp + nb * 32 + 8 * g);
+					}
+				}
+			}
+		}
+
+		// K loop as 12 macro-steps m = (dx, ks): the 3 vertical taps x 2 cout blocks
+		// of weights (6 fragments) and the wave's 4 input rows (4 fragments) feed
+		// 12 MFMAs.  With one wave per SIMD nothing but this wave's own instruction
+		// stream can hide LDS latency, and hipcc schedules fragment reads just in
+		// time (ds_read; s_waitcnt lgkmcnt(0); mfma), so the loop is hand-scheduled:
+		// the 10 fragment reads of step m+1 are issued, one behind each of the first
+		// 10 MFMAs of step m, IN THE ORDER step m+1 consumes them; each MFMA waits
+		// with a counted lgkmcnt for exactly the reads it needs (LDS reads return in
+		// order).  Reads are asm (hipcc must not count or move them); each wait is
+		// followed by sched_barrier(0) so no MFMA is hoisted above it.
+		//
+		// consumption order of a step's reads:   a00 b0 a01 b1 a10 a11 b2 a20 a21 b3
+		// MFMA k = (dy, rw, nb) = (k>>2, (k>>1)&1, k&1) uses a[dy][nb], b[rw+dy]
+		Vec8<T> fa[2][3][2], fb[2][4];
+		const unsigned tileAddr = ldsBase + kTowerWBytes + buf * kTowerTileBytes;
+		auto issueRead = [&](int m, int set, int idx) {
+			// idx = position in the consumption order above
+			const int dx = m >> 2, ks = m & 3;
+			constexpr int kind[10] = {0, 1, 0, 1, 0, 0, 1, 0, 0, 1};   // 0 = weight, 1 = activation
+			constexpr int sub[10] = {0, 0, 1, 1, 2, 3, 2, 4, 5, 3};    // a: dy*2+nb ; b: row
+			if (kind[idx] == 0) {
+				const int dy = sub[idx] >> 1, nb = sub[idx] & 1;
+				const int widx = (dy * 3 + dx) * 4 + ks;
+				const int off = widx * 2048 + nb * 512;
+				if (off < 65536 - 512) {
+					asm volatile("ds_read_b128 %0, %1 offset:%2"
+					             : "=v"(fa[set][dy][nb]) : "v"(wAddr), "n"(off));
+				} else {
+					asm volatile("ds_read_b128 %0, %1 offset:%2"
+					             : "=v"(fa[set][dy][nb]) : "v"(wAddrHi), "n"(off - 40960));
+				}
+			} else {
+				const int r = sub[idx];
+				const int q = q0 + r * 34 + dx;
+				const unsigned a = tileAddr + q * 128 + (((ks * 2 + hh) ^ ((q >> 1) & 7)) << 4);
+				asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][r]) : "v"(a));
+			}
+		};
+		// reads that must have landed before MFMA k of a step: index of the last one
+		// it needs in the consumption order (-1: nothing new)
+		constexpr int needs[12] = {1, 2, 3, -1, 4, 5, 6, -1, 7, 8, 9, -1};
+		// start from an empty LGKM counter: the counted waits below must see only
+		// this loop's own reads (compiler-issued scalar loads would skew them)
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int i = 0; i < (VARIANT == 1 ? 0 : 10); ++i) issueRead(0, 0, i);
+#pragma unroll
+		for (int m = 0; m < (VARIANT == 1 ? 0 : 12); ++m) {
+			const int set = m & 1;
+			const bool more = (m + 1 < 12);
+#pragma unroll
+			for (int k = 0; k < 12; ++k) {
+				if (needs[k] >= 0) {
+					// outstanding reads allowed = (this step's reads younger than needs[k])
+					//                           + (next step's reads already issued = k)
+					const int allowed = (9 - needs[k]) + (more ? (k < 10 ? k : 10) : 0);
+					if (allowed >= 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+					else if (allowed == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+					else if (allowed == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+					else if (allowed == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+					else if (allowed == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+					else if (allowed == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+					else if (allowed == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+					else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+					else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+					else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+					else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				const int dy = k >> 2, rw = (k >> 1) & 1, nb = k & 1;
+				acc[nb][rw] = mfma32(fa[set][dy][nb], fb[set][rw + dy], acc[nb][rw]);
+				if (more && k < 10) issueRead(m + 1, set ^ 1, k);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		// ---- epilogue ----
+		// Each lane holds, per (row rw, cout block nb, group g), 4 consecutive output
+		// channels of ONE pixel: stored directly that is an 8-byte write into each of
+		// 32 different 128-byte pixel records per instruction, and a layer becomes ~1M
+		// partial-line L2 requests (measured: 9.4 of 19.5 us).  Instead the wave
+		// transposes its 2 rows x 32 px x 64 ch through LDS (its own 8 KiB slice of
+		// the input buffer it has just finished with) and stores whole records,
+		// 16 B per lane, 1 KiB contiguous per instruction.
+		__syncthreads();  // every wave is done reading this tile's input (halo rows are shared)
+		{
+			unsigned char *slice = smT + buf * kTowerTileBytes + wave * 8192;
+#pragma unroll
+			for (int rw = 0; rw < 2; ++rw) {
+				const int pi = rw * 32 + px;  // pixel index inside the slice
+#pragma unroll
+				for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						float v[4];
+#pragma unroll
+						for (int i = 0; i < 4; ++i) v[i] = acc[nb][rw][4 * g + i];
+						if (VARIANT != 2 && p.res != nullptr) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(resv[rw][nb][g][i]);
+						}
+						if (p.relu) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+						}
+						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]),
+						    static_cast<T>(v[2]), static_cast<T>(v[3])};
+						const int c = nb * 4 + g;  // 16-byte chunk = channels 8c .. 8c+7
+						*reinterpret_cast<Vec4<T> *>(
+						    slice + pi * 128 + ((c ^ (pi & 7)) << 4) + hh * 8) = o;
+					}
+				}
+			}
+			// same-wave exchange through LDS: order the writes before the reads
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			if (VARIANT != 2) {
+				T *outp = static_cast<T *>(p.out);
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					const int pi = i * 8 + (lane >> 3);
+					const int c = (lane & 7) ^ (pi & 7);
+					typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+					const u32x4 val = *reinterpret_cast<const u32x4 *>(slice + i * 1024 + lane * 16);
+					const int gy = ty * 8 + wave * 2 + (pi >> 5);
+					const int gxo = tx * 32 + (pi & 31);
+					if (gy < p.H && gxo < p.W) {
+						// (non-temporal stores measured no better: 18.2 vs 17.4 us)
+						*reinterpret_cast<u32x4 *>(
+						    outp + ((size_t)(gy + 1) * p.pitch + gxo + 1) * 64 + c * 8) = val;
+					}
+				}
+			} else {
+				asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[0][1]), "v"(acc[1][1]));
+			}
+		}
+		// End of iteration.  The next tile's DMA was already drained by the
+		// __syncthreads() in front of the epilogue (its fence waits vmcnt(0) while an
+		// LDS-DMA is pending), so nothing here waits on memory: in particular not on
+		// the record stores' acknowledgements (an s_waitcnt vmcnt(0) here cost ~1.5 us
+		// per tile).  Only the staging slices must be read out before the next
+		// iteration's DMA refills this buffer: LDS wait + raw s_barrier.
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
+int g_TowerVariant = 0;
+int g_ResidentFault = 0;  // test hook: launch the resident tower this many workgroups short
+
+template <typename T, int VARIANT>
+void launchTowerT(const ConvParams &p, hipStream_t stream) {
+	auto kern = conv_tower_kernel<T, VARIANT>;
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kTowerLds, &ldsDone, "tower");
+	const int pitch = towerPitch(p.W);
+	const size_t origin = towerOrigin(p.W) * 64 * 2;  // bytes from allocation start to pixel (0,0)
+	TowerParams t{};
+	t.in = static_cast<const unsigned char *>(p.in) - origin;
+	t.wgt = p.wgt;
+	t.bias = p.bias;
+	t.res = p.res ? static_cast<const unsigned char *>(p.res) - origin : nullptr;
+	t.out = static_cast<unsigned char *>(p.out) - origin;
+	t.H = p.H;
+	t.W = p.W;
+	t.pitch = pitch;
+	t.tilesX = (p.W + 31) / 32;
+	t.numTiles = t.tilesX * ((p.H + 7) / 8);
+	t.relu = p.relu;
+	// The XCD remap in the kernel is a bijection only on grids that are a multiple
+	// of 8; surplus workgroups find no tile and exit after the weight prologue.
+	const int grid = ((t.numTiles < 256 ? t.numTiles : 256) + 7) / 8 * 8;
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(kTowerThreads), kTowerLds, stream, t);
+	hipCheckLaunch("conv_tower");
+}
+
+// ---------------------------------------------------------------------------
+// resident tower: all 2*B convolutions of the generator's residual blocks in
+// ONE launch, activations never leaving the CU
+// ---------------------------------------------------------------------------
+// Per-layer launches are memory- and latency-chain-bound:
+// a 64->64 layer moves ~46 MB for 9.6 GFLOP and pays a kernel boundary plus the
+// flush of 16.6 MB of dirty L2.  Here each workgroup (one per CU) owns a region
+// of 32 x RH (<= 16) pixels for the whole tower (480x270: 15 x 17 = 255 regions):
+//   * two LDS buffers of (RH+2) x 34 px x 128 B hold the block input X and the
+//     intermediate T, including a one-pixel halo ring; conv1 reads X writes T,
+//     conv2 reads T, adds the residual from X and writes X in place; the 16-byte
+//     chunk swizzle is keyed on the COLUMN ((cc>>1)&7): a row is 272 x 16 B, a
+//     multiple of the 16-slot bank row, so rows do not shift the slot pattern;
+//   * the wave's weights (its 32 output channels x 576) are the MFMA A operand
+//     straight from 144 VGPRs, double-buffered (288) so the next layer's weights
+//     stream in from L2 behind the current layer's MFMAs;
+//   * after every layer only the edge ring (<= 94 px, 12 KB) is exchanged with the
+//     <= 8 neighbouring workgroups through a global mailbox of self-validating
+//     16-byte slots (epoch tag in the 8 free sign bits of post-ReLU values), one
+//     write-through (sc1) store each, no drain and no release; a relaxed flag is
+//     only a hint to start looking; the consumer reads with 16-byte sc1 loads and
+//     retries slots whose tag is still old (cdna_hip_programming.md Guideline 16:
+//     the "data is the flag" form R2, at 16 B).  Measured alternatives: drained
+//     stores + flag + load (R1) 4.1 us per layer; 8-byte {tag,data} granules 13 us
+//     (write-through stores are one fabric transaction each, so width matters).
+// Nothing depends on dispatch order or XCD placement; all workgroups must be
+// co-resident (grid <= #CUs, one workgroup per CU by LDS size); every wait is
+// bounded in time and reports through *error.
+constexpr int kResRW = 32;                                          // region width = one MFMA block
+constexpr int kResMaxRH = 16;                                       // 8 row pairs, 4 per wave group
+constexpr int kResPitch = kResRW + 2;                               // LDS row: 32 px + halo column each side
+constexpr int kResRowBytes = kResPitch * 128;                       // 4352
+constexpr int kResBufBytes = (kResMaxRH + 2) * kResRowBytes;       // 78336
+constexpr int kResOffA = 0;
+constexpr int kResOffB = kResBufBytes;
+constexpr int kResOffMisc = kResOffB + kResBufBytes;
+static_assert(kResRowBytes == 4352, "the ds_read immediates in tower_resident_kernel assume a 4352-byte row");
+constexpr int kResLds = kResOffMisc + 64 + 512;                     // flag, 2 bias slots
+constexpr int kResMailSlots = 4 * 32 * 8;                           // 16-byte slots per region per parity
+constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of s_memrealtime
+
+struct ResidentParams {
+	const void *in;           // first layer's input, addressed at image pixel (0,0)
+	int inPitch;              // its row pitch in pixels (dense W, or towerPitch(W))
+	int hasHead;              // 1: layer 0 is the generator's conv_1 (no residual), blocks follow
+	void *out;                // tower-layout tensor, allocation start (last layer's output)
+	const void *weights;      // nLayers x 73728 B, kernel-ready (packConvWeights)
+	const float *bias;        // nLayers x 64
+	uint4 *mail;              // [regions][2][kResMailSlots] 16-byte slots
+	unsigned *flag;           // [regions] {generation<<8 | layers published}
+	const unsigned *gen;      // launch generation (bumped by bump_generation_kernel)
+	unsigned *error;          // host-visible word, 0 = ok
+	unsigned long long *debug;  // VARIANT 4 only: [regions][4 waves][8] cycle sums
+	int H, W, pitch;
+	int GX, GY, RH;
+	int nLayers;
+	int bumpGeneration;  // host-side only: launch bump_generation_kernel first
+};
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__global__ void bump_generation_kernel(unsigned *gen) {
+	*gen = *gen + 1;
+}
+
+// VARIANT: timing ablation only (0 = product; bit 0 = no halo exchange, bit 1 = no MFMA loop)
+// HEAD: layer 0 is the generator's conv_1 (plain conv + ReLU), residual blocks follow
+template <typename T, int VARIANT, bool HEAD>
+__global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr bool xchg = !(VARIANT & 1);
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6;
+	const int lane = tid & 63;
+	const int px = lane & 31;
+	const int hh = lane >> 5;
+	const int ch = wave & 1;   // cout half of this wave
+	const int rp = wave >> 1;  // row-pair parity of this wave
+	// Workgroups are dealt to the 8 XCDs round-robin (b % 8).  Give each XCD a
+	// contiguous, row-major run of regions, so that most of a region's 8 neighbours
+	// live on the same XCD and their mailbox lines are served by that XCD's L2.  A
+	// bijection for any grid size: XCD x holds count_x = ceil((n - x) / 8) workgroups.
+	// (Measured: 654-656 us per frame against 654-661 with region = blockIdx.x -- the
+	// sc1 mailbox traffic mostly bypasses L2 either way.)
+	int region;
+	{
+		const int n = gridDim.x, x = blockIdx.x & 7;
+		int start = 0;
+		for (int y = 0; y < x; ++y) start += (n - y + 7) >> 3;
+		region = start + (blockIdx.x >> 3);
+	}
+	const int gxr = region % p.GX;
+	const int gyr = region / p.GX;
+	const int x0 = gxr * kResRW;
+	const int y0 = gyr * p.RH;
+	const int rwv = min(kResRW, p.W - x0);  // valid columns / rows of this region
+	const int rhv = min(p.RH, p.H - y0);
+	volatile int *failFlag = reinterpret_cast<volatile int *>(smem + kResOffMisc);
+	float *ldsBias = reinterpret_cast<float *>(smem + kResOffMisc + 64);
+	const unsigned genTag = (*p.gen) << 8;  // uniform; never matches a previous launch
+
+	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (__attribute__((address_space(3))) unsigned char *)smem));
+
+	// ---- zero both buffers (border, out-of-image area and overrun pads stay zero) ----
+	for (int i = tid; i < kResOffMisc / 16; i += 256) {
+		reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+	}
+	if (tid == 0) *failFlag = 0;
+	__syncthreads();
+
+	// ---- first layer's input: region + halo straight from the complete global tensor;
+	//      pixels outside the image stay zero (the buffers were just cleared) ----
+	{
+		const T *in = static_cast<const T *>(p.in);
+		const int nPix = (rhv + 2) * kResPitch;
+		const int nInstr = (nPix + 7) / 8;  // 8 pixels (1 KiB) per wave-instruction, rows back to back
+		for (int i = wave; i < nInstr; i += 4) {
+			const int q = i * 8 + (lane >> 3);
+			const int rr = q / kResPitch, cc = q - rr * kResPitch;
+			const int c = (lane & 7) ^ ((cc >> 1) & 7);
+			const int gy = y0 - 1 + rr, gx = x0 - 1 + cc;
+			if (q < nPix && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+				glds16(in + ((size_t)gy * p.inPitch + gx) * 64 + c * 8, smem + kResOffA + i * 1024);
+			}
+		}
+	}
+
+	// ---- register-resident weights: A fragment f = (dy*3+dx)*4+ks of this wave's cout half ----
+	// Buffer loads: per-lane byte offset in ONE VGPR, fragment/layer offset scalar, so
+	// a load costs no address VALU and no temporaries (a flat load 2048*f bytes away is
+	// out of immediate range and needs a 64-bit add per load).
+	typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+	const __amdgpu_buffer_rsrc_t wRsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    const_cast<void *>(p.weights), 0, p.nLayers * 73728, 0x00020000);
+	const unsigned wLaneOff = (unsigned)((hh * 64 + ch * 32 + px) * 16);
+	auto loadWeightFrag = [&](int layer, int f) -> Vec8<T> {
+		const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(wRsrc, wLaneOff, layer * 73728 + f * 2048, 0);
+		return __builtin_bit_cast(Vec8<T>, v);
+	};
+	Vec8<T> w0[36], w1[36];
+	auto loadWeights = [&](int layer, Vec8<T>(&w)[36]) {
+#pragma unroll
+		for (int f = 0; f < 36; ++f) w[f] = loadWeightFrag(layer, f);
+	};
+	loadWeights(0, w0);
+	float biasNext = 0.f;  // wave 0: next layer's bias in flight (one value per lane)
+	if (wave == 0) ldsBias[lane] = p.bias[lane];
+
+	// per-lane LDS address parts (the swizzle depends only on the column: rows are 32 px)
+	// B fragment of macro-step (dx, ks): byte offset inside a row =
+	// colBase[dx] + (((ks*2+hh) ^ colSwz[dx]) << 4); 6 registers instead of 12
+	unsigned colBase[3], colSwz[3];
+#pragma unroll
+	for (int dx = 0; dx < 3; ++dx) {
+		const int cq = px + dx;
+		colBase[dx] = cq * 128;
+		colSwz[dx] = (cq >> 1) & 7;
+	}
+	unsigned outsw[4];  // [g]: byte offset of this lane's 4 output channels inside a row
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		const int cq = px + 1;
+		outsw[g] = cq * 128 + (((ch * 4 + g) ^ ((cq >> 1) & 7)) << 4) + hh * 8;
+	}
+
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+
+	// VARIANT 4 (diagnostic build only): per-wave cycle sums of the phases below
+	u64 prof[7] = {0, 0, 0, 0, 0, 0, 0};
+	auto stamp = [&]() -> u64 {
+		if constexpr (VARIANT == 4) {
+			__builtin_amdgcn_sched_barrier(0);
+			u64 t;
+			asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+			__builtin_amdgcn_sched_barrier(0);
+			return t;
+		} else {
+			return 0;
+		}
+	};
+	// ------------------------------------------------------------------------
+	// one convolution layer over the region: in/out are LDS buffer offsets
+	// ------------------------------------------------------------------------
+	auto computeLayer = [&](auto residualTag, const int layer, const int inOff, const int outOff,
+	                        const Vec8<T>(&w)[36]) {
+		constexpr bool residual = decltype(residualTag)::value;
+
+		const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
+
+		// rows of this wave: full pairs j = rp, rp+2, ... and, for an odd region
+		// height, the last row as a single-row unit on the wave group with fewer pairs
+		const int np2 = rhv >> 1;
+		const int nUnits = np2 + (rhv & 1);
+		Vec8<T> fb[2][4];
+		auto issue = [&](unsigned rowAddr, int m, int set, int j) {
+			const int dx = m >> 2, ks = m & 3;
+			const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
+			if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
+			else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4352" : "=v"(fb[set][1]) : "v"(a));
+			else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8704" : "=v"(fb[set][2]) : "v"(a));
+			else asm volatile("ds_read_b128 %0, %1 offset:13056" : "=v"(fb[set][3]) : "v"(a));
+		};
+		auto rowAddrOf = [&](int unit) { return ldsBase + inOff + (2 * unit) * kResRowBytes; };
+
+		// ROWS = 2: a row pair; ROWS = 1: the odd last row.  `primed`: this unit's
+		// first 4 fragments were already issued by the previous unit's last step.
+		auto unitBody = [&](auto rowsTag, const int unit, const bool primed, const int nextUnit) {
+			constexpr int ROWS = decltype(rowsTag)::value;
+			const u64 tu0 = stamp();
+			constexpr int NR = ROWS + 2;      // input rows / fragment reads per macro-step
+			constexpr int NM = 3 * ROWS;      // MFMAs per macro-step
+			const int ra = 1 + 2 * unit;      // first output row (buffer row index)
+			f32x16 acc[ROWS];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const f32x4 bg = *reinterpret_cast<const f32x4 *>(biasPtr + 8 * g);
+#pragma unroll
+				for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = bg[i];
+				}
+			}
+			const unsigned rowAddr = rowAddrOf(unit);
+			if (!(VARIANT & 2)) {
+				if (!primed) {
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int j = 0; j < NR; ++j) issue(rowAddr, 0, 0, j);
+				}
+#pragma unroll
+				for (int m = 0; m < 12; ++m) {
+					const int set = m & 1;
+					const bool more = (m + 1 < 12);
+					const int dx = m >> 2, ks = m & 3;
+#pragma unroll
+					for (int k = 0; k < NM; ++k) {
+						// MFMA k = (dy, r): ROWS=2 -> (k>>1, k&1); ROWS=1 -> (k, 0); it needs
+						// fragment r+dy, fragments are read (and return) in order 0..NR-1
+						const int dy = ROWS == 2 ? (k >> 1) : k;
+						const int r = ROWS == 2 ? (k & 1) : 0;
+						const int need = r + dy;
+						const bool fresh = ROWS == 2 ? (k == 0 || k == 1 || k == 3 || k == 5) : true;
+						if (fresh) {
+							// outstanding allowed = younger reads of this step + next step's issued so far
+							const int issuedNext = more ? (k < NR ? k : NR) : 0;
+							const int allowed = (NR - 1 - need) + issuedNext;
+							if (allowed >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+							else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+							else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+							else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+							else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+							__builtin_amdgcn_sched_barrier(0);
+						}
+						acc[r] = mfma32(w[(dy * 3 + dx) * 4 + ks], fb[set][need], acc[r]);
+						if (more && k < NR) issue(rowAddr, m + 1, set ^ 1, k);
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				}
+				// prime the next unit (always a pair or single with >= 3 input rows): its
+				// first fragments travel while this unit's epilogue runs
+				if (nextUnit >= 0) {
+					const unsigned na = rowAddrOf(nextUnit);
+					const bool nextSingle = (nextUnit == np2);
+#pragma unroll
+					for (int j = 0; j < 3; ++j) issue(na, 0, 0, j);
+					if (!nextSingle) issue(na, 0, 0, 3);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			const u64 tu1 = stamp();
+			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
+			// (row ra + r <= rhv always: units are whole pairs, or the odd last row)
+			if (px < rwv) {
+				// The residual is read-modify-write in place.  All reads of the unit
+				// first, then the arithmetic and the writes: left to the compiler every
+				// group is read -> wait -> write -> next read (it cannot prove the groups
+				// do not alias), i.e. 8 exposed LDS round trips per unit.
+				Vec4<T> rv[ROWS][4];
+				if (residual) {
+#pragma unroll
+					for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+						for (int g = 0; g < 4; ++g) {
+							rv[r][g] = *reinterpret_cast<const Vec4<T> *>(
+							    smem + outOff + (ra + r) * kResRowBytes + outsw[g]);
+						}
+					}
+					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				}
+#pragma unroll
+				for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						float v[4];
+#pragma unroll
+						for (int i = 0; i < 4; ++i) v[i] = acc[r][4 * g + i];
+						if (residual) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[r][g][i]);
+						}
+						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
+						    static_cast<T>(v[3])};
+						*reinterpret_cast<Vec4<T> *>(smem + outOff + (ra + r) * kResRowBytes + outsw[g]) =
+						    reluPacked<T>(o);
+					}
+				}
+			}
+			const u64 tu2 = stamp();
+			prof[5] += tu1 - tu0;
+			prof[6] += tu2 - tu1;
+		};
+
+		// pairs u = rp, rp+2, ... ; the odd last row goes to the wave group with fewer
+		// pairs (group 0 when both have the same number)
+		using R2 = std::integral_constant<int, 2>;
+		using R1 = std::integral_constant<int, 1>;
+		const bool mySingle = (rhv & 1) && rp == (np2 & 1);
+		bool primed = false;
+		for (int u = rp; u < np2; u += 2) {
+			const int nu = (u + 2 < np2) ? u + 2 : (mySingle ? np2 : -1);
+			unitBody(R2{}, u, primed, nu);
+			primed = nu >= 0 && !(VARIANT & 2);
+		}
+		if (mySingle) unitBody(R1{}, np2, primed, -1);
+		(void)nUnits;
+	};
+
+	// ------------------------------------------------------------------------
+	// edge ring -> mailbox (publish) and neighbours' mailboxes -> halo ring
+	// ------------------------------------------------------------------------
+	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * kResMailSlots * 16), 0x00020000);
+	constexpr int kSc1 = 16;  // cache-policy bit of sc1 (write-through store / L2-bypassing load)
+	// LDS address of 16-byte chunk c of pixel (rr, cc) in buffer `off`
+	auto ldsChunk = [&](int off, int rr, int cc, int c) -> unsigned char * {
+		return smem + off + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4);
+	};
+	// Self-validating slots: every tower output is post-ReLU (>= 0), so the sign bit
+	// of each of the 8 values in a 16-byte slot is free; it carries one bit of an
+	// 8-bit epoch tag {generation & 3, layer + 1}.  Consecutive writes to the same
+	// slot (layers l-2, l, l+2, ... and the previous launch) always differ in tag,
+	// so a consumer can tell "new" from "old" from the payload itself and the
+	// producer needs neither a drain nor a release: ONE hop instead of
+	// store-ack -> flag -> load.  The flag below is only a hint that keeps 65k
+	// threads from polling the fabric before the data can possibly be there.
+	auto tagMasks = [&](int layer, u32x4 *m) {
+		const unsigned t = ((genTag >> 8) & 3u) << 6 | (unsigned)((layer + 1) & 63);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			(*m)[k] = ((t >> (2 * k)) & 1u) << 15 | ((t >> (2 * k + 1)) & 1u) << 31;
+		}
+	};
+	// `layer`: the layer whose output (in buffer `off`) is published
+	auto publish = [&](int off, int layer) {
+		// (the caller has just passed the workgroup barrier: the region's output is in LDS)
+		u32x4 tm;
+		tagMasks(layer, &tm);
+		const unsigned base = (unsigned)((region * 2 + ((layer + 1) & 1)) * kResMailSlots) * 16u;
+#pragma unroll
+		for (int it = 0; it < kResMailSlots / 256; ++it) {
+			const int idx = it * 256 + tid;
+			const int strip = idx >> 8, e = (idx >> 3) & 31, c = idx & 7;
+			int rr, cc;
+			bool valid;
+			if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
+			else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
+			else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
+			else { rr = e + 1; cc = rwv; valid = e < rhv; }
+			if (valid) {
+				u32x4 v = *reinterpret_cast<const u32x4 *>(ldsChunk(off, rr, cc, c));
+				v = (v & 0x7fff7fffu) | tm;
+				__builtin_amdgcn_raw_buffer_store_b128(v, mailRsrc, base + idx * 16, 0, kSc1);
+			}
+		}
+		if (tid == 0) {  // hint only: no drain, no barrier
+			__hip_atomic_store((gu32 *)(p.flag + region), genTag | (unsigned)(layer + 1),
+			    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	};
+	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
+	// returns false on timeout (uniform across the workgroup)
+	constexpr bool kUseHint = false;  // measured: polling a hint flag first is not faster than sweeping
+	auto fillHalo = [&](int off, int layer) -> bool {
+		const unsigned want = genTag | (unsigned)(layer + 1);
+		(void)want;
+		const u64 t0 = __builtin_amdgcn_s_memrealtime();
+		if (wave == 0 && kUseHint) {
+			bool ready = true;
+			const gu32 *f = nullptr;
+			if (lane < 8) {
+				const int k = lane < 4 ? lane : lane + 1;  // skip the centre of the 3x3
+				const int nx = gxr + (k % 3) - 1, ny = gyr + (k / 3) - 1;
+				if (nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY) {
+					f = (const gu32 *)(p.flag + ny * p.GX + nx);
+					ready = false;
+				}
+			}
+			while (!__all(ready)) {
+				if (!ready) {
+					const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					ready = (v - want) <= 1u;  // a neighbour is at most one layer ahead
+				}
+				if (__builtin_amdgcn_s_memrealtime() - t0 > kResTimeoutTicks) break;  // the sweep reports it
+				__builtin_amdgcn_s_sleep(1);
+			}
+		}
+		if (kUseHint) __syncthreads();
+		const int par = (layer + 1) & 1;
+		u32x4 tm;
+		tagMasks(layer, &tm);
+		constexpr int NS = kResMailSlots / 256 + 1;  // 4 sides x 32 entries x 8 chunks, + the 4 corners
+		unsigned hsrc[NS];
+		unsigned char *hd[NS];
+		unsigned pending = 0;
+#pragma unroll
+		for (int it = 0; it < NS; ++it) {
+			int nx = gxr, ny = gyr, strip, se, rr, cc, c;
+			bool valid;
+			if (it < NS - 1) {
+				const int idx = it * 256 + tid;
+				const int hp = idx >> 3;
+				c = idx & 7;
+				const int side = hp >> 5, e = hp & 31;
+				// side 0: row above, 1: row below, 2: column left, 3: column right
+				if (side < 2) {
+					ny += side == 0 ? -1 : 1;
+					strip = side == 0 ? 1 : 0;  // their bottom row / their top row
+					rr = side == 0 ? 0 : rhv + 1;
+					se = e;
+					cc = e + 1;
+					valid = e < rwv;
+				} else {
+					nx += side == 2 ? -1 : 1;
+					strip = side == 2 ? 3 : 2;  // their right column / their left column
+					se = e;
+					rr = e + 1;
+					cc = side == 2 ? 0 : rwv + 1;
+					valid = e < rhv;
+				}
+			} else {
+				// corners: threads 0..31 = 4 corners x 8 chunks; the diagonal neighbour's
+				// bottom/top row strip, last/first entry (interior columns are 32 wide)
+				const int k = tid >> 3;
+				c = tid & 7;
+				const bool up = k < 2, left = (k & 1) == 0;
+				ny += up ? -1 : 1;
+				nx += left ? -1 : 1;
+				strip = up ? 1 : 0;
+				se = left ? kResRW - 1 : 0;
+				rr = up ? 0 : rhv + 1;
+				cc = left ? 0 : rwv + 1;
+				valid = tid < 32;
+			}
+			valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
+			const int nreg = valid ? ny * p.GX + nx : region;
+			hsrc[it] = (unsigned)((nreg * 2 + par) * kResMailSlots + (strip * 32 + se) * 8 + c) * 16u;
+			hd[it] = ldsChunk(off, rr, cc, c);
+			if (valid) pending |= 1u << it;
+		}
+		// sweep: all loads of a pass in flight together, sc1 (never a stale L1/L2 line);
+		// a slot is accepted only when all 8 tag bits match
+		while (__any(pending != 0)) {
+			u32x4 hv[NS];
+#pragma unroll
+			for (int it = 0; it < NS; ++it) {
+				hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, hsrc[it], 0, kSc1);
+			}
+#pragma unroll
+			for (int it = 0; it < NS; ++it) {
+				const u32x4 tg = hv[it] & 0x80008000u;
+				const bool ok = tg[0] == tm[0] && tg[1] == tm[1] && tg[2] == tm[2] && tg[3] == tm[3];
+				if ((pending >> it & 1u) && ok) {
+					*reinterpret_cast<u32x4 *>(hd[it]) = hv[it] & 0x7fff7fffu;
+					pending &= ~(1u << it);
+				}
+			}
+			if (pending != 0) {
+				if (__builtin_amdgcn_s_memrealtime() - t0 > kResTimeoutTicks) {
+					*failFlag = 1;
+					__hip_atomic_store((gu32 *)p.error, 0x700u + (unsigned)layer, __ATOMIC_RELAXED,
+					    __HIP_MEMORY_SCOPE_SYSTEM);
+					break;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+		}
+		__syncthreads();
+		return *failFlag == 0;
+	};
+
+	// ------------------------------------------------------------------------
+	// the tower: conv1 X->T (weights w0), conv2 T->X (+X) (weights w1)
+	// ------------------------------------------------------------------------
+	// Layer i reads buffer (i even ? A : B) and writes the other one: conv1 X->T, and
+	// conv2 T->X adds the residual already sitting in its output buffer.  With a head
+	// layer (generator conv_1) everything shifts by one.  Layer i uses weight set i&1.
+	const int L = p.nLayers;
+	// RES / PAR are compile-time: a runtime `if (residual)` around the epilogue's LDS
+	// read makes hipcc branch and wait per element (+1 us per layer, measured).
+	auto layerStep = [&](auto resTag, auto parTag, const int i, const Vec8<T>(&wc)[36],
+	                     Vec8<T>(&wn)[36]) -> bool {
+		constexpr int PAR = decltype(parTag)::value;
+		constexpr int inOff = PAR ? kResOffB : kResOffA;
+		constexpr int outOff = PAR ? kResOffA : kResOffB;
+		const bool more = i + 1 < L;
+		const u64 t0 = stamp();
+		// vmcnt is in-order: the next layer's weight stream (36 loads per lane) is issued
+		// AFTER the halo loads so they never queue behind it, and lands behind the MFMAs.
+		if (i > 0 && xchg) {
+			if (!fillHalo(inOff, i - 1)) return false;
+		}
+		const u64 t1 = stamp();
+		// (Interleaving these 36 loads into the first unit's MFMA loop was tried: the
+		// burst costs ~2.2k cycles of issue stall per layer -- four waves push 144 KB
+		// through the CU's 64 B/clk address path -- but the interleaved form was no
+		// faster end to end and doubled the code.)
+		if (more) {
+			loadWeights(i + 1, wn);
+			if (wave == 0) biasNext = p.bias[(i + 1) * 64 + lane];
+		}
+		const u64 t2 = stamp();
+		computeLayer(resTag, i, inOff, outOff, wc);
+		const u64 t3 = stamp();
+		if (more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
+		if (more && xchg) {
+			__syncthreads();  // (publish starts with this barrier; split out for the profile)
+			const u64 t4 = stamp();
+			publish(outOff, i);
+			const u64 t5 = stamp();
+			prof[3] += t4 - t3;
+			prof[4] += t5 - t4;
+		} else {
+			__syncthreads();
+		}
+		prof[0] += t1 - t0;
+		prof[1] += t2 - t1;
+		prof[2] += t3 - t2;
+		return true;
+	};
+	using No = std::false_type;
+	using Yes = std::true_type;
+	using P0 = std::integral_constant<int, 0>;
+	using P1 = std::integral_constant<int, 1>;
+	if (HEAD) {  // conv_1, then (conv1, conv2+skip) pairs: L is odd
+		if (!layerStep(No{}, P0{}, 0, w0, w1)) return;
+		for (int i = 1; i + 1 < L; i += 2) {
+			if (!layerStep(No{}, P1{}, i, w1, w0)) return;
+			if (!layerStep(Yes{}, P0{}, i + 1, w0, w1)) return;
+		}
+	} else {  // (conv1, conv2+skip) pairs: L is even
+		for (int i = 0; i + 1 < L; i += 2) {
+			if (!layerStep(No{}, P0{}, i, w0, w1)) return;
+			if (!layerStep(Yes{}, P1{}, i + 1, w1, w0)) return;
+		}
+	}
+	const int finalOff = (L & 1) ? kResOffB : kResOffA;
+	if constexpr (VARIANT == 4) {
+		if (lane == 0 && p.debug != nullptr) {
+			for (int k = 0; k < 7; ++k) p.debug[(region * 4 + wave) * 8 + k] = prof[k];
+		}
+	}
+
+	// ---- last block output: region interior -> global tower-layout tensor ----
+	{
+		T *out = static_cast<T *>(p.out);
+		for (int i = tid; i < rhv * kResRW * 8; i += 256) {
+			const int c = i & 7;
+			const int pxl = (i >> 3) % kResRW;
+			const int row = (i >> 3) / kResRW;
+			if (pxl < rwv) {
+				const int rr = row + 1, cc = pxl + 1;
+				const uint4 v = *reinterpret_cast<const uint4 *>(
+				    smem + finalOff + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
+				*reinterpret_cast<uint4 *>(
+				    out + ((size_t)(y0 + rr) * p.pitch + x0 + cc) * 64 + c * 8) = v;
+			}
+		}
+	}
+}
+
+template <typename T, int VARIANT, bool HEAD>
+void launchResidentT(const ResidentParams &p, hipStream_t stream) {
+	auto kern = tower_resident_kernel<T, VARIANT, HEAD>;
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kResLds, &ldsDone, "resident tower");
+	if (p.bumpGeneration) {
+		hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream,
+		    const_cast<unsigned *>(p.gen));
+	}
+	// (g_ResidentFault > 0, tests only: some regions are never computed, their neighbours'
+	// bounded waits expire and the error path runs)
+	const int grid = p.GX * p.GY - (g_ResidentFault < p.GX * p.GY ? g_ResidentFault : 0);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kResLds, stream, p);
+	hipCheckLaunch("tower_resident");
+}
+
+}  // namespace
+
+void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
+	const int pitch = towerPitch(p.W);
+	const bool fits = p.taps == 9 && p.cin == 64 && p.cout == 64 && !p.outF32 && p.nb == 2 &&
+	                  p.inPitch == pitch && p.outPitch == pitch &&
+	                  (p.res == nullptr || p.resPitch == pitch);
+	if (!fits) {
+		launchConv(dt, p, stream);
+		return;
+	}
+	if (dt == kF16) {
+		launchTowerT<f16, 0>(p, stream);
+		return;
+	}
+	switch (g_TowerVariant) {
+	case 1: launchTowerT<bf16, 1>(p, stream); break;
+	case 2: launchTowerT<bf16, 2>(p, stream); break;
+	case 3: launchTowerT<bf16, 3>(p, stream); break;
+	case 4: launchTowerT<bf16, 4>(p, stream); break;
+	default: launchTowerT<bf16, 0>(p, stream); break;
+	}
+}
+
+void setTowerVariant(int v) { g_TowerVariant = v; }
+void setResidentFault(int n) { g_ResidentFault = n; }
+
+void launchBumpGeneration(unsigned *generation, hipStream_t stream) {
+	hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream, generation);
+	hipCheckLaunch("bump_generation");
+}
+
+bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH) {
+	const int gx = (W + kResRW - 1) / kResRW;
+	const int gy = (H + kResMaxRH - 1) / kResMaxRH;
+	if (gx * gy > numCUs) return false;
+	*GX = gx;
+	*GY = gy;
+	*RH = (H + gy - 1) / gy;  // <= kResMaxRH, balances the last row of regions
+	return true;
+}
+
+std::size_t residentMailboxBytes(int GX, int GY) {
+	return static_cast<std::size_t>(GX) * GY * 2 * kResMailSlots * 16;
+}
+
+void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t stream) {
+	ResidentParams p{};
+	const std::size_t origin = towerOrigin(q.W) * 64 * 2;
+	p.in = q.in;
+	p.inPitch = q.inPitch ? q.inPitch : q.W;
+	p.hasHead = q.hasHead;
+	p.out = static_cast<unsigned char *>(q.out) - origin;
+	p.weights = q.weights;
+	p.bias = q.bias;
+	p.mail = static_cast<uint4 *>(q.mailbox);
+	p.gen = q.generation;
+	p.flag = q.generation + 16;  // same small buffer: word 0 = generation, flags from byte 64
+	p.debug = static_cast<unsigned long long *>(q.debug);
+	p.error = q.error;
+	p.H = q.H;
+	p.W = q.W;
+	p.pitch = towerPitch(q.W);
+	p.GX = q.GX;
+	p.GY = q.GY;
+	p.RH = q.RH;
+	p.nLayers = q.nLayers;
+	p.bumpGeneration = q.bumpGeneration;
+	if ((p.nLayers & 1) != (p.hasHead ? 1 : 0)) {
+		throw std::invalid_argument("resident tower: layer count must be 2*blocks (+1 with a head)");
+	}
+	if (!p.hasHead) {
+		if (dt == kF16) launchResidentT<f16, 0, false>(p, stream);
+		else launchResidentT<bf16, 0, false>(p, stream);
+		return;
+	}
+	if (dt == kF16) {
+		launchResidentT<f16, 0, true>(p, stream);
+		return;
+	}
+	switch (g_TowerVariant) {
+	case 1: launchResidentT<bf16, 1, true>(p, stream); break;
+	case 2: launchResidentT<bf16, 2, true>(p, stream); break;
+	case 3: launchResidentT<bf16, 3, true>(p, stream); break;
+	case 4: launchResidentT<bf16, 4, true>(p, stream); break;
+	default: launchResidentT<bf16, 0, true>(p, stream); break;
+	}
+}
+
+
+}  // namespace ju

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "joshupscale_amd/csrc/kernels.hip")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "joshupscale_amd/csrc/tower_kernels.hip")
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
        f"-I{root}/include", f"-I{root}/joshupscale_amd/csrc", "-c", src, "-o", "/dev/null",
