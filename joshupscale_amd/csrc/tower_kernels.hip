@@ -478,10 +478,25 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(wRsrc, wLaneOff, layer * 73728 + f * 2048, 0);
 		return __builtin_bit_cast(Vec8<T>, v);
 	};
-	Vec8<T> w0[36], w1[36];
-	auto loadWeights = [&](int layer, Vec8<T>(&w)[36]) {
+	// Fragment f = (dy*3+dx)*4+ks is first used in macro-step dx*4+ks of a layer's first
+	// unit.  The 24 fragments with dx < 2 are double-buffered (the next layer's set is
+	// fetched during the current layer); the 12 with dx = 2 are needed only ~1.6k cycles
+	// into the layer, so ONE set suffices: it is refilled at the head of its own layer
+	// and lands behind the first eight macro-steps.  48 registers less than two full sets.
+	Vec8<T> w0[24], w1[24], wl[12];
+	auto earlyIdx = [](int f) { return (f / 12) * 8 + (f % 12); };      // dx < 2: f % 12 < 8
+	auto lateIdx = [](int f) { return (f / 12) * 4 + (f % 12) - 8; };   // dx = 2
+	auto loadWeights = [&](int layer, Vec8<T>(&w)[24]) {
 #pragma unroll
-		for (int f = 0; f < 36; ++f) w[f] = loadWeightFrag(layer, f);
+		for (int f = 0; f < 36; ++f) {
+			if (f % 12 < 8) w[earlyIdx(f)] = loadWeightFrag(layer, f);
+		}
+	};
+	auto loadLateWeights = [&](int layer) {
+#pragma unroll
+		for (int f = 0; f < 36; ++f) {
+			if (f % 12 >= 8) wl[lateIdx(f)] = loadWeightFrag(layer, f);
+		}
 	};
 	loadWeights(0, w0);
 	float biasNext = 0.f;  // wave 0: next layer's bias in flight (one value per lane)
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// one convolution layer over the region: in/out are LDS buffer offsets
 	// ------------------------------------------------------------------------
 	auto computeLayer = [&](auto residualTag, const int layer, const int inOff, const int outOff,
-	                        const Vec8<T>(&w)[36]) {
+	                        const Vec8<T>(&w)[24]) {
 		constexpr bool residual = decltype(residualTag)::value;
 
 		const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
@@ -594,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 							else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 							__builtin_amdgcn_sched_barrier(0);
 						}
-						acc[r] = mfma32(w[(dy * 3 + dx) * 4 + ks], fb[set][need], acc[r]);
+						acc[r] = mfma32(dx < 2 ? w[dy * 8 + dx * 4 + ks] : wl[dy * 4 + ks], fb[set][need], acc[r]);
 						if (more && k < NR) issue(rowAddr, m + 1, set ^ 1, k);
 						__builtin_amdgcn_sched_barrier(0);
 					}
@@ -841,8 +856,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int L = p.nLayers;
 	// RES / PAR are compile-time: a runtime `if (residual)` around the epilogue's LDS
 	// read makes hipcc branch and wait per element (+1 us per layer, measured).
-	auto layerStep = [&](auto resTag, auto parTag, const int i, const Vec8<T>(&wc)[36],
-	                     Vec8<T>(&wn)[36]) -> bool {
+	auto layerStep = [&](auto resTag, auto parTag, const int i, const Vec8<T>(&wc)[24],
+	                     Vec8<T>(&wn)[24]) -> bool {
 		constexpr int PAR = decltype(parTag)::value;
 		constexpr int inOff = PAR ? kResOffB : kResOffA;
 		constexpr int outOff = PAR ? kResOffA : kResOffB;
@@ -858,6 +873,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		// burst costs ~2.2k cycles of issue stall per layer -- four waves push 144 KB
 		// through the CU's 64 B/clk address path -- but the interleaved form was no
 		// faster end to end and doubled the code.)
+		loadLateWeights(i);  // this layer's dx = 2 fragments: first used in macro-step 8
 		if (more) {
 			loadWeights(i + 1, wn);
 			if (wave == 0) biasNext = p.bias[(i + 1) * 64 + lane];
