@@ -455,3 +455,25 @@ def test_resident_tower_failure_falls_back_to_the_per_layer_path(monkeypatch):
     assert any(lvl == 1 and b"per-layer" in msg for lvl, msg in seen), seen
     assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(want, got))
     rt.close()
+
+
+def test_full_size_run_is_deterministic():
+    """The halo exchange of the resident tower is timing-dependent (retries, neighbours
+    running a layer ahead); its result must not be: two runs of 200 frames on the
+    full benchmark model give byte-identical frames (tests/soak_determinism.py is
+    the long form)."""
+    import hashlib
+    cfg = M.PRESETS["psp-quality"]
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    clip = M.synthetic_frames(8, cfg.frame_height, cfg.frame_width, seed=7, kind="smooth")
+    digests = []
+    for _ in range(2):
+        rt = R.Runtime(blob, 0, R.DTYPE_BF16)
+        h = hashlib.sha256()
+        for i in range(200):
+            out = rt.process_image(clip[i % 8])
+            if i % 20 == 19:
+                h.update(out.tobytes())
+        digests.append(h.hexdigest())
+        rt.close()
+    assert digests[0] == digests[1]
