@@ -148,7 +148,8 @@ JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double
     int *launches, double *flops);
 
 /* Developer switches (timing ablations and fault injection; never needed by a
- * caller).  Keys: "tower_variant" 0..4 (0 = product kernel); "resident_fault" n
+ * caller).  Keys: "tower_variant" 0..5 (0 = product kernel, 4 = phase profile, 5 =
+ * per-layer output maxima for quantisation calibration); "resident_fault" n
  * (launch the resident tower n workgroups short: tests the fallback). */
 JU_API int ju_debug_set(const char *key, int value);
 

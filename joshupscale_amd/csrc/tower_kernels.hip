@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 
 	// VARIANT 4 (diagnostic build only): per-wave cycle sums of the phases below
 	u64 prof[7] = {0, 0, 0, 0, 0, 0, 0};
+	float calibMax = 0.f;  // VARIANT 5: largest post-ReLU output of the current layer (this lane)
 	auto stamp = [&]() -> u64 {
 		if constexpr (VARIANT == 4) {
 			__builtin_amdgcn_sched_barrier(0);
@@ -655,6 +656,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 						if (residual) {
 #pragma unroll
 							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[r][g][i]);
+						}
+						if constexpr (VARIANT == 5) {  // calibration build: range of the layer's output
+#pragma unroll
+							for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, v[i]);
 						}
 						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
 						    static_cast<T>(v[3])};
@@ -880,6 +885,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 		const u64 t2 = stamp();
 		computeLayer(resTag, i, inOff, outOff, wc);
+		if constexpr (VARIANT == 5) {
+			// per-layer maximum over the frame -> debug[i] (non-negative floats order like
+			// their bit patterns, so an integer atomic max does it)
+			float m = calibMax;
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+			if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(p.debug) + i, __float_as_uint(m));
+			calibMax = 0.f;
+		}
 		const u64 t3 = stamp();
 		if (more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
 		if (more && xchg) {
@@ -1039,6 +1053,10 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	case 2: launchResidentT<bf16, 2, true>(p, stream); break;
 	case 3: launchResidentT<bf16, 3, true>(p, stream); break;
 	case 4: launchResidentT<bf16, 4, true>(p, stream); break;
+	case 5:  // calibration: per-layer output maxima of this frame in debug[0 .. nLayers)
+		(void)hipMemsetAsync(p.debug, 0, static_cast<std::size_t>(p.nLayers) * sizeof(unsigned), stream);
+		launchResidentT<bf16, 5, true>(p, stream);
+		break;
 	default: launchResidentT<bf16, 0, true>(p, stream); break;
 	}
 }

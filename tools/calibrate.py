@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Activation ranges of a model over a clip: the input of an 8-bit (int8 / fp8 e4m3)
+build of the convolutions (the reference's TensorRT flow is
+scripts/inference/tensorrt/generate_calibration.py + quantize_int8.py: symmetric
+per-tensor activation scales, per-channel weight scales).
+
+Tower: the resident kernel's calibration variant records the largest post-ReLU output
+of each of its layers per frame (ju_debug_set("tower_variant", 5)); flow net and
+generator input: max |x| of the materialised tensors (ju_read_tensor).  Needs a GPU.
+
+usage: tools/calibrate.py [--preset psp-quality] [--frames 16] [--kind smooth] > ranges.json
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+os.environ["JU_NO_GRAPH"] = "1"  # eager launches: the variant switch acts on new launches only
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from joshupscale_amd import model_file as M, runtime as R  # noqa: E402
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="psp-quality")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--kind", default="smooth", choices=["smooth", "noise"])
+    args = ap.parse_args()
+    cfg = M.PRESETS[args.preset]
+    weights = M.make_seeded_weights(cfg)
+    rt = R.Runtime(M.serialize(cfg, weights), 0, R.DTYPE_BF16)
+    lib = R.load_library()
+    n_layers = 1 + 2 * cfg.gen_blocks
+    clip = M.synthetic_frames(args.frames, cfg.frame_height, cfg.frame_width, seed=99, kind=args.kind)
+    tower = np.zeros(n_layers, np.float64)
+    others = {}
+    names = ["gen_in", "flow"] + [f"flow/block_{i + 1}/a_1" for i in range(len(cfg.flow_filters) - 1)]
+    if lib.ju_debug_set(b"tower_variant", 5) != 0:
+        raise SystemExit(lib.ju_last_error().decode())
+    try:
+        for f in clip:
+            rt.process_image(f)
+            m = rt.read_tensor("tower_profile")[:n_layers].view(np.float32).astype(np.float64)
+            tower = np.maximum(tower, m)
+            for name in names:
+                try:
+                    v = float(np.abs(rt.read_tensor(name)).max())
+                except R.JoshUpscaleError:
+                    continue
+                others[name] = max(others.get(name, 0.0), v)
+    finally:
+        lib.ju_debug_set(b"tower_variant", 0)
+    rt.close()
+
+    def scales(amax):
+        return {"amax": round(amax, 6), "int8_scale": round(127.0 / amax, 4) if amax > 0 else None,
+                "e4m3_scale": round(448.0 / amax, 4) if amax > 0 else None}
+
+    layer_names = ["generator/conv_1"] + [f"generator/block_{i // 2 + 1}/conv_{i % 2 + 1}"
+                                          for i in range(2 * cfg.gen_blocks)]
+    w_amax = {}
+    for name in layer_names:
+        k = weights[name + "/kernel"]
+        w_amax[name] = float(np.abs(k).max())   # (per-output-channel scales come from the folded kernels)
+    report = {
+        "preset": args.preset, "clip": f"{args.frames} frames, {args.kind}, seed 99",
+        "note": "activation = largest post-ReLU output of the layer over the clip (tower: recorded in-kernel); "
+                "scale = full-range / amax, symmetric per tensor",
+        "tower_layers": {n: scales(float(a)) for n, a in zip(layer_names, tower)},
+        "other_tensors": {n: scales(a) for n, a in others.items()},
+        "weight_amax_unfolded": {n: round(a, 6) for n, a in w_amax.items()},
+    }
+    print(json.dumps(report, indent=1))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
