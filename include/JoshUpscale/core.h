@@ -40,39 +40,47 @@ namespace JoshUpscale {
 namespace core {
 
 // ---------------------------------------------------------------- logging --
-enum class LogLevel : std::uint8_t { INFO, WARNING, ERROR };
+// (uint8_t-backed, values 0, 1, 2: the plugins pass them through a virtual call)
+enum class LogLevel : std::uint8_t {
+	INFO,     // 0
+	WARNING,  // 1
+	ERROR     // 2
+};
 
 // Borrowed for the lifetime of the process once installed (OBS installs a
-// static instance: reference obs_plugin/src/plugin.cc:93-106).
+// static instance: reference obs_plugin/src/plugin.cc:93-106).  The only virtual
+// function is the call operator.
 struct LogSink {
-	virtual void operator()(const char *tag, LogLevel logLevel, const std::string &message) = 0;
+	virtual void operator()(const char *component, LogLevel severity, const std::string &text) = 0;
 };
 
 // nullptr restores the default console sink.
 JOSHUPSCALE_EXPORT void setLogSink(LogSink *sink);
 
 // ----------------------------------------------------------------- frames --
-enum class DataLocation : std::uint8_t { CPU, CUDA, GRAPHICS_RESOURCE };
+enum class DataLocation : std::uint8_t {
+	CPU,               // host pointer
+	CUDA,              // device pointer: a HIP device pointer in this runtime
+	GRAPHICS_RESOURCE  // not supported here
+};
 
 // 4 bytes per pixel, byte order B,G,R,X.  `stride` is in bytes and may be
 // negative (bottom-up frames); `ptr` addresses the first logical row.  The
-// memory is borrowed for the duration of processImage only.
+// memory is borrowed for the duration of processImage only.  Field order and
+// types are ABI: {pointer, 1-byte enum, signed stride, width, height}.
 struct Image {
 	void *ptr;
 	DataLocation location;
 	std::ptrdiff_t stride;
-	std::size_t width;
-	std::size_t height;
+	std::size_t width, height;
 };
 
 enum class GraphicsResourceImageType : std::uint8_t { INPUT, OUTPUT };
 
+// vtable: the destructor only; one Image member behind it.
 struct GraphicsResourceImage {
-	virtual ~GraphicsResourceImage() {
-	}
-	Image getImage() const {
-		return m_Image;
-	}
+	virtual ~GraphicsResourceImage() {}
+	Image getImage() const { return m_Image; }
 
 protected:
 	Image m_Image = {};
@@ -80,42 +88,33 @@ protected:
 
 // Both throw std::runtime_error in this runtime (see header comment).
 JOSHUPSCALE_EXPORT int getGLDeviceIndex();
-JOSHUPSCALE_EXPORT GraphicsResourceImage *getGLImage(
-    std::uint32_t image, GraphicsResourceImageType type);
+JOSHUPSCALE_EXPORT GraphicsResourceImage *getGLImage(std::uint32_t glTexture,
+    GraphicsResourceImageType role);
 
 // ---------------------------------------------------------------- runtime --
 // One recurrent super-resolution stream.  Not thread-safe; processImage is
-// synchronous and advances the recurrent state by one frame.
+// synchronous and advances the recurrent state by one frame.  vtable: destructor,
+// then processImage; the four sizes follow the vptr and are read by the inline
+// getters compiled into the CALLER.
 struct Runtime {
-	virtual ~Runtime() {
-	}
+	virtual ~Runtime() {}
+	virtual void processImage(const Image &lowRes, const Image &highRes) = 0;
 
-	virtual void processImage(const Image &inputImage, const Image &outputImage) = 0;
-
-	std::size_t getInputWidth() const {
-		return m_InputWidth;
-	}
-	std::size_t getInputHeight() const {
-		return m_InputHeight;
-	}
-	std::size_t getOutputWidth() const {
-		return m_OutputWidth;
-	}
-	std::size_t getOutputHeight() const {
-		return m_OutputHeight;
-	}
+	std::size_t getInputWidth() const { return m_Size[0]; }
+	std::size_t getInputHeight() const { return m_Size[1]; }
+	std::size_t getOutputWidth() const { return m_Size[2]; }
+	std::size_t getOutputHeight() const { return m_Size[3]; }
 
 protected:
-	std::size_t m_InputWidth = 0;
-	std::size_t m_InputHeight = 0;
-	std::size_t m_OutputWidth = 0;
-	std::size_t m_OutputHeight = 0;
+	// input width, input height, output width, output height (four consecutive
+	// size_t, the layout of the reference's four separate members)
+	std::size_t m_Size[4] = {0, 0, 0, 0};
 };
 
-// Caller owns the result and destroys it with `delete`.  `modelPath` names a
-// .jupw container (joshupscale_amd/model_file.py); TensorRT engines are
-// rejected with std::invalid_argument.
-JOSHUPSCALE_EXPORT Runtime *createRuntime(int deviceId, const std::filesystem::path &modelPath);
+// Caller owns the result and destroys it with `delete`.  `model` names a .jupw
+// container (joshupscale_amd/model_file.py); TensorRT engines are rejected with
+// std::invalid_argument.
+JOSHUPSCALE_EXPORT Runtime *createRuntime(int device, const std::filesystem::path &model);
 
 // Only valid inside a catch block: formats the exception being handled as
 // "Type: what()" with nested exceptions indented (reference

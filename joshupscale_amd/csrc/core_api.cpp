@@ -49,7 +49,7 @@ struct HipRuntime final : Runtime {
 	HipRuntime(int deviceId, const std::filesystem::path &modelPath) {
 		const int rc = ju_create(deviceId, modelPath.string().c_str(), &m_Handle);
 		if (rc != JU_OK) raise(rc);
-		ju_get_size(m_Handle, &m_InputWidth, &m_InputHeight, &m_OutputWidth, &m_OutputHeight);
+		ju_get_size(m_Handle, &m_Size[0], &m_Size[1], &m_Size[2], &m_Size[3]);
 	}
 	~HipRuntime() override {
 		ju_destroy(m_Handle);
