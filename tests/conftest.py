@@ -15,8 +15,16 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def hip_library():
-    """The in-tree HIP library; GPU tests fail loudly when it is not built."""
+    """The in-tree HIP library.  The product never builds or falls back by itself
+    (runtime.load_library raises when the .so is missing); the TEST session builds it
+    once when it is absent and hipcc is available, so a fresh checkout can run the CPU
+    suite (hipcc cross-compiles gfx950 without a GPU)."""
+    import shutil
+    import subprocess
     from joshupscale_amd import runtime
+    if "JU_LIBRARY" not in os.environ and not os.path.exists(runtime.library_path()):
+        if shutil.which("make") and os.path.exists("/opt/rocm/bin/hipcc"):
+            subprocess.check_call(["make", "-s", "-j8", "-C", ROOT])
     return runtime.load_library()
 
 
