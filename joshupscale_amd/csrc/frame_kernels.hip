@@ -427,11 +427,16 @@ __global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
 //            pixel (a' = g2, b' = hh).
 // One workgroup = 8 LR rows x 32 px (4 waves x 2 rows); outputs are staged in LDS
 // and written as whole rows, 16 B per lane.
-constexpr int kTailLdsIn = 8 * 32 * 128;          // 32 KiB input tile
+// LDS (72 KiB, two workgroups per CU): per wave ONE input row (4 KiB; the f16 state
+// rows of the output staging reuse it once stage 1 has consumed it), 16 KiB convT1
+// weights, per wave 8 KiB of mid pixels and 2 KiB of u8 output staging.
+constexpr int kTailLdsRow = 32 * 128;             // 4 KiB: one LR row of 32 px x 64 ch
+constexpr int kTailLdsIn = 4 * kTailLdsRow;       // one row per wave
 constexpr int kTailLdsW1 = 64 * 128 * 2;          // 16 KiB convT1 weights (fragment order)
 constexpr int kTailLdsMid = 4 * 4 * 32 * 64;      // per wave: 4 mid-pixel groups x 32 px x 64 B = 8 KiB
-constexpr int kTailLdsOut = 4 * (4 * 128 * 8 + 4 * 128 * 4);  // per wave: 4 HR rows x 128 px x (8 + 4) B
-constexpr int kTailLds = kTailLdsIn + kTailLdsW1 + kTailLdsMid + kTailLdsOut;
+constexpr int kTailLdsU8 = 4 * (4 * 128 * 4);     // per wave: 4 HR rows x 128 px x 4 B
+constexpr int kTailLds = kTailLdsIn + kTailLdsW1 + kTailLdsMid + kTailLdsU8;
+static_assert(4 * 128 * 8 == kTailLdsRow, "the f16 state staging (4 HR rows x 128 px x 8 B) overlays the input row");
 
 struct TailFusedParams {
 	const void *x;        // trunk, addressed at image pixel (0,0)
@@ -452,36 +457,37 @@ struct TailFusedParams {
 template <typename T>
 __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	unsigned char *smI = smem;
-	unsigned char *smW = smem + kTailLdsIn;
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
+	unsigned char *smRow = smem + wave * kTailLdsRow;  // this wave's current input row / state staging
+	unsigned char *smW = smem + kTailLdsIn;
 	unsigned char *smMid = smem + kTailLdsIn + kTailLdsW1 + wave * (kTailLdsMid / 4);
-	unsigned char *smOut = smem + kTailLdsIn + kTailLdsW1 + kTailLdsMid + wave * (kTailLdsOut / 4);
+	unsigned char *smU8 = smem + kTailLdsIn + kTailLdsW1 + kTailLdsMid + wave * (kTailLdsU8 / 4);
 	const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 8;
 	const T *__restrict__ x = static_cast<const T *>(p.x);
 	const float bright = brightnessOf(p.sums, 1.0f / static_cast<float>(p.H * p.W));
 
-	// ---- stage weights (linear) and the 8 x 32 input tile (swizzled chunks, zero outside) ----
+	// ---- weights (linear) for the workgroup; each wave fetches its own rows: the row
+	//      after the current one travels in registers while the current one is processed ----
+	// (four named registers and macros: an array that lives across the wave barriers
+	// below, or a lambda capturing it, is left in scratch memory by hipcc)
+#define JU_TAIL_ROW_ADDR(LR, K)                                                                  \
+	(x + ((size_t)min(ty0 + (LR), p.H - 1) * p.xPitch + min(tx0 + ((lane + (K) * 64) >> 3), p.W - 1)) * 64 + \
+	    ((lane + (K) * 64) & 7) * 8)
+#define JU_TAIL_LOAD_ROW(LR)                                                    \
+	row0 = *reinterpret_cast<const uint4 *>(JU_TAIL_ROW_ADDR(LR, 0));           \
+	row1 = *reinterpret_cast<const uint4 *>(JU_TAIL_ROW_ADDR(LR, 1));           \
+	row2 = *reinterpret_cast<const uint4 *>(JU_TAIL_ROW_ADDR(LR, 2));           \
+	row3 = *reinterpret_cast<const uint4 *>(JU_TAIL_ROW_ADDR(LR, 3));
+#define JU_TAIL_ROW_LDS(K)                                                                      \
+	(smRow + ((lane + (K) * 64) >> 3) * 128 +                                                   \
+	    ((((lane + (K) * 64) & 7) ^ ((((lane + (K) * 64) >> 3) >> 1) & 7)) << 4))
+	uint4 row0, row1, row2, row3;
+	JU_TAIL_LOAD_ROW(wave * 2)
 	{
 		const uint4 *src = reinterpret_cast<const uint4 *>(p.w1);
 		uint4 *dst = reinterpret_cast<uint4 *>(smW);
 #pragma unroll
 		for (int k = 0; k < kTailLdsW1 / 16 / 256; ++k) dst[tid + k * 256] = src[tid + k * 256];
-		uint4 v[8];
-#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const int i = tid + k * 256;  // 8 rows x 32 px x 8 chunks = 2048
-			const int q = i >> 3, c = i & 7;
-			const int r = q >> 5, xx = q & 31;
-			const int gy = min(ty0 + r, p.H - 1), gx = min(tx0 + xx, p.W - 1);
-			v[k] = *reinterpret_cast<const uint4 *>(x + ((size_t)gy * p.xPitch + gx) * 64 + c * 8);
-		}
-#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const int i = tid + k * 256;
-			const int q = i >> 3, c = i & 7;
-			*reinterpret_cast<uint4 *>(smI + q * 128 + ((c ^ ((q >> 1) & 7)) << 4)) = v[k];
-		}
 	}
 	// convT2 A fragments (2 k-steps) and biases in registers
 	Vec8<T> a2[2];
@@ -490,9 +496,22 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 	const float b2v[3] = {p.b2[0], p.b2[1], p.b2[2]};
 	__syncthreads();
 
+#pragma unroll
 	for (int rw = 0; rw < 2; ++rw) {
 		const int lr = wave * 2 + rw;  // LR row inside the tile
 		const int h = ty0 + lr;
+		// this row -> LDS (the previous row's output staging was read out at the end of
+		// the last iteration); the next row's loads go out before the MFMAs
+		*reinterpret_cast<uint4 *>(JU_TAIL_ROW_LDS(0)) = row0;
+		*reinterpret_cast<uint4 *>(JU_TAIL_ROW_LDS(1)) = row1;
+		*reinterpret_cast<uint4 *>(JU_TAIL_ROW_LDS(2)) = row2;
+		*reinterpret_cast<uint4 *>(JU_TAIL_ROW_LDS(3)) = row3;
+		if (rw == 0) {
+			JU_TAIL_LOAD_ROW(lr + 1)
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		// ---- stage 1: 128 couts x 32 px ----
 		f32x16 acc[4];
 #pragma unroll
@@ -506,9 +525,9 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 		}
 #pragma unroll
 		for (int ks = 0; ks < 4; ++ks) {
-			const int q = lr * 32 + px;
+			const int q = px;
 			const int c = ks * 2 + hh;
-			const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(smI + q * 128 + ((c ^ ((q >> 1) & 7)) << 4));
+			const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(smRow + q * 128 + ((c ^ ((q >> 1) & 7)) << 4));
 #pragma unroll
 			for (int nb = 0; nb < 4; ++nb) {
 				// weights: [cog = nb>>1][tap 0][ks][h][n = 64][8]
@@ -580,8 +599,8 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 				}
 				st[3] = static_cast<f16>(0.f);
 				const int xcol = 4 * px + xq;  // HR column inside the 128-px row segment
-				*reinterpret_cast<Vec4<f16> *>(smOut + yq * 1024 + xcol * 8) = st;
-				*reinterpret_cast<unsigned *>(smOut + 4096 + yq * 512 + xcol * 4) = packed;
+				*reinterpret_cast<Vec4<f16> *>(smRow + yq * 1024 + xcol * 8) = st;
+				*reinterpret_cast<unsigned *>(smU8 + yq * 512 + xcol * 4) = packed;
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -597,12 +616,12 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 				const int Y = 4 * h + yq;
 				// state: 1024 B per row = 64 lanes x 16 B (2 px per lane)
 				if (2 * lane < nValidPx) {
-					const uint4 v = *reinterpret_cast<const uint4 *>(smOut + yq * 1024 + lane * 16);
+					const uint4 v = *reinterpret_cast<const uint4 *>(smRow + yq * 1024 + lane * 16);
 					*reinterpret_cast<uint4 *>(stateOut + ((size_t)Y * WW + 4 * tx0 + 2 * lane) * 4) = v;
 				}
 				// u8: 512 B per row = 64 lanes x 8 B (2 px per lane)
 				if (2 * lane < nValidPx) {
-					const uint2 v = *reinterpret_cast<const uint2 *>(smOut + 4096 + yq * 512 + lane * 8);
+					const uint2 v = *reinterpret_cast<const uint2 *>(smU8 + yq * 512 + lane * 8);
 					*reinterpret_cast<uint2 *>(p.outU8 + Y * p.outStride + (4 * tx0 + 2 * lane) * 4) = v;
 				}
 			}
@@ -611,6 +630,10 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 		__builtin_amdgcn_wave_barrier();
 	}
 }
+
+#undef JU_TAIL_LOAD_ROW
+#undef JU_TAIL_ROW_ADDR
+#undef JU_TAIL_ROW_LDS
 
 template <typename T>
 void launchTailFusedT(const TailFusedParams &p, hipStream_t stream) {
