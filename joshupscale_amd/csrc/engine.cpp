@@ -46,7 +46,10 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 	ConvWeights cw;
 	// generator conv_1 (64 padded input channels) runs as layer 0 of the resident tower
 	const bool towerLayer = name.rfind("generator/block_", 0) == 0 || name == "generator/conv_1";
-	if ((towerLayer && f.cout == 64) || name == "generator/conv_trans_1") {
+	// flow-resnet with 64 filters: its blocks are packed like the generator's tower
+	const bool flowTower = m_Config.flowArch == 1 && m_Config.flowResFilters == 64;
+	const bool flowBlock = flowTower && name.rfind("flow/block_", 0) == 0;
+	if ((towerLayer && f.cout == 64) || flowBlock || name == "generator/conv_trans_1") {
 		cw.nb = 2;  // the tower kernels and the fused tail read the 64-cout-block layout
 		cw.rw = 2;
 	} else {
@@ -64,6 +67,18 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 	if (towerLayer) {  // tower layers, in execution order
 		m_TowerHostW.insert(m_TowerHostW.end(), packed.begin(), packed.end());
 		m_TowerHostB.insert(m_TowerHostB.end(), f.bias.begin(), f.bias.end());
+	}
+	if (flowBlock) {
+		m_FlowTowerHostW.insert(m_FlowTowerHostW.end(), packed.begin(), packed.end());
+		m_FlowTowerHostB.insert(m_FlowTowerHostB.end(), f.bias.begin(), f.bias.end());
+	} else if (flowTower && name == "flow/conv_1") {
+		// layer 0 of the flow tower reads 64-channel records: same kernel, input
+		// channels 12.. are zero (the per-layer path keeps its own 16-channel packing)
+		std::vector<int> map64(64, -1);
+		for (int k = 0; k < f.cin && k < 64; ++k) map64[k] = k;
+		const auto head = packConvWeights(f, map64, 2, m_DType);
+		m_FlowTowerHostW.insert(m_FlowTowerHostW.end(), head.begin(), head.end());
+		m_FlowTowerHostB.insert(m_FlowTowerHostB.end(), f.bias.begin(), f.bias.end());
 	}
 	auto res = m_Convs.emplace(name, std::move(cw));
 	if (!res.second) throw std::logic_error("duplicate conv " + name);
@@ -219,6 +234,34 @@ void Engine::buildProgram(int set) {
 			cur = Op("flow/a_1");
 		}
 		if (upsampleNext) throw std::logic_error("flow head cannot take a half-resolution input");
+	} else if (m_ResidentFlow) {
+		// flow-resnet body = conv_1 + residual blocks, 64 filters: ONE launch of the
+		// resident tower kernel (own mailbox and generation word)
+		void *in64 = T("flow/in64");
+		prog.push_back({"flow", 0.0,
+		    [=](hipStream_t s) { launchExpandChannels(dt, packedOut, in64, PH * PW, s); }});
+		ResidentTowerParams rp{};
+		rp.in = in64;
+		rp.inPitch = PW;
+		rp.hasHead = 1;
+		rp.out = Op("flow/trunk").ptr;
+		rp.weights = m_FlowTowerW.get();
+		rp.bias = m_FlowTowerB.as<float>();
+		rp.mailbox = m_FlowMail.get();
+		rp.generation = m_FlowFlags.as<unsigned>();
+		rp.error = m_ResErrorDev;
+		rp.debug = m_Tensors.at("tower_profile").buf.get();
+		rp.H = PH;
+		rp.W = PW;
+		rp.GX = m_FlowGX;
+		rp.GY = m_FlowGY;
+		rp.RH = m_FlowRH;
+		rp.nLayers = 1 + 2 * c.flowResBlocks;
+		rp.bumpGeneration = 1;  // (pack_frames bumps the generator tower's word only)
+		prog.push_back({"flow",
+		    2.0 * PH * PW * 9.0 * (3.0 * c.numFlowInputs * 64 + 64.0 * 64 * 2 * c.flowResBlocks),
+		    [=](hipStream_t s) { launchResidentTower(dt, rp, s); }});
+		cur = Op("flow/trunk");
 	} else {
 		addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/x0"), h, w, true, false);
 		const char *xs[2] = {"flow/x0", "flow/x1"};
@@ -377,6 +420,20 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		}
 		m_TowerHostW.clear();
 		m_TowerHostW.shrink_to_fit();
+		const char *flowMode = std::getenv("JU_FLOW");
+		if (m_Resident && !(flowMode && std::string(flowMode) == "layers") && c.flowArch == 1 &&
+		    c.flowResFilters == 64 && c.flowResBlocks >= 1 && 3 * c.numFlowInputs <= 64 &&
+		    residentTowerGeometry(PH, PW, cus, &m_FlowGX, &m_FlowGY, &m_FlowRH)) {
+			m_ResidentFlow = true;
+			m_FlowTowerW = DeviceBuffer(m_FlowTowerHostW.size() * 2);
+			m_FlowTowerW.upload(m_FlowTowerHostW.data(), m_FlowTowerHostW.size() * 2);
+			m_FlowTowerB = DeviceBuffer(m_FlowTowerHostB.size() * 4);
+			m_FlowTowerB.upload(m_FlowTowerHostB.data(), m_FlowTowerHostB.size() * 4);
+			m_FlowMail = DeviceBuffer(residentMailboxBytes(m_FlowGX, m_FlowGY));
+			m_FlowFlags = DeviceBuffer(64 + (static_cast<std::size_t>(m_FlowGX) * m_FlowGY * 4 + 15) / 16 * 16);
+		}
+		m_FlowTowerHostW.clear();
+		m_FlowTowerHostW.shrink_to_fit();
 	}
 
 	// ---- buffers (all zero-initialised) ----
@@ -402,6 +459,10 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		}
 		if (c.flowFilters.size() % 2) addTensor("flow/a_1", px * c.flowFilters.back());
 	} else {
+		if (m_ResidentFlow) {
+			addTensor("flow/in64", plr * 64);  // [PH][PW][64]: ch 0..15 = the packed flow input, rest zero
+			addTowerTensor("flow/trunk", PH, PW, 64);
+		}
 		addTensor("flow/x0", plr * c.flowResFilters);
 		addTensor("flow/x1", plr * c.flowResFilters);
 		addTensor("flow/t", plr * c.flowResFilters);
@@ -490,6 +551,7 @@ void Engine::fallbackToLayers(unsigned code) {
 	      "kernels (slower) for the rest of this runtime's life";
 	logMessage(LogLevel::Warning, "Engine", ss.str());
 	m_Resident = false;
+	m_ResidentFlow = false;
 	for (int s = 0; s < 2; ++s) {
 		m_Graph[s] = GraphExec();
 		buildProgram(s);

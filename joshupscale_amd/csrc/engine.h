@@ -154,6 +154,13 @@ private:
 	std::vector<std::uint16_t> m_TowerHostW;
 	std::vector<float> m_TowerHostB;
 	DeviceBuffer m_TowerW, m_TowerB, m_ResMail, m_ResFlags;
+	// flow-resnet (models.py:257-331) through the same resident kernel: conv_1 + its
+	// residual blocks are a 64-filter tower too
+	bool m_ResidentFlow = false;
+	int m_FlowGX = 0, m_FlowGY = 0, m_FlowRH = 0;
+	std::vector<std::uint16_t> m_FlowTowerHostW;
+	std::vector<float> m_FlowTowerHostB;
+	DeviceBuffer m_FlowTowerW, m_FlowTowerB, m_FlowMail, m_FlowFlags;
 	unsigned *m_ResErrorHost = nullptr;  // pinned, device-visible
 	unsigned *m_ResErrorDev = nullptr;
 	unsigned takeResidentError();        // 0 = none; clears it

@@ -74,6 +74,16 @@ __global__ __launch_bounds__(1024) void frame_sums_kernel(const std::uint8_t *__
 	}
 }
 
+// packed flow input [N][16] -> the first two 16-byte chunks of 64-channel records
+// [N][64] (the other chunks stay zero from allocation): input of the flow-resnet's
+// resident tower, whose layer 0 reads 64-channel pixels.
+__global__ __launch_bounds__(256) void expand_channels_kernel(const uint4 *__restrict__ in,
+    uint4 *__restrict__ out, int nPix) {
+	const int i = blockIdx.x * 256 + threadIdx.x;  // one 16-byte chunk
+	if (i >= nPix * 2) return;
+	out[(size_t)(i >> 1) * 8 + (i & 1)] = in[i];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_frames_kernel(const std::uint8_t *__restrict__ frame,
     std::ptrdiff_t frameStride, const T *__restrict__ prev, T *__restrict__ cur, int H, int W,
@@ -684,6 +694,12 @@ void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameS
 		    W, PH, PW, padTop, padLeft, numInputs, sums, generation);
 	}
 	hipCheckLaunch("pack_frames");
+}
+
+void launchExpandChannels(DType, const void *in16, void *out64, int nPix, hipStream_t stream) {
+	hipLaunchKernelGGL(expand_channels_kernel, dim3(blocksFor((size_t)nPix * 2)), dim3(256), 0, stream,
+	    static_cast<const uint4 *>(in16), static_cast<uint4 *>(out64), nPix);
+	hipCheckLaunch("expand_channels");
 }
 
 void launchMaxPool2(DType dt, const void *in, void *out, int H, int W, int C, hipStream_t stream) {

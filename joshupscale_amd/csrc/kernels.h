@@ -162,6 +162,8 @@ void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameS
 void launchFrameSums(const std::uint8_t *frame, std::ptrdiff_t frameStride, int H, int W,
     unsigned *sums, hipStream_t stream);
 
+// [nPix][16] 16-bit -> channels 0..15 of [nPix][64] records (the rest is not written).
+void launchExpandChannels(DType dt, const void *in16, void *out64, int nPix, hipStream_t stream);
 void launchMaxPool2(DType dt, const void *in, void *out, int H, int W, int C,
     hipStream_t stream);  // in [H][W][C] -> out [H/2][W/2][C]
 

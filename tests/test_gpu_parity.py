@@ -477,3 +477,26 @@ def test_full_size_run_is_deterministic():
         digests.append(h.hexdigest())
         rt.close()
     assert digests[0] == digests[1]
+
+
+def test_flow_resnet_resident_and_per_layer_paths_agree(monkeypatch):
+    """The flow-resnet body (conv_1 + residual blocks, 64 filters) runs as a second
+    launch of the resident tower kernel; JU_FLOW=layers keeps the per-layer convs.
+    Same arithmetic up to the fp32 summation order."""
+    cfg = small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=3,
+                       frame_height=34, frame_width=50)
+    wts, blob, rt = make(cfg, R.DTYPE_BF16)
+    frames = M.synthetic_frames(4, 34, 50, seed=51, kind="smooth")
+    fused = [rt.process_image(f).copy() for f in frames]
+    flow_fused = rt.read_tensor("flow").copy()
+    rt.close()
+    monkeypatch.setenv("JU_FLOW", "layers")
+    rt2 = R.Runtime(blob, 0, R.DTYPE_BF16)
+    layered = [rt2.process_image(f).copy() for f in frames]
+    flow_layered = rt2.read_tensor("flow").copy()
+    rt2.close()
+    assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(fused, layered))
+    assert err(flow_fused, flow_layered)["rel_to_max"] < 2e-2
+    sess = O.Session(wts, oracle_config(cfg))
+    for f, out in zip(frames, fused):
+        check_u8(out, sess.run(f), R.DTYPE_BF16, "flowres-resident")
