@@ -74,6 +74,24 @@ inline void ensureDynamicLds(const void *kern, int bytes, std::atomic<std::uint6
 	doneMask->fetch_or(bit, std::memory_order_release);
 }
 
+// four f32 -> packed 16-bit (RNE).  f16: a pairwise vector convert maps to one
+// v_cvt_pk_f16_f32 per two values (element-wise casts cost a convert per value plus
+// merges).  bf16: hipcc scalarises the vector form (more ops, not fewer), and an
+// inline-asm v_cvt_pk_bf16_f32 is not padded with the MFMA -> VALU wait states, so the
+// element-wise casts stay.
+template <typename T>
+__device__ __forceinline__ Vec4<T> pack4(float a, float b, float c, float d) {
+	if constexpr (std::is_same<T, _Float16>::value) {
+		typedef float f32x2p __attribute__((ext_vector_type(2)));
+		typedef T t2p __attribute__((ext_vector_type(2)));
+		const f32x2p lo = {a, b}, hi = {c, d};
+		return __builtin_shufflevector(__builtin_convertvector(lo, t2p), __builtin_convertvector(hi, t2p),
+		    0, 1, 2, 3);
+	} else {
+		return Vec4<T>{static_cast<T>(a), static_cast<T>(b), static_cast<T>(c), static_cast<T>(d)};
+	}
+}
+
 inline void hipCheckLaunch(const char *what) {
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) {

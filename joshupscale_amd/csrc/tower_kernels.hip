@@ -661,10 +661,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #pragma unroll
 							for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, v[i]);
 						}
-						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
-						    static_cast<T>(v[3])};
 						*reinterpret_cast<Vec4<T> *>(smem + outOff + (ra + r) * kResRowBytes + outsw[g]) =
-						    reluPacked<T>(o);
+						    reluPacked<T>(pack4<T>(v[0], v[1], v[2], v[3]));
 					}
 				}
 			}
