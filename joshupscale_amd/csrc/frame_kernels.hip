@@ -21,28 +21,6 @@ namespace {
 // ---------------------------------------------------------------------------
 // flow input packing
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float preprocessU8(unsigned v) {
-	// PreprocessLayer: x / 255 - 0.5 (reference keras_layers.py:208).  Multiply by the
-	// f32 reciprocal: at most 1 ulp (6e-8) from the correctly rounded quotient, far below
-	// the 16-bit activations and the 1/255 output step, and one op instead of the ~10 of
-	// an IEEE division (the tail evaluates 12 per lane); 0 and 255 map to -0.5 and 0.5
-	// exactly.
-	return static_cast<float>(v) * (1.0f / 255.0f) - 0.5f;
-}
-
-// normalize_brightness (reference models.py:772-779, utils.py:151): the scalar
-// b = mean(x * BGR_LUMA * 3) over H, W, C of the preprocessed frame
-//   = sum_c luma_c * (S_c / (255 N) - 0.5)
-// from the three exact integer channel sums S_c (order-independent, so the
-// reduction is deterministic).  sums == nullptr: feature off, b = 0.
-__device__ __forceinline__ float brightnessOf(const unsigned *__restrict__ sums, float invN) {
-	if (sums == nullptr) return 0.0f;
-	const float mb = static_cast<float>(sums[0]) * invN / 255.0f - 0.5f;
-	const float mg = static_cast<float>(sums[1]) * invN / 255.0f - 0.5f;
-	const float mr = static_cast<float>(sums[2]) * invN / 255.0f - 0.5f;
-	return 0.114f * mb + 0.587f * mg + 0.2989f * mr;
-}
-
 __global__ __launch_bounds__(1024) void frame_sums_kernel(const std::uint8_t *__restrict__ frame,
     std::ptrdiff_t frameStride, int H, int W, unsigned *__restrict__ sums) {
 	__shared__ unsigned part[3][16];
@@ -504,6 +482,7 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 	a2[0] = reinterpret_cast<const Vec8<T> *>(p.w2)[lane];
 	a2[1] = reinterpret_cast<const Vec8<T> *>(p.w2)[64 + lane];
 	const float b2v[3] = {p.b2[0], p.b2[1], p.b2[2]};
+	const TailRowArgs args{p.b1, p.frame, p.frameStride, p.state, p.outU8, p.outStride, p.H, p.W};
 	__syncthreads();
 
 #pragma unroll
@@ -522,122 +501,11 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		// ---- stage 1: 128 couts x 32 px ----
-		f32x16 acc[4];
-#pragma unroll
-		for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-			for (int g = 0; g < 4; ++g) {
-				const f32x4 b = *reinterpret_cast<const f32x4 *>(p.b1 + nb * 32 + 8 * g + 4 * hh);
-#pragma unroll
-				for (int i = 0; i < 4; ++i) acc[nb][4 * g + i] = b[i];
-			}
-		}
-#pragma unroll
-		for (int ks = 0; ks < 4; ++ks) {
-			const int q = px;
+		const auto fetchB = [&](int ks) {
 			const int c = ks * 2 + hh;
-			const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(smRow + q * 128 + ((c ^ ((q >> 1) & 7)) << 4));
-#pragma unroll
-			for (int nb = 0; nb < 4; ++nb) {
-				// weights: [cog = nb>>1][tap 0][ks][h][n = 64][8]
-				const Vec8<T> a = *reinterpret_cast<const Vec8<T> *>(
-				    smW + (nb >> 1) * (64 * 64 * 2) + (((ks * 2 + hh) * 64 + (nb & 1) * 32 + px) << 4));
-				acc[nb] = mfma32(a, b, acc[nb]);
-			}
-		}
-		// ReLU, 16-bit, to LDS as mid pixels: group nb, pixel px, 64 B (4 chunks, P = 4 swizzle)
-#pragma unroll
-		for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-			for (int g = 0; g < 4; ++g) {
-				Vec4<T> o = {static_cast<T>(acc[nb][4 * g + 0]), static_cast<T>(acc[nb][4 * g + 1]),
-				    static_cast<T>(acc[nb][4 * g + 2]), static_cast<T>(acc[nb][4 * g + 3])};
-				*reinterpret_cast<Vec4<T> *>(smMid + nb * 2048 + px * 64 +
-				                             ((g ^ ((px >> 2) & 3)) << 4) + hh * 8) = reluPacked<T>(o);
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-		// LR neighbourhood for the bilinear x4 skip of this lane's LR pixel (px)
-		const int w = tx0 + px;
-		const int hc = min(h, p.H - 1), wc = min(w, p.W - 1);
-		const int h1 = min(hc + 1, p.H - 1), w1 = min(wc + 1, p.W - 1);
-		float lrv[2][2][3];
-#pragma unroll
-		for (int yy = 0; yy < 2; ++yy) {
-#pragma unroll
-			for (int xx = 0; xx < 2; ++xx) {
-				const unsigned v = *reinterpret_cast<const unsigned *>(
-				    p.frame + (yy ? h1 : hc) * p.frameStride + (xx ? w1 : wc) * 4);
-				lrv[yy][xx][0] = preprocessU8(v & 0xff);
-				lrv[yy][xx][1] = preprocessU8((v >> 8) & 0xff);
-				lrv[yy][xx][2] = preprocessU8((v >> 16) & 0xff);
-			}
-		}
-		// ---- stage 2 per mid-pixel group (a, b) ----
-#pragma unroll
-		for (int nb = 0; nb < 4; ++nb) {
-			const int a = nb >> 1, bb = nb & 1;
-			f32x16 d = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-			for (int ks = 0; ks < 2; ++ks) {
-				const int c = ks * 2 + hh;
-				const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(
-				    smMid + nb * 2048 + px * 64 + ((c ^ ((px >> 2) & 3)) << 4));
-				d = mfma32(a2[ks], b, d);
-			}
-			// lane (px, hh), g2: HR pixel (4h + 2a + g2, 4w + 2b + hh), channels d[4*g2 + 0..2]
-#pragma unroll
-			for (int g2 = 0; g2 < 2; ++g2) {
-				const int yq = 2 * a + g2, xq = 2 * bb + hh;  // position inside the 4x4 HR block
-				const float fy = yq * 0.25f, fx = xq * 0.25f;
-				Vec4<f16> st;
-				unsigned packed = 0;
-#pragma unroll
-				for (int c = 0; c < 3; ++c) {
-					const float top = lrv[0][0][c] + (lrv[0][1][c] - lrv[0][0][c]) * fx;
-					const float bot = lrv[1][0][c] + (lrv[1][1][c] - lrv[1][0][c]) * fx;
-					const float skip = top + (bot - top) * fy;
-					float r = fastTanh(d[4 * g2 + c] + b2v[c]) + skip;
-					r = fminf(fmaxf(r, -0.5f), 0.5f);
-					st[c] = static_cast<f16>(r - bright);
-					const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);
-					packed |= (u & 0xff) << (8 * c);
-				}
-				st[3] = static_cast<f16>(0.f);
-				const int xcol = 4 * px + xq;  // HR column inside the 128-px row segment
-				*reinterpret_cast<Vec4<f16> *>(smRow + yq * 1024 + xcol * 8) = st;
-				*reinterpret_cast<unsigned *>(smU8 + yq * 512 + xcol * 4) = packed;
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		// ---- coalesced output: 4 HR rows x 128 px ----
-		if (h < p.H) {
-			const int WW = 4 * p.W;
-			const int nValidPx = min(128, 4 * (p.W - tx0));
-			f16 *stateOut = static_cast<f16 *>(p.state);
-#pragma unroll
-			for (int yq = 0; yq < 4; ++yq) {
-				const int Y = 4 * h + yq;
-				// state: 1024 B per row = 64 lanes x 16 B (2 px per lane)
-				if (2 * lane < nValidPx) {
-					const uint4 v = *reinterpret_cast<const uint4 *>(smRow + yq * 1024 + lane * 16);
-					*reinterpret_cast<uint4 *>(stateOut + ((size_t)Y * WW + 4 * tx0 + 2 * lane) * 4) = v;
-				}
-				// u8: 512 B per row = 64 lanes x 8 B (2 px per lane)
-				if (2 * lane < nValidPx) {
-					const uint2 v = *reinterpret_cast<const uint2 *>(smU8 + yq * 512 + lane * 8);
-					*reinterpret_cast<uint2 *>(p.outU8 + Y * p.outStride + (4 * tx0 + 2 * lane) * 4) = v;
-				}
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
+			return *reinterpret_cast<const Vec8<T> *>(smRow + px * 128 + ((c ^ ((px >> 1) & 7)) << 4));
+		};
+		tailRow<T>(fetchB, smW, smMid, smRow, smU8, a2, b2v, args, bright, tx0, h, lane);
 	}
 }
 
