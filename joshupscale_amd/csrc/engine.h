@@ -146,6 +146,7 @@ private:
 	bool m_FusedUpsample = true;  // flow decoder: bilinear x2 folded into the next conv's staging
 	bool m_FusedPool = true;  // max-pool folded into the flow encoder's conv epilogues
 	bool m_FusedTail = true;  // JU_TAIL=split: convT1 as a conv launch + the VALU tail kernel
+	bool m_TailInTower = false;  // JU_TAIL=tower: the fused tail runs inside the resident tower launch
 	DeviceBuffer m_InStage, m_OutStage, m_RawStage;
 	DeviceBuffer m_State[2], m_Packed[2];
 	// resident tower (one launch for all residual-block convolutions)

@@ -418,13 +418,6 @@ __global__ __launch_bounds__(256) void tail_kernel(const T *__restrict__ y,
 // LDS (72 KiB, two workgroups per CU): per wave ONE input row (4 KiB; the f16 state
 // rows of the output staging reuse it once stage 1 has consumed it), 16 KiB convT1
 // weights, per wave 8 KiB of mid pixels and 2 KiB of u8 output staging.
-constexpr int kTailLdsRow = 32 * 128;             // 4 KiB: one LR row of 32 px x 64 ch
-constexpr int kTailLdsIn = 4 * kTailLdsRow;       // one row per wave
-constexpr int kTailLdsW1 = 64 * 128 * 2;          // 16 KiB convT1 weights (fragment order)
-constexpr int kTailLdsMid = 4 * 4 * 32 * 64;      // per wave: 4 mid-pixel groups x 32 px x 64 B = 8 KiB
-constexpr int kTailLdsU8 = 4 * (4 * 128 * 4);     // per wave: 4 HR rows x 128 px x 4 B
-constexpr int kTailLds = kTailLdsIn + kTailLdsW1 + kTailLdsMid + kTailLdsU8;
-static_assert(4 * 128 * 8 == kTailLdsRow, "the f16 state staging (4 HR rows x 128 px x 8 B) overlays the input row");
 
 struct TailFusedParams {
 	const void *x;        // trunk, addressed at image pixel (0,0)

@@ -122,6 +122,16 @@ __device__ __forceinline__ float brightnessOf(const unsigned *__restrict__ sums,
 	return 0.114f * mb + 0.587f * mg + 0.2989f * mr;
 }
 
+// LDS footprint of the generator tail (tail_fused_kernel; the resident tower runs the
+// same row code in a free activation buffer)
+constexpr int kTailLdsRow = 32 * 128;             // 4 KiB: one LR row of 32 px x 64 ch
+constexpr int kTailLdsIn = 4 * kTailLdsRow;       // one row per wave
+constexpr int kTailLdsW1 = 64 * 128 * 2;          // 16 KiB convT1 weights (fragment order)
+constexpr int kTailLdsMid = 4 * 4 * 32 * 64;      // per wave: 4 mid-pixel groups x 32 px x 64 B = 8 KiB
+constexpr int kTailLdsU8 = 4 * (4 * 128 * 4);     // per wave: 4 HR rows x 128 px x 4 B
+constexpr int kTailLds = kTailLdsIn + kTailLdsW1 + kTailLdsMid + kTailLdsU8;
+static_assert(4 * 128 * 8 == kTailLdsRow, "the f16 state staging (4 HR rows x 128 px x 8 B) overlays the input row");
+
 // ---------------------------------------------------------------------------
 // One LR row (32 px) of the generator tail on one wave: convT1 (MFMA, weights in LDS
 // at smW) -> ReLU -> LDS (smMid) -> convT2 (MFMA, a2 in registers) -> tanh + bilinear

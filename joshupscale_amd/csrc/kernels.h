@@ -135,6 +135,19 @@ struct ResidentTowerParams {
 	int GX, GY, RH;
 	int nLayers;
 	int bumpGeneration;  // 1: bump *generation in a 1-thread launch first (0: someone else did)
+	// Optional fused generator tail (tailW1 != nullptr): instead of writing the last
+	// layer to `out`, every workgroup runs the tail (launchTailFused's arithmetic) on
+	// its LDS-resident region and writes the HR state and the BGRX frame directly.
+	const void *tailW1;       // convT1 as 1x1 conv 64->128, packConvWeights order with nb = 2
+	const float *tailB1;      // [128]
+	const void *tailW2;       // packTailWeights fragments
+	const float *tailB2;      // [3]
+	const std::uint8_t *frame;
+	std::ptrdiff_t frameStride;
+	void *state;              // f16 [4H][4W][4]
+	std::uint8_t *outU8;
+	std::ptrdiff_t outStride;
+	const unsigned *sums;     // normalize_brightness channel sums or nullptr
 };
 void launchBumpGeneration(unsigned *generation, hipStream_t stream);
 bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH);

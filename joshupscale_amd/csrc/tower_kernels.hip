@@ -393,6 +393,17 @@ struct ResidentParams {
 	int GX, GY, RH;
 	int nLayers;
 	int bumpGeneration;  // host-side only: launch bump_generation_kernel first
+	// fused generator tail (tailW1 != nullptr), see ResidentTowerParams
+	const void *tailW1;
+	const float *tailB1;
+	const void *tailW2;
+	const float *tailB2;
+	const std::uint8_t *frame;
+	std::ptrdiff_t frameStride;
+	void *state;
+	std::uint8_t *outU8;
+	std::ptrdiff_t outStride;
+	const unsigned *sums;
 };
 
 typedef unsigned long long u64;
@@ -932,6 +943,44 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 	}
 
+	if (p.tailW1 != nullptr) {
+		// ---- fused generator tail on the LDS-resident last layer (models.py:552-593):
+		// the buffer the last layer did NOT write is free now: 16 KiB of convT1 weights,
+		// then per wave 8 KiB mid pixels + 4 KiB state staging + 2 KiB u8 staging.
+		// Saves the trunk's 16.6 MB write and re-read and one launch.
+		const int scratchOff = finalOff == kResOffA ? kResOffB : kResOffA;
+		static_assert(kTailLdsW1 + 4 * (kTailLdsMid / 4 + kTailLdsRow + kTailLdsU8 / 4) <= kResBufBytes,
+		    "tail scratch must fit one activation buffer");
+		unsigned char *smW = smem + scratchOff;
+		unsigned char *waveBase = smW + kTailLdsW1 + wave * (kTailLdsMid / 4 + kTailLdsRow + kTailLdsU8 / 4);
+		unsigned char *smMid = waveBase;
+		unsigned char *smState = waveBase + kTailLdsMid / 4;
+		unsigned char *smU8 = smState + kTailLdsRow;
+		{
+			const uint4 *src = reinterpret_cast<const uint4 *>(p.tailW1);
+			uint4 *dst = reinterpret_cast<uint4 *>(smW);
+#pragma unroll
+			for (int k = 0; k < kTailLdsW1 / 16 / 256; ++k) dst[tid + k * 256] = src[tid + k * 256];
+		}
+		Vec8<T> a2[2];
+		a2[0] = reinterpret_cast<const Vec8<T> *>(p.tailW2)[lane];
+		a2[1] = reinterpret_cast<const Vec8<T> *>(p.tailW2)[64 + lane];
+		const float b2v[3] = {p.tailB2[0], p.tailB2[1], p.tailB2[2]};
+		const TailRowArgs args{p.tailB1, p.frame, p.frameStride, p.state, p.outU8, p.outStride, p.H, p.W};
+		const float bright = brightnessOf(p.sums, 1.0f / static_cast<float>(p.H * p.W));
+		__syncthreads();
+		for (int r = wave; r < rhv; r += 4) {
+			const unsigned char *rowBase = smem + finalOff + (r + 1) * kResRowBytes;
+			const auto fetchB = [&](int ks) {
+				const int cc = px + 1;
+				return *reinterpret_cast<const Vec8<T> *>(
+				    rowBase + cc * 128 + (((ks * 2 + hh) ^ ((cc >> 1) & 7)) << 4));
+			};
+			tailRow<T>(fetchB, smW, smMid, smState, smU8, a2, b2v, args, bright, x0, y0 + r, lane);
+		}
+		return;
+	}
+
 	// ---- last block output: region interior -> global tower-layout tensor ----
 	{
 		T *out = static_cast<T *>(p.out);
@@ -1034,6 +1083,16 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
 	p.bumpGeneration = q.bumpGeneration;
+	p.tailW1 = q.tailW1;
+	p.tailB1 = q.tailB1;
+	p.tailW2 = q.tailW2;
+	p.tailB2 = q.tailB2;
+	p.frame = q.frame;
+	p.frameStride = q.frameStride;
+	p.state = q.state;
+	p.outU8 = q.outU8;
+	p.outStride = q.outStride;
+	p.sums = q.sums;
 	if ((p.nLayers & 1) != (p.hasHead ? 1 : 0)) {
 		throw std::invalid_argument("resident tower: layer count must be 2*blocks (+1 with a head)");
 	}

@@ -189,6 +189,11 @@ def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
     split = [rt5.process_image(f).copy() for f in frames]
     assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(first, split))
     rt5.close()
+    monkeypatch.setenv("JU_TAIL", "tower")              # the fused tail inside the resident tower launch
+    rt8 = R.Runtime(blob, 0, R.DTYPE_BF16)               # instead of its own: same row code
+    own = [rt8.process_image(f).copy() for f in frames]
+    assert all(np.array_equal(a, b) for a, b in zip(first, own))
+    rt8.close()
     monkeypatch.delenv("JU_TAIL")
     monkeypatch.setenv("JU_POOL", "split")              # separate max-pool launches: rounding is
     rt6 = R.Runtime(blob, 0, R.DTYPE_BF16)               # monotonic, so fusing it is bit-exact
