@@ -537,6 +537,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_PreferDirect = !(direct && direct[0] == '0');
 	const char *noGraph = std::getenv("JU_NO_GRAPH");
 	m_UseGraph = !(noGraph && noGraph[0] == '1');
+	if (const char *spin = std::getenv("JU_SYNC_SPIN_US")) m_SpinUs = static_cast<unsigned>(std::atoi(spin));
 	if (m_UseGraph) {
 		for (int s = 0; s < 2; ++s) {
 			m_Graph[s] = GraphExec::capture(m_Stream, [&] {
@@ -758,7 +759,7 @@ void Engine::enqueue(const Frame &in, const Frame &out) {
 void Engine::process(const Frame &in, const Frame &out) {
 	DeviceGuard g(m_Device);
 	submit(in, out);
-	m_Stream.synchronize();
+	m_Stream.synchronizeSpin(m_SpinUs);
 	if (const unsigned code = takeResidentError()) {
 		// the frame's inputs (previous state, frame history) are intact: the step only
 		// wrote the other half of the ping-pong -- run it again on the per-layer path

@@ -136,6 +136,8 @@ private:
 	DType m_DType;
 	Stream m_Stream;
 	bool m_UseGraph = true;
+	// process() polls the stream this long before it blocks (JU_SYNC_SPIN_US, 0 = block at once)
+	unsigned m_SpinUs = 2000;
 	int m_Idx = 0;
 	std::string m_TrunkOut = "trunk_a";
 

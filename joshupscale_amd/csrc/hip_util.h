@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cstddef>
 #include <stdexcept>
 #include <string>
@@ -121,6 +122,21 @@ public:
 	Stream &operator=(const Stream &) = delete;
 	operator hipStream_t() const { return m_Stream; }  // NOLINT
 	void synchronize() const { JU_HIP(hipStreamSynchronize(m_Stream)); }
+	// Poll for completion for up to `spinUs` microseconds before blocking: a frame
+	// takes well under a millisecond, and the wake-up of a blocking wait costs
+	// several microseconds of it.
+	void synchronizeSpin(unsigned spinUs) const {
+		if (spinUs) {
+			const auto t0 = std::chrono::steady_clock::now();
+			for (;;) {
+				const hipError_t st = hipStreamQuery(m_Stream);
+				if (st == hipSuccess) return;
+				if (st != hipErrorNotReady) JU_HIP(st);
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spinUs)) break;
+			}
+		}
+		JU_HIP(hipStreamSynchronize(m_Stream));
+	}
 
 private:
 	hipStream_t m_Stream = nullptr;

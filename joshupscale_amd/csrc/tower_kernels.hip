@@ -416,7 +416,9 @@ __global__ void bump_generation_kernel(unsigned *gen) {
 
 // VARIANT: timing ablation only (0 = product; bit 0 = no halo exchange, bit 1 = no MFMA loop)
 // HEAD: layer 0 is the generator's conv_1 (plain conv + ReLU), residual blocks follow
-template <typename T, int VARIANT, bool HEAD>
+// TAIL: the generator tail runs on the LDS-resident last layer (JU_TAIL=tower); a
+// separate instantiation so that the default kernel carries none of its code
+template <typename T, int VARIANT, bool HEAD, bool TAIL = false>
 __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr bool xchg = !(VARIANT & 1);
@@ -943,7 +945,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 	}
 
-	if (p.tailW1 != nullptr) {
+	if constexpr (TAIL) {
 		// ---- fused generator tail on the LDS-resident last layer (models.py:552-593):
 		// the buffer the last layer did NOT write is free now: 16 KiB of convT1 weights,
 		// then per wave 8 KiB mid pixels + 4 KiB state staging + 2 KiB u8 staging.
@@ -999,9 +1001,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	}
 }
 
-template <typename T, int VARIANT, bool HEAD>
+template <typename T, int VARIANT, bool HEAD, bool TAIL = false>
 void launchResidentT(const ResidentParams &p, hipStream_t stream) {
-	auto kern = tower_resident_kernel<T, VARIANT, HEAD>;
+	auto kern = tower_resident_kernel<T, VARIANT, HEAD, TAIL>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), kResLds, &ldsDone, "resident tower");
 	if (p.bumpGeneration) {
@@ -1099,6 +1101,11 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	if (!p.hasHead) {
 		if (dt == kF16) launchResidentT<f16, 0, false>(p, stream);
 		else launchResidentT<bf16, 0, false>(p, stream);
+		return;
+	}
+	if (p.tailW1 != nullptr) {  // fused tail: product kernel only (the ablation variants keep the split)
+		if (dt == kF16) launchResidentT<f16, 0, true, true>(p, stream);
+		else launchResidentT<bf16, 0, true, true>(p, stream);
 		return;
 	}
 	if (dt == kF16) {
