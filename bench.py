@@ -31,6 +31,7 @@ from joshupscale_amd import model_file as M  # noqa: E402
 from joshupscale_amd import runtime as R  # noqa: E402
 
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled e4m3 MFMA (same guide: twice the bf16 rate)
 
 
 def cpu_baseline(blob: bytes, cfg, frames: np.ndarray, budget_s: float) -> dict:
@@ -58,7 +59,8 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--preset", default="psp-quality", choices=sorted(M.PRESETS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp8"],
+                    help="fp8: e4m3 block convolutions over fp16 (BASELINE.json config 5)")
     ap.add_argument("--location", default="device", choices=["device", "host"],
                     help="host = PCIe-inclusive (not the headline value)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -81,7 +83,7 @@ def main() -> int:
     if rank == 0:
         blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=42))
     blob = jdist.broadcast_model(blob, device)
-    dt = R.DTYPE_BF16 if args.dtype == "bf16" else R.DTYPE_F16
+    dt = {"bf16": R.DTYPE_BF16, "fp16": R.DTYPE_F16, "fp8": R.DTYPE_FP8}[args.dtype]
     rt = R.Runtime(blob, device=local_rank, dtype=dt)
 
     h, w = cfg.frame_height, cfg.frame_width
@@ -127,15 +129,18 @@ def main() -> int:
         fps = world * args.steps / elapsed
         # dominant kernel: the 3x3 64->64 convolution of the residual tower,
         # timed with HIP events on the engine's own stream
-        ms, launches, flops = rt.time_steps("tower", args.roofline_iters)
+        fp8 = args.dtype == "fp8"
+        # (fp8: step 0 of the tower stage is the quantise kernel; time one convolution)
+        ms, launches, flops = rt.time_steps("tower#1" if fp8 else "tower", args.roofline_iters)
         flops_per_launch = flops / max(launches, 1)
+        peak = PEAK_FP8_TFLOPS if fp8 else PEAK_MFMA_TFLOPS
         achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         total_flops = rt.time_steps("", 0)[2]
         # HBM traffic of the dominant kernel from the committed PMC summary (bench.py cannot
         # run rocprofv3 around itself); only used when it describes the kernel measured here
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_tower_traffic.json")
-        if launches == 1 and args.preset == "psp-quality" and os.path.exists(tpath):
+        if launches == 1 and not fp8 and args.preset == "psp-quality" and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("bytes_per_launch")
         result = {
@@ -158,10 +163,11 @@ def main() -> int:
                 "whole_frame_tflops": total_flops * fps / world / 1e12,
             },
             "roofline": {
-                "kernel": "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch"
+                "kernel": "conv_tower_fp8_kernel 3x3 64->64 on e4m3 operands (one residual-block conv)" if fp8
+                          else "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch"
                           if launches == 1 else "conv_tower_kernel 3x3 64->64 (one residual-block conv)",
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS, "traffic": traffic,
+                "bound": "mfma", "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_tower_traffic.json)",
                 "launch_ms": ms, "launches_per_frame": launches,
                 "flops_per_launch": flops_per_launch,

@@ -47,8 +47,12 @@ enum {
  * reference's CUDA location reinterpreted as "HIP device pointer". */
 enum { JU_LOC_CPU = 0, JU_LOC_DEVICE = 1, JU_LOC_GRAPHICS_RESOURCE = 2 };
 
-/* Compute precision of MFMA operands / stored activations. */
-enum { JU_DTYPE_DEFAULT = -1, JU_DTYPE_F16 = 0, JU_DTYPE_BF16 = 1 };
+/* Compute precision of MFMA operands / stored activations.  JU_DTYPE_FP8: the 64->64
+ * residual-block convolutions of the generator run on OCP e4m3 operands (block-scaled
+ * MFMA; the counterpart of the reference's TensorRT INT8 engines,
+ * scripts/inference/tensorrt/quantize_int8.py:140-209), every other layer and the
+ * residual stream stay fp16. */
+enum { JU_DTYPE_DEFAULT = -1, JU_DTYPE_F16 = 0, JU_DTYPE_BF16 = 1, JU_DTYPE_FP8 = 2 };
 
 /* LogLevel of core/public/JoshUpscale/core.h:21. */
 enum { JU_LOG_INFO = 0, JU_LOG_WARNING = 1, JU_LOG_ERROR = 2 };
@@ -128,7 +132,7 @@ JU_API int ju_get_gl_image(uint32_t gl_texture, int type, ju_image *out_image);
 
 /* ---- introspection (tests and bench.py; no reference counterpart) ---------- */
 
-/* Compute dtype actually in use (JU_DTYPE_F16 / JU_DTYPE_BF16). */
+/* Compute dtype actually in use (JU_DTYPE_F16 / JU_DTYPE_BF16 / JU_DTYPE_FP8). */
 JU_API int ju_get_dtype(const ju_runtime *runtime);
 
 /* Copies a named internal tensor to host memory as float32.  *count receives the

@@ -171,7 +171,7 @@ int ju_get_gl_image(uint32_t, int, ju_image *out_image) {
 
 int ju_get_dtype(const ju_runtime *runtime) {
 	if (runtime == nullptr || !runtime->engine) return -1;
-	return static_cast<int>(runtime->engine->dtype());
+	return runtime->engine->reportedDtype();
 }
 
 int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, size_t capacity,

@@ -6,6 +6,7 @@
 #include <sstream>
 #include <stdexcept>
 
+#include "fp8.h"
 #include "log.h"
 
 namespace ju {
@@ -64,6 +65,15 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 	cw.cout = f.cout;
 	cw.taps = f.taps;
 	cw.cinReal = f.cin;
+	if (m_Fp8Tower && name.rfind("generator/block_", 0) == 0 && f.cout == 64 && f.cin == 64) {
+		const Fp8ConvWeights q = packFp8TowerWeights(f);
+		Fp8Conv dev;
+		dev.w = DeviceBuffer(q.w.size());
+		dev.w.upload(q.w.data(), q.w.size());
+		dev.scaleA = DeviceBuffer(q.scaleA.size() * 4);
+		dev.scaleA.upload(q.scaleA.data(), q.scaleA.size() * 4);
+		m_Fp8Convs.emplace(name, std::move(dev));
+	}
 	if (towerLayer) {  // tower layers, in execution order
 		m_TowerHostW.insert(m_TowerHostW.end(), packed.begin(), packed.end());
 		m_TowerHostB.insert(m_TowerHostB.end(), f.bias.begin(), f.bias.end());
@@ -337,6 +347,34 @@ void Engine::buildProgram(int set) {
 			    launchResidentTower(dt, r, s);
 		    }});
 		a = 1;
+	} else if (m_Fp8Tower) {
+		// stream (fp16, trunk_a, updated in place) + e4m3 copies x8 / t8 of the conv inputs
+		void *streamBuf = m_Tensors.at("trunk_a").buf.get();
+		void *x8 = m_Fp8X.get(), *t8 = m_Fp8T.get();
+		const int e0 = m_Fp8Exp[0];
+		prog.push_back({"tower", 0.0,
+		    [=](hipStream_t s) { launchQuantizeTower(dt, streamBuf, x8, H, W, e0, s); }});
+		for (int i = 0; i < c.genBlocks; ++i) {
+			const std::string n = "generator/block_" + std::to_string(i + 1);
+			for (int j = 0; j < 2; ++j) {
+				const std::string name = n + (j ? "/conv_2" : "/conv_1");
+				const Fp8Conv &q = m_Fp8Convs.at(name);
+				Fp8TowerParams fp{};
+				fp.in8 = j ? t8 : x8;
+				fp.weights = q.w.get();
+				fp.scaleA = q.scaleA.as<int>();
+				fp.bias = m_Convs.at(name).bias.as<float>();
+				fp.stream = j ? streamBuf : nullptr;
+				fp.out8 = j ? x8 : t8;
+				fp.inExp = m_Fp8Exp[2 * i + j];
+				// the last block's e4m3 copy has no reader; any exponent will do
+				fp.outExp = (2 * i + j + 1 < 2 * c.genBlocks) ? m_Fp8Exp[2 * i + j + 1] : 0;
+				fp.H = H;
+				fp.W = W;
+				prog.push_back({"tower", 2.0 * H * W * 9.0 * 64 * 64,
+				    [=](hipStream_t s) { launchConvTowerFp8(dt, fp, s); }});
+			}
+		}
 	} else {
 		for (int i = 0; i < c.genBlocks; ++i) {
 			const std::string n = "generator/block_" + std::to_string(i + 1);
@@ -407,6 +445,13 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_Config = model.config();
 	const ModelConfig &c = m_Config;
 	int dt = dtypeOverride >= 0 ? dtypeOverride : c.computeDtype;
+	if (dt == 2) {
+		// JU_DTYPE_FP8: the 64->64 block convolutions run on e4m3 operands (fp8.h); the
+		// residual stream and every other layer stay fp16
+		if (c.genFilters != 64) throw std::invalid_argument("fp8 tower needs a 64-filter generator");
+		m_Fp8Tower = true;
+		dt = kF16;
+	}
 	if (dt != kF16 && dt != kBF16) throw std::invalid_argument("Unsupported compute dtype");
 	m_DType = static_cast<DType>(dt);
 	const int H = c.frameHeight, W = c.frameWidth;
@@ -432,7 +477,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		const char *mode = std::getenv("JU_TOWER");
 		int cus = 0;
 		JU_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-		const bool wanted = !(mode && std::string(mode) == "layers");
+		// (the 8-bit tower has a per-layer kernel only)
+		const bool wanted = !(mode && std::string(mode) == "layers") && !m_Fp8Tower;
 		if (wanted && c.genFilters == 64 && c.genBlocks >= 1 &&
 		    residentTowerGeometry(c.frameHeight, c.frameWidth, cus, &m_ResGX, &m_ResGY, &m_ResRH)) {
 			m_Resident = true;
@@ -505,6 +551,16 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	addTowerTensor("trunk_a", H, W, c.genFilters);
 	addTowerTensor("trunk_b", H, W, c.genFilters);
 	addTowerTensor("trunk_t", H, W, c.genFilters);
+	if (m_Fp8Tower) {
+		m_Fp8X = DeviceBuffer(towerPixels(H, W) * 64);
+		m_Fp8T = DeviceBuffer(towerPixels(H, W) * 64);
+		// activation ranges: optional calibration tensor, else one fixed scale (fp8.h)
+		m_Fp8Exp.assign(2 * static_cast<std::size_t>(c.genBlocks), fp8ActivationExponent(kFp8DefaultAmax));
+		if (model.has("generator/fp8_amax")) {
+			const TensorView &am = model.tensor("generator/fp8_amax", {2 * c.genBlocks});
+			for (int i = 0; i < 2 * c.genBlocks; ++i) m_Fp8Exp[i] = fp8ActivationExponent(am.data[i]);
+		}
+	}
 	addTensor("tail_y", lr * 128);
 	addTensor("tower_profile", 256 * 4 * 8 * 2, true);  // u64 cycle sums of the diagnostic tower variant
 

@@ -61,6 +61,8 @@ public:
 	FrameSize frameSize() const;
 	int device() const { return m_Device; }
 	DType dtype() const { return m_DType; }
+	// JU_DTYPE_* as reported to the caller: 2 when the block convolutions run in e4m3
+	int reportedDtype() const { return m_Fp8Tower ? 2 : static_cast<int>(m_DType); }
 	const ModelConfig &config() const { return m_Config; }
 	void setUseGraph(bool on) { m_UseGraph = on; }
 
@@ -143,6 +145,16 @@ private:
 
 	std::map<std::string, Tensor> m_Tensors;
 	std::map<std::string, ConvWeights> m_Convs;
+	// 8-bit tower (JU_DTYPE_FP8, fp8.h): e4m3 weights of the block convolutions, the two
+	// e4m3 activation tensors (block input, first conv's output) and the per-tensor
+	// exponents, index 2i = input of block i's conv_1, 2i+1 = input of its conv_2
+	struct Fp8Conv {
+		DeviceBuffer w, scaleA;
+	};
+	bool m_Fp8Tower = false;
+	std::map<std::string, Fp8Conv> m_Fp8Convs;
+	DeviceBuffer m_Fp8X, m_Fp8T;
+	std::vector<int> m_Fp8Exp;
 	DeviceBuffer m_TailW2, m_TailB2, m_TailW2Frag;
 	DeviceBuffer m_TemporalAcc;  // 32.32 fixed-point sum of |gen - pre_warp| (temporal filter)
 	bool m_FusedUpsample = true;  // flow decoder: bilinear x2 folded into the next conv's staging

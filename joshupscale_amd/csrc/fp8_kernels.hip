@@ -1,0 +1,381 @@
+// gfx950 (CDNA4, MI355X): 8-bit (OCP e4m3) form of the generator's residual-block
+// convolutions (reference scripts/training/models.py:193-254; the reference's own 8-bit
+// deployment is TensorRT INT8, scripts/inference/tensorrt/quantize_int8.py:140-209).
+// Quantisation scheme and operand packing: fp8.h.
+//
+//  * conv_tower_fp8_kernel   one 3x3 64->64 layer per launch on the block-scaled
+//                            matrix instruction v_mfma_scale_f32_32x32x64_f8f6f4:
+//                            K = 64 is exactly one tap of the 64-channel input, so a
+//                            32 px x 32 cout tile is 9 instructions
+//  * quantize_tower_kernel   16-bit tower tensor -> e4m3 copy (once per frame, after
+//                            the generator's conv_1)
+#include "kernel_common.h"
+
+namespace ju {
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Persistent, TWO workgroups per CU (4 waves each, two waves per SIMD): with one wave per
+// SIMD the tile pipeline is serial -- fragment reads, 36 matrix instructions, barrier,
+// epilogue -- and the matrix cores idle for 2/3 of it (measured: 6400 cycles per tile
+// against 2300 of MFMA); a second resident workgroup fills those gaps.  That caps a wave
+// at 256 registers and a workgroup at 80 KiB of LDS, hence the split:
+//   wave = (ch, rp): output channels 32 ch .. 32 ch + 31 of tile rows 4 rp .. 4 rp + 3.
+// Each wave keeps the weights of its 32 output channels in registers as A fragments
+// (9 taps x 8 VGPRs), so the LDS serves pixel fragments only (36 ds_read_b128 per 36
+// matrix instructions).  Input tiles (8 rows x 32 px + halo = 10 x 34 records of 64 B)
+// are double-buffered and fetched with global_load_lds; the wave's share of the skip
+// connection (4 rows x 32 px x 64 B) is DMA'd into its private 8 KiB LDS slice at the top
+// of the tile and the same slice then transposes the outputs, so that memory only sees
+// whole 64-byte (stream) and 32-byte (e4m3) half records.  One barrier per tile.
+constexpr int kF8Threads = 256;
+constexpr int kF8TileBytes = 22 * 1024;  // 340 records of 64 B, rounded up to whole 1 KiB DMA writes
+constexpr int kF8Slice = 8192;           // per wave
+constexpr int kF8Lds = 2 * kF8TileBytes + 4 * kF8Slice;  // 77824: two workgroups per CU
+
+// Buffer addressing (resource descriptor in SGPRs + 32-bit lane offset + scalar offset):
+// the loop-invariant lane offsets cost one VGPR each instead of a 64-bit address pair,
+// which is what keeps this kernel under the 256 registers of two waves per SIMD.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bufferOf(const void *base, unsigned bytes) {
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, static_cast<int>(bytes), 0x00020000);
+}
+// 16 bytes per lane, memory -> LDS without a VGPR round trip (lands at l + lane * 16)
+__device__ __forceinline__ void bufferToLds16(__amdgpu_buffer_rsrc_t r, unsigned laneOff, unsigned uniformOff,
+    void *l) {
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)l, 16,
+	    static_cast<int>(laneOff), static_cast<int>(uniformOff), 0, 0);
+}
+
+// e4m3 of four non-negative values, saturating (the hardware conversion returns NaN
+// above 448: tools/probes/fp8_mfma_probe.hip), packed into one dword
+__device__ __forceinline__ int quantize4(float a, float b, float c, float d, float mul) {
+	a = fminf(a * mul, 448.0f);
+	b = fminf(b * mul, 448.0f);
+	c = fminf(c * mul, 448.0f);
+	d = fminf(d * mul, 448.0f);
+	int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+	return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+
+struct Fp8KernelParams {
+	const unsigned char *in8;  // e4m3 tower-layout allocation start (row -1, col -1 of the image)
+	const unsigned char *wgt;  // fp8.h packFp8TowerWeights
+	const int *scaleA;         // [64] E8M0 codes, per output channel
+	const float *bias;         // [64]
+	const void *res;           // 16-bit stream, allocation start; nullptr: first conv of a block
+	void *outT;                // 16-bit stream out (may alias res), allocation start; nullptr: none
+	unsigned char *out8;       // e4m3 out, allocation start
+	int scaleB;                // E8M0 code of the input tensor's scale 2^-ea
+	float outMul;              // 2^ea of the output tensor
+	int H, W, pitch;           // pitch in pixels
+	int tilesX, numTiles;
+	unsigned bytes8, bytesT;   // sizes of the e4m3 / 16-bit tensors
+};
+
+// STREAM: second conv of a block: + skip connection, writes the 16-bit stream too
+template <typename T, bool STREAM>
+__global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8KernelParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	unsigned char *smT = smem;
+	const int tid = threadIdx.x;
+	// wave-uniform values in SGPRs: addresses below are "uniform base + 32-bit lane offset"
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int lane = tid & 63;
+	const int px = lane & 31;
+	const int hh = lane >> 5;
+	const int ch = wave & 1;
+	const int rp = wave >> 1;
+	unsigned char *slice = smem + 2 * kF8TileBytes + wave * kF8Slice;
+	// half-record transfers (skip DMA, stream store): instruction i moves pixels
+	// 16 i + (lane >> 2) of the wave's 4 x 32; the chunk swizzle (pi >> 2) & 3 = (lane >> 4) & 3
+	// does not depend on i
+	const unsigned halfOff = (lane >> 2) * 128 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);  // bytes
+
+	// XCD-aware tile order (as conv_tower_kernel): each XCD gets a contiguous run of tiles
+	const int nwg = gridDim.x;
+	const int bid = blockIdx.x;
+	const int perX = (nwg + 7) >> 3;
+	const int slot = (bid & 7) * perX + (bid >> 3);
+
+	const __amdgpu_buffer_rsrc_t rsIn = bufferOf(p.in8, p.bytes8);
+	const __amdgpu_buffer_rsrc_t rsOut8 = bufferOf(p.out8, p.bytes8);
+	const __amdgpu_buffer_rsrc_t rsT = bufferOf(STREAM ? p.res : p.in8, STREAM ? p.bytesT : 0u);
+
+	// Tile in LDS: record q = r * 34 + x at q * 64; 16-byte chunk c of column x sits at
+	// position c ^ ((x >> 2) & 3): a fragment read (16 consecutive columns per quarter wave)
+	// covers all 64 banks, and the swizzle does not depend on the row, so the 6 rows of a
+	// tap are immediate offsets from one address.
+	auto stageTile = [&](int tile, int buf) {
+		const int ty = tile / p.tilesX;
+		const int tx = tile - ty * p.tilesX;
+		const unsigned base = static_cast<unsigned>(((ty * 8) * p.pitch + tx * 32) * 64);
+		unsigned char *dst = smT + buf * kF8TileBytes;
+#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			const int i = wave + 4 * k;          // wave-instruction index: 16 records each
+			const int q = i * 16 + (lane >> 2);  // record index inside the 10 x 34 tile
+			if (i < 22 && q < 340) {
+				const int r = q / 34;
+				const int x = q - r * 34;
+				const int c = (lane & 3) ^ ((x >> 2) & 3);  // swizzled on the SOURCE side (DMA writes lane-linear)
+				bufferToLds16(rsIn, static_cast<unsigned>((r * p.pitch + x) * 64 + c * 16), base, dst + i * 1024);
+			}
+		}
+	};
+
+	int tile = slot;
+	if (tile < p.numTiles) stageTile(tile, 0);
+
+	// ---- the weights of this wave's 32 output channels: 9 A fragments of 32 bytes per lane ----
+	i32x8 wf[9];
+	{
+		const i32x4 *wsrc = reinterpret_cast<const i32x4 *>(p.wgt);
+#pragma unroll
+		for (int t = 0; t < 9; ++t) {
+			const i32x4 lo = wsrc[((t * 2 + ch) * 64 + lane) * 2];
+			const i32x4 hi = wsrc[((t * 2 + ch) * 64 + lane) * 2 + 1];
+			wf[t] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+		}
+	}
+	const int scA = p.scaleA[ch * 32 + px];
+	const int scB = p.scaleB;
+	f32x4 biasv[4];
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		biasv[g] = *reinterpret_cast<const f32x4 *>(p.bias + ch * 32 + 8 * g + 4 * hh);
+	}
+
+	__syncthreads();  // the first tile has landed (the barrier's fence waits for vmcnt(0))
+
+	int buf = 0;
+	const int stride = perX * 8;
+	for (; tile < p.numTiles; tile += stride, buf ^= 1) {
+		const int ty = tile / p.tilesX;
+		const int tx = tile - ty * p.tilesX;
+		const int gy0 = ty * 8 + rp * 4;  // first image row of this wave
+		const int gx0 = tx * 32;
+
+		// skip connection: this wave's 4 rows x 32 px half records (channels 32 ch ..), DMA'd
+		// into its slice; lands during the K loop.  Slice layout: pixel pi = rw * 32 + px at
+		// pi * 64, 16-byte chunk c at position c ^ ((pi >> 2) & 3) (conflict-free b64 access).
+		if constexpr (STREAM) {
+			// rows beyond H and columns beyond W read the zero border / the next tile:
+			// harmless, those pixels are never stored
+			const unsigned base = static_cast<unsigned>(((gy0 + 1) * p.pitch + gx0 + 1) * 128 + ch * 64);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				bufferToLds16(rsT, halfOff, base + static_cast<unsigned>(((i >> 1) * p.pitch + (i & 1) * 16) * 128),
+				    slice + i * 1024);
+			}
+		}
+		// every wave is done with the other tile buffer (barrier of the previous
+		// iteration): refill it
+		const int next = tile + stride;
+		if (next < p.numTiles) stageTile(next, buf ^ 1);
+		f32x16 acc[4];
+#pragma unroll
+		for (int rw = 0; rw < 4; ++rw) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				acc[rw][4 * g + 0] = biasv[g][0];
+				acc[rw][4 * g + 1] = biasv[g][1];
+				acc[rw][4 * g + 2] = biasv[g][2];
+				acc[rw][4 * g + 3] = biasv[g][3];
+			}
+		}
+
+		// ---- K loop: per horizontal tap dx, the wave's 6 input rows (6 B fragments of
+		// 32 bytes: channels 32h .. 32h+31 of the lane's pixel) feed 12 instructions ----
+		const unsigned char *tileBase = smT + buf * kF8TileBytes;
+#pragma unroll
+		for (int dx = 0; dx < 3; ++dx) {
+			// (keeps hipcc from hoisting all 18 fragments above the first instruction:
+			// 144 VGPRs, spills)
+			__builtin_amdgcn_sched_barrier(0);
+			i32x8 fb[6];
+			const int x = px + dx;
+			const int sw = (x >> 2) & 3;
+			const unsigned char *col = tileBase + ((rp * 4) * 34 + x) * 64;
+			const unsigned char *colLo = col + (((2 * hh) ^ sw) << 4);
+			const unsigned char *colHi = col + (((2 * hh + 1) ^ sw) << 4);
+#pragma unroll
+			for (int r = 0; r < 6; ++r) {
+				const i32x4 lo = *reinterpret_cast<const i32x4 *>(colLo + r * (34 * 64));
+				const i32x4 hi = *reinterpret_cast<const i32x4 *>(colHi + r * (34 * 64));
+				fb[r] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+			}
+#pragma unroll
+			for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+				for (int rw = 0; rw < 4; ++rw) {
+					acc[rw] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+					    wf[dy * 3 + dx], fb[rw + dy], acc[rw], 0, 0, 0, scA, 0, scB);
+				}
+			}
+		}
+
+		// every wave is done with this tile's input; the next tile and the skip records
+		// have landed (the barrier's fence waits for this wave's DMA: vmcnt(0))
+		__syncthreads();
+
+		// ---- epilogue: bias is in the accumulator; + skip, ReLU ----
+		if constexpr (STREAM) {
+			// skip values out of the slice, results back into the same places
+#pragma unroll
+			for (int rw = 0; rw < 4; ++rw) {
+				const int pi = rw * 32 + px;
+				unsigned char *rec = slice + pi * 64 + hh * 8;
+				const int sw = (pi >> 2) & 3;
+				Vec4<T> rv[4];
+#pragma unroll
+				for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const Vec4<T> *>(rec + ((g ^ sw) << 4));
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						acc[rw][4 * g + i] = fmaxf(acc[rw][4 * g + i] + static_cast<float>(rv[g][i]), 0.0f);
+					}
+					*reinterpret_cast<Vec4<T> *>(rec + ((g ^ sw) << 4)) =
+					    pack4<T>(acc[rw][4 * g], acc[rw][4 * g + 1], acc[rw][4 * g + 2], acc[rw][4 * g + 3]);
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			const unsigned base = static_cast<unsigned>(((gy0 + 1) * p.pitch + gx0 + 1) * 128 + ch * 64);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const i32x4 val = *reinterpret_cast<const i32x4 *>(slice + i * 1024 + lane * 16);
+				const int gy = gy0 + (i >> 1);
+				const int gx = gx0 + (i & 1) * 16 + (lane >> 2);
+				if (gy < p.H && gx < p.W) {
+					__builtin_amdgcn_raw_buffer_store_b128(val, rsT, static_cast<int>(halfOff),
+					    static_cast<int>(base + static_cast<unsigned>(((i >> 1) * p.pitch + (i & 1) * 16) * 128)), 0);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int rw = 0; rw < 4; ++rw) {
+#pragma unroll
+				for (int i = 0; i < 16; ++i) acc[rw][i] = fmaxf(acc[rw][i], 0.0f);
+			}
+		}
+		// e4m3 copy through the slice: [rw][g][px][hh] dwords (every write instruction covers
+		// all 64 banks once); a half record (32 B) is read back as four 8-byte pieces
+#pragma unroll
+		for (int rw = 0; rw < 4; ++rw) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				*reinterpret_cast<int *>(slice + ((rw * 4 + g) * 64 + px * 2 + hh) * 4) =
+				    quantize4(acc[rw][4 * g], acc[rw][4 * g + 1], acc[rw][4 * g + 2], acc[rw][4 * g + 3], p.outMul);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {  // one tile row per instruction: lane = (pixel, 16-byte half)
+			const int pxo = lane >> 1;
+			const int c = lane & 1;  // channels 32 ch + 16 c .. + 15  =  g in {2c, 2c+1}
+			typedef int i32x2 __attribute__((ext_vector_type(2)));
+			const i32x2 a = *reinterpret_cast<const i32x2 *>(slice + ((i * 4 + 2 * c) * 64 + pxo * 2) * 4);
+			const i32x2 b = *reinterpret_cast<const i32x2 *>(slice + ((i * 4 + 2 * c + 1) * 64 + pxo * 2) * 4);
+			const int gy = gy0 + i;
+			const int gx = gx0 + pxo;
+			if (gy < p.H && gx < p.W) {
+				__builtin_amdgcn_raw_buffer_store_b128(i32x4{a[0], a[1], b[0], b[1]}, rsOut8, pxo * 64 + c * 16,
+				    ((gy + 1) * p.pitch + gx0 + 1) * 64 + ch * 32, 0);
+			}
+		}
+		// the slice is read out before the next tile's skip DMA refills it: LDS reads of
+		// one wave complete in order, but the DMA is a memory operation -- wait for them
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	}
+}
+
+// 16-bit tower tensor -> e4m3 copy (interior pixels only: the border stays zero)
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_tower_kernel(const T *__restrict__ in,
+    unsigned char *__restrict__ out, int H, int W, int pitch, float mul) {
+	const int i = blockIdx.x * 256 + threadIdx.x;  // one 16-channel chunk per thread
+	const int chunk = i & 3;
+	const int pix = i >> 2;
+	if (pix >= H * W) return;
+	const int y = pix / W, x = pix - y * W;
+	const size_t rec = (size_t)(y + 1) * pitch + x + 1;
+	const Vec8<T> a = *reinterpret_cast<const Vec8<T> *>(in + rec * 64 + chunk * 16);
+	const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(in + rec * 64 + chunk * 16 + 8);
+	float v[16];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		v[k] = fmaxf(static_cast<float>(a[k]), 0.0f);
+		v[8 + k] = fmaxf(static_cast<float>(b[k]), 0.0f);
+	}
+	i32x4 o;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) o[k] = quantize4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], mul);
+	*reinterpret_cast<i32x4 *>(out + rec * 64 + chunk * 16) = o;
+}
+
+template <typename T, bool STREAM>
+void launchFp8T(const Fp8KernelParams &k, int grid, hipStream_t stream) {
+	auto kern = conv_tower_fp8_kernel<T, STREAM>;
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kF8Lds, &ldsDone, "fp8 tower");
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(kF8Threads), kF8Lds, stream, k);
+	hipCheckLaunch("conv_tower_fp8");
+}
+
+}  // namespace
+
+void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
+	Fp8KernelParams k{};
+	k.in8 = static_cast<const unsigned char *>(q.in8);
+	k.wgt = static_cast<const unsigned char *>(q.weights);
+	k.scaleA = q.scaleA;
+	k.bias = q.bias;
+	k.res = q.stream;
+	k.outT = q.stream;  // in place: a lane's skip values are read before its wave writes the records
+	k.out8 = static_cast<unsigned char *>(q.out8);
+	k.scaleB = 127 - q.inExp;
+	k.outMul = std::ldexp(1.0f, q.outExp);
+	k.H = q.H;
+	k.W = q.W;
+	k.pitch = towerPitch(q.W);
+	k.tilesX = (q.W + 31) / 32;
+	k.numTiles = k.tilesX * ((q.H + 7) / 8);
+	k.bytes8 = static_cast<unsigned>(towerPixels(q.H, q.W) * 64);
+	k.bytesT = static_cast<unsigned>(towerPixels(q.H, q.W) * 128);
+	int dev = 0, cus = 256;
+	if (hipGetDevice(&dev) == hipSuccess) {
+		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	}
+	const int grid = k.numTiles < 2 * cus ? k.numTiles : 2 * cus;  // two workgroups per CU
+	if (q.stream != nullptr) {
+		if (dt == kF16) launchFp8T<f16, true>(k, grid, stream);
+		else launchFp8T<bf16, true>(k, grid, stream);
+	} else {
+		if (dt == kF16) launchFp8T<f16, false>(k, grid, stream);
+		else launchFp8T<bf16, false>(k, grid, stream);
+	}
+}
+
+void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int exponent,
+    hipStream_t stream) {
+	const int n = H * W * 4;
+	const float mul = std::ldexp(1.0f, exponent);
+	const int pitch = towerPitch(W);
+	if (dt == kF16) {
+		hipLaunchKernelGGL(quantize_tower_kernel<f16>, dim3((n + 255) / 256), dim3(256), 0, stream,
+		    static_cast<const f16 *>(in), static_cast<unsigned char *>(out8), H, W, pitch, mul);
+	} else {
+		hipLaunchKernelGGL(quantize_tower_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, stream,
+		    static_cast<const bf16 *>(in), static_cast<unsigned char *>(out8), H, W, pitch, mul);
+	}
+	hipCheckLaunch("quantize_tower");
+}
+
+}  // namespace ju

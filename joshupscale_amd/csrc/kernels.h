@@ -110,6 +110,25 @@ void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
 // pitch == towerPitch(W); other shapes fall back to launchConv.
 void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream);
 
+// ---- 8-bit (e4m3) residual-block convolution (fp8_kernels.hip, scheme: fp8.h) ---
+// All tensors are tower-layout ALLOCATION STARTS (row -1, column -1 of the image).
+struct Fp8TowerParams {
+	const void *in8;      // e4m3 input, 64 B per pixel
+	const void *weights;  // packFp8TowerWeights().w on the device
+	const int *scaleA;    // [64] E8M0 codes per output channel
+	const float *bias;    // [64]
+	void *stream;         // second conv of a block: the 16-bit residual stream, updated in place
+	                      // (out = relu(conv + stream)); nullptr: first conv (out = relu(conv))
+	void *out8;           // e4m3 copy of the output (the next convolution's input)
+	int inExp;            // the input tensor holds e4m3(x * 2^inExp)
+	int outExp;           // the output copy holds e4m3(y * 2^outExp)
+	int H, W;
+};
+void launchConvTowerFp8(DType dt, const Fp8TowerParams &p, hipStream_t stream);
+// e4m3(max(x, 0) * 2^exponent) of a 16-bit tower tensor (allocation starts)
+void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int exponent,
+    hipStream_t stream);
+
 // ---- resident tower: every residual-block convolution in one launch --------
 // in: first layer's input addressed at image pixel (0,0) with row pitch inPitch
 // (0 = dense W); out: tower-layout tensor addressed at its interior origin.

@@ -107,7 +107,9 @@ void validateConfig(const ModelConfig &c) {
 	}
 	if (c.numFlowInputs < 1 || c.numFlowInputs > 5) bad("1..5 flow inputs supported");
 	if (c.flowArch != 0 && c.flowArch != 1) bad("unknown flow architecture");
-	if (c.computeDtype != kF16 && c.computeDtype != kBF16) bad("unknown compute dtype");
+	if (c.computeDtype != kF16 && c.computeDtype != kBF16 && c.computeDtype != 2) {
+		bad("unknown compute dtype");  // 2 = JU_DTYPE_FP8 (e4m3 block convolutions over fp16)
+	}
 	if (c.flowPadFactor < 0 || c.flowPadFactor > 256) bad("flow_pad_factor must be in 0..256");
 	if (c.genFilters <= 0 || c.genFilters > 1024 || c.genFilters % 32 != 0) {
 		bad("gen_filters must be a multiple of 32 (at most 1024)");

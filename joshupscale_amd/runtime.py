@@ -28,7 +28,10 @@ _LIB: Optional[C.CDLL] = None
 
 LOC_CPU, LOC_DEVICE, LOC_GRAPHICS_RESOURCE = 0, 1, 2
 DTYPE_DEFAULT, DTYPE_F16, DTYPE_BF16 = -1, 0, 1
-DTYPE_NAMES = {DTYPE_F16: "fp16", DTYPE_BF16: "bf16"}
+# the 64->64 block convolutions of the generator on e4m3 operands (csrc/fp8.h), every
+# other layer and the residual stream fp16
+DTYPE_FP8 = 2
+DTYPE_NAMES = {DTYPE_F16: "fp16", DTYPE_BF16: "bf16", DTYPE_FP8: "fp8"}
 
 
 class JuImage(C.Structure):

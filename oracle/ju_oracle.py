@@ -65,6 +65,11 @@ class ModelConfig:
     # script: window 0, gain 0, L1, no limit, no luma weighting); strength 0 = absent
     temporal_strength: float = 0.0
     temporal_threshold: float = 0.1
+    # BASELINE.json config 5: the 64->64 block convolutions of the generator on 8-bit
+    # (OCP e4m3) operands.  Not a reference feature as such -- the reference's 8-bit
+    # deployment is TensorRT INT8 (scripts/inference/tensorrt/quantize_int8.py) -- so
+    # this restates the BUILD's scheme (joshupscale_amd/csrc/fp8.h) for parity checks.
+    fp8_tower: bool = False
 
     @property
     def padded_height(self) -> int:
@@ -273,6 +278,61 @@ def res_block(x, wts: Weights, name: str, eps: float) -> np.ndarray:
     return relu(y + x)
 
 
+# --------------------------------------------------------------------------
+# 8-bit tower (scheme of joshupscale_amd/csrc/fp8.h, restated)
+# --------------------------------------------------------------------------
+FP8_DEFAULT_AMAX = 7.0
+
+
+def e4m3_round(x: np.ndarray) -> np.ndarray:
+    """Nearest OCP e4m3fn value, ties to even, saturating at +-448: 3 mantissa bits,
+    normal exponents -6..8, subnormal step 2^-9."""
+    x = np.asarray(x, np.float64)
+    a = np.minimum(np.abs(x), 448.0)
+    _, e = np.frexp(a)                       # a = m * 2^e, m in [0.5, 1)
+    step = np.exp2(np.maximum(e - 1, -6) - 3.0)
+    q = np.minimum(np.round(a / step) * step, 448.0)   # np.round: half to even
+    return np.copysign(q, x)
+
+
+def fp8_activation_exponent(amax: float) -> int:
+    """Power-of-two scale with one bit of headroom: amax * 2^e in (112, 224]."""
+    if not (amax > 0 and np.isfinite(amax)):
+        return 0
+    return int(np.clip(np.floor(np.log2(224.0 / amax)), -16, 16))
+
+
+def _fold_bn(wts: Weights, conv: str, bn: str, eps: float):
+    """BN folded into the convolution, in float32 like the engine's loader."""
+    k = np.asarray(wts[conv + "/kernel"], np.float32)
+    g = np.asarray(wts[bn + "/gamma"], np.float32)
+    scale = g / np.sqrt(np.asarray(wts[bn + "/moving_variance"], np.float32) + np.float32(eps))
+    bias = np.asarray(wts[bn + "/beta"], np.float32) - np.asarray(wts[bn + "/moving_mean"], np.float32) * scale
+    return (k * scale).astype(np.float32), bias.astype(np.float32)
+
+
+def fp8_quantize_weights(k: np.ndarray) -> np.ndarray:
+    """Per OUTPUT channel: 2^ew with max|w| * 2^ew in (224, 448], e4m3, scaled back."""
+    amax = np.abs(k).reshape(-1, k.shape[-1]).max(axis=0).astype(np.float64)
+    ew = np.where(amax > 0, np.floor(np.log2(448.0 / np.maximum(amax, 1e-300))), 0.0)
+    ew = np.clip(ew, -32, 32)
+    return e4m3_round(k.astype(np.float64) * np.exp2(ew)) * np.exp2(-ew)
+
+
+def fp8_quantize_activation(x: np.ndarray, exponent: int) -> np.ndarray:
+    return e4m3_round(np.minimum(x * 2.0 ** exponent, 448.0)) * 2.0 ** -exponent
+
+
+def res_block_fp8(x, wts: Weights, name: str, eps: float, ex: int, et: int) -> np.ndarray:
+    """res_block with both convolutions on e4m3 operands; bias, ReLU and the skip
+    connection in full precision (the stream ``x`` itself is never quantised)."""
+    k1, b1 = _fold_bn(wts, name + "/conv_1", name + "/bn_1", eps)
+    k2, b2 = _fold_bn(wts, name + "/conv_2", name + "/bn_2", eps)
+    t = relu(conv2d_same(fp8_quantize_activation(x, ex), fp8_quantize_weights(k1)) + b1)
+    y = conv2d_same(fp8_quantize_activation(t, et), fp8_quantize_weights(k2)) + b2
+    return relu(y + x)
+
+
 def flow_autoencoder(frames: Sequence[np.ndarray], wts: Weights,
                      cfg: ModelConfig, trace: Optional[dict] = None) -> np.ndarray:
     """``get_flow_autoencoder`` (models.py:334-481).  Returns the flow field
@@ -326,8 +386,15 @@ def generator(images: np.ndarray, pre_warp: np.ndarray, wts: Weights,
     _rec(trace, "gen_in_ref", x)  # reference channel order, 51 channels
     x = _conv_bn_act(x, wts, "generator/conv_1", "generator/bn_1", eps)
     _rec(trace, "gen_head", x)
+    if cfg.fp8_tower:
+        amax = wts.get("generator/fp8_amax")
+        exps = [fp8_activation_exponent(FP8_DEFAULT_AMAX if amax is None else float(np.float32(amax[j])))
+                for j in range(2 * cfg.gen_blocks)]
     for i in range(cfg.gen_blocks):
-        x = res_block(x, wts, f"generator/block_{i + 1}", eps)
+        if cfg.fp8_tower:
+            x = res_block_fp8(x, wts, f"generator/block_{i + 1}", eps, exps[2 * i], exps[2 * i + 1])
+        else:
+            x = res_block(x, wts, f"generator/block_{i + 1}", eps)
     _rec(trace, "trunk", x)
     x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_1/kernel"])
     b = "generator/bn_2"

@@ -13,7 +13,7 @@ from joshupscale_amd import model_file as M  # noqa: E402
 from oracle import ju_oracle as O  # noqa: E402
 
 
-def oracle_config(cfg: M.ModelConfig) -> O.ModelConfig:
+def oracle_config(cfg: M.ModelConfig, fp8_tower: bool = False) -> O.ModelConfig:
     """Oracle configuration equal to a container configuration (bn_eps goes
     through float32 exactly as it does in the file header)."""
     return O.ModelConfig(
@@ -25,7 +25,8 @@ def oracle_config(cfg: M.ModelConfig) -> O.ModelConfig:
         normalize_brightness=cfg.normalize_brightness,
         bn_eps=float(np.float32(cfg.bn_eps)),
         temporal_strength=float(np.float32(cfg.temporal_strength)),
-        temporal_threshold=float(np.float32(cfg.temporal_threshold)))
+        temporal_threshold=float(np.float32(cfg.temporal_threshold)),
+        fp8_tower=fp8_tower)
 
 
 def small_config(**kw) -> M.ModelConfig:
