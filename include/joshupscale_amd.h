@@ -157,6 +157,10 @@ JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double
  * (launch the resident tower n workgroups short: tests the fallback). */
 JU_API int ju_debug_set(const char *key, int value);
 
+/* The loader's e4m3 quantiser (round to nearest even, saturating at +-448), exposed so
+ * that the CPU tests can pin it against the oracle's restatement.  No device needed. */
+JU_API int ju_debug_e4m3(const float *values, unsigned char *codes, size_t count);
+
 /* Library version string, e.g. "joshupscale-amd 0.1 (gfx950)". */
 JU_API const char *ju_version(void);
 

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "fp8.h"
 #include "log.h"
 #include "model.h"
 
@@ -200,6 +201,13 @@ int ju_debug_set(const char *key, int value) {
 		if (k == "tower_variant") ju::setTowerVariant(value);
 		else if (k == "resident_fault") ju::setResidentFault(value);
 		else throw std::invalid_argument("unknown debug key " + k);
+	});
+}
+
+int ju_debug_e4m3(const float *values, unsigned char *codes, size_t count) {
+	return guarded([&] {
+		if (count && (!values || !codes)) throw std::invalid_argument("ju_debug_e4m3: null buffer");
+		for (size_t i = 0; i < count; ++i) codes[i] = ju::e4m3FromFloat(values[i]);
 	});
 }
 

@@ -94,11 +94,21 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 	// does not depend on i
 	const unsigned halfOff = (lane >> 2) * 128 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4);  // bytes
 
-	// XCD-aware tile order (as conv_tower_kernel): each XCD gets a contiguous run of tiles
+	// XCD-aware tile order: workgroups b, b+8, ... share an XCD (and its L2); in every full
+	// round each XCD gets a contiguous run of tiles.  The tiles of the last, partial round
+	// are dealt out one per workgroup in launch order instead, which spreads them over all
+	// XCDs and CUs (the contiguous order gave them all to the first XCDs: 6 tiles on some
+	// CUs, 4 on the others).  The launcher keeps the grid a multiple of 8.
 	const int nwg = gridDim.x;
 	const int bid = blockIdx.x;
-	const int perX = (nwg + 7) >> 3;
-	const int slot = (bid & 7) * perX + (bid >> 3);
+	const int slot = nwg >= 8 ? (bid & 7) * (nwg >> 3) + (bid >> 3) : bid;
+	const int fullTiles = p.numTiles / nwg * nwg;
+	auto tileAt = [&](int k) {
+		const int base = k * nwg;
+		if (base < fullTiles) return base + slot;
+		if (fullTiles == 0) return (k == 0 && slot < p.numTiles) ? slot : -1;  // one round, surplus workgroups idle
+		return (base == fullTiles && base + bid < p.numTiles) ? base + bid : -1;
+	};
 
 	const __amdgpu_buffer_rsrc_t rsIn = bufferOf(p.in8, p.bytes8);
 	const __amdgpu_buffer_rsrc_t rsOut8 = bufferOf(p.out8, p.bytes8);
@@ -126,8 +136,9 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 		}
 	};
 
-	int tile = slot;
-	if (tile < p.numTiles) stageTile(tile, 0);
+	int round = 0;
+	int tile = tileAt(0);
+	if (tile >= 0) stageTile(tile, 0);
 
 	// ---- the weights of this wave's 32 output channels: 9 A fragments of 32 bytes per lane ----
 	i32x8 wf[9];
@@ -151,8 +162,8 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 	__syncthreads();  // the first tile has landed (the barrier's fence waits for vmcnt(0))
 
 	int buf = 0;
-	const int stride = perX * 8;
-	for (; tile < p.numTiles; tile += stride, buf ^= 1) {
+	for (; tile >= 0; buf ^= 1) {
+		const int next = tileAt(++round);
 		const int ty = tile / p.tilesX;
 		const int tx = tile - ty * p.tilesX;
 		const int gy0 = ty * 8 + rp * 4;  // first image row of this wave
@@ -173,8 +184,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 		}
 		// every wave is done with the other tile buffer (barrier of the previous
 		// iteration): refill it
-		const int next = tile + stride;
-		if (next < p.numTiles) stageTile(next, buf ^ 1);
+		if (next >= 0) stageTile(next, buf ^ 1);
 		f32x16 acc[4];
 #pragma unroll
 		for (int rw = 0; rw < 4; ++rw) {
@@ -293,6 +303,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 		// the slice is read out before the next tile's skip DMA refills it: LDS reads of
 		// one wave complete in order, but the DMA is a memory operation -- wait for them
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		tile = next;
 	}
 }
 
@@ -353,7 +364,10 @@ void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
 	if (hipGetDevice(&dev) == hipSuccess) {
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	}
-	const int grid = k.numTiles < 2 * cus ? k.numTiles : 2 * cus;  // two workgroups per CU
+	int grid = k.numTiles < 2 * cus ? k.numTiles : 2 * cus;  // two workgroups per CU
+	// the kernel's XCD tile order needs a multiple of 8: round up when everything fits one
+	// round (surplus workgroups exit), down otherwise
+	if (grid > 8) grid = k.numTiles <= 2 * cus ? (grid + 7) / 8 * 8 : grid - grid % 8;
 	if (q.stream != nullptr) {
 		if (dt == kF16) launchFp8T<f16, true>(k, grid, stream);
 		else launchFp8T<bf16, true>(k, grid, stream);

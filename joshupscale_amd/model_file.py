@@ -23,7 +23,7 @@ Layout (all little endian):
     48  u32      gen_blocks, flow_res_filters, flow_res_blocks, n_flow_filters
     64  u32[8]   flow_filters
     96  f32      bn_eps
-    100 u32      compute_dtype hint (0 fp16, 1 bf16)
+    100 u32      compute_dtype hint (0 fp16, 1 bf16, 2 fp8 = e4m3 block convolutions over fp16)
     104 u32      n_tensors
     108 f32      temporal_strength (0 = filter off), temporal_threshold
     116 u32      reserved[3]                        -> header_bytes = 128
@@ -46,6 +46,7 @@ HEADER_BYTES = 128
 ENTRY_BYTES = 128
 DTYPE_F16 = 0
 DTYPE_BF16 = 1
+DTYPE_FP8 = 2  # e4m3 block convolutions over fp16 (csrc/fp8.h)
 
 FLOW_ARCH = {"autoencoder": 0, "resnet": 1}
 FLOW_ARCH_INV = {v: k for k, v in FLOW_ARCH.items()}
@@ -91,7 +92,7 @@ class ModelConfig:
 PRESETS: Dict[str, ModelConfig] = {
     "psp-quality": ModelConfig(),
     "psp-fast": ModelConfig(gen_blocks=8, compute_dtype=DTYPE_F16),
-    "ps2-quality": ModelConfig(frame_height=448, frame_width=640),
+    "ps2-quality": ModelConfig(frame_height=448, frame_width=640),  # BASELINE config 5 runs it with dtype fp8
     "psp-quality-flowres": ModelConfig(flow_arch="resnet", flow_pad_factor=0),
 }
 

@@ -88,6 +88,7 @@ def load_library() -> C.CDLL:
         "ju_get_gl_device_index": (C.c_int, [P(C.c_int)]),
         "ju_get_gl_image": (C.c_int, [C.c_uint32, C.c_int, P(JuImage)]),
         "ju_get_dtype": (C.c_int, [C.c_void_p]),
+        "ju_debug_e4m3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "ju_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
                                      P(C.c_size_t)]),
         "ju_time_steps": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, P(C.c_double),

@@ -38,9 +38,11 @@ def main() -> int:
         clip = M.synthetic_frames(args.frames, h, w, seed=1234, kind=kind)
         ref = CSession(blob, h, w)
         refs = [ref.run(f) for f in clip]
-        for name, dt in (("bf16", R.DTYPE_BF16), ("fp16", R.DTYPE_F16)):
+        outs = {}
+        for name, dt in (("bf16", R.DTYPE_BF16), ("fp16", R.DTYPE_F16), ("fp8", R.DTYPE_FP8)):
             rt = R.Runtime(blob, 0, dt)
-            stats = [u8_stats(rt.process_image(f), r) for f, r in zip(clip, refs)]
+            outs[name] = [rt.process_image(f).copy() for f in clip]
+            stats = [u8_stats(o, r) for o, r in zip(outs[name], refs)]
             rt.close()
             report["clips"][f"{kind}/{name}"] = {
                 "psnr_db_min": round(min(s["psnr"] for s in stats), 2),
@@ -49,6 +51,14 @@ def main() -> int:
                 "max_abs_u8": max(s["max"] for s in stats),
                 "bytes_off_by_more_than_1_percent": round(100 * max(s["frac_gt1"] for s in stats), 4),
             }
+        # BASELINE.json config 5: the 8-bit tower against the bf16 engine, frame by frame
+        vs = [u8_stats(a, b) for a, b in zip(outs["fp8"], outs["bf16"])]
+        report["clips"][f"{kind}/fp8_vs_bf16_engine"] = {
+            "psnr_db_min": round(min(s["psnr"] for s in vs), 2),
+            "psnr_db_mean": round(float(np.mean([s["psnr"] for s in vs])), 2),
+            "max_abs_u8": max(s["max"] for s in vs),
+            "bytes_off_by_more_than_1_percent": round(100 * max(s["frac_gt1"] for s in vs), 4),
+        }
     print(json.dumps(report, indent=1))
     return 0
 

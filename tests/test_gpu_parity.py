@@ -505,3 +505,100 @@ def test_flow_resnet_resident_and_per_layer_paths_agree(monkeypatch):
     sess = O.Session(wts, oracle_config(cfg))
     for f, out in zip(frames, fused):
         check_u8(out, sess.run(f), R.DTYPE_BF16, "flowres-resident")
+
+
+# ---------------------------------------------------------------------------
+# 8-bit tower (BASELINE.json config 5): e4m3 block convolutions, csrc/fp8.h
+# ---------------------------------------------------------------------------
+def _psnr(a, b):
+    d = a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)
+    return 99.0 if not d.any() else 10 * np.log10(255.0 ** 2 / np.mean(d * d))
+
+
+def _fp8_case(cfg, wts, frames):
+    """Engine (fp8) against the oracle's restatement of the same scheme and against the
+    float oracle.  Rounding to a 3-bit mantissa amplifies last-bit differences of the
+    16-bit layers in front into whole e4m3 steps, so the engine cannot track the 8-bit
+    oracle much more closely than the quantisation noise itself; what must hold:
+      * it is as close to the float oracle as the 8-bit oracle is (same noise level:
+        within 0.5 dB),
+      * it is closer to the 8-bit oracle than that oracle is to the float one (it
+        reproduces the SAME quantisation, not merely a similar amount of noise),
+      * the tower output agrees with the 8-bit oracle to a fraction of the noise."""
+    blob = M.serialize(cfg, wts)
+    rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+    assert rt.dtype == R.DTYPE_FP8
+    h, w = cfg.frame_height, cfg.frame_width
+    s8, sf = O.Session(wts, oracle_config(cfg, fp8_tower=True)), O.Session(wts, oracle_config(cfg))
+    for t, f in enumerate(frames):
+        t8, tf = {}, {}
+        r8, rf = s8.run(f, t8), sf.run(f, tf)
+        out = rt.process_image(f)
+        assert (out[..., 3] == 0).all()
+        p_eng_f, p_orc_f, p_eng_orc = _psnr(out, rf), _psnr(r8, rf), _psnr(out, r8)
+        assert abs(p_eng_f - p_orc_f) <= 0.5, (t, p_eng_f, p_orc_f)
+        assert p_eng_orc >= p_orc_f + 0.5, (t, p_eng_orc, p_orc_f)
+        trunk = rt.read_tensor("trunk").reshape(h, w, 64)
+        noise = err(t8["trunk"], tf["trunk"])["rms"]
+        assert err(trunk, t8["trunk"])["rms"] <= 0.95 * noise, (t, err(trunk, t8["trunk"]), noise)
+        assert err(trunk, tf["trunk"])["rms"] <= 1.1 * noise
+    rt.close()
+
+
+@pytest.mark.parametrize("h,w,blocks", [
+    (30, 48, 3),     # 8 tiles: one round, grid = tiles
+    (34, 50, 2),     # 10 tiles, ragged edges: grid rounded up to 16, surplus workgroups idle
+    (64, 96, 5),
+    (40, 70, 24),    # the full depth
+])
+def test_fp8_tower_matches_its_oracle(h, w, blocks):
+    cfg = small_config(frame_height=h, frame_width=w, gen_blocks=blocks)
+    _fp8_case(cfg, M.make_seeded_weights(cfg), M.synthetic_frames(3, h, w, seed=5, kind="smooth"))
+
+
+def test_fp8_tower_multi_round_tiles():
+    """More 8x32 tiles than resident workgroups (2 per CU): full rounds in XCD order plus
+    the spread-out remainder round, at about the benchmark's pixel count."""
+    h, w = 328, 416   # 41 x 13 = 533 tiles > 512
+    cfg = small_config(frame_height=h, frame_width=w, gen_blocks=1)
+    _fp8_case(cfg, M.make_seeded_weights(cfg), M.synthetic_frames(1, h, w, seed=11, kind="smooth"))
+
+
+def test_fp8_calibration_tensor_and_saturation():
+    """generator/fp8_amax picks the per-tensor exponents; a range far too small makes both
+    the engine and the oracle saturate at 448 / 2^e in the same places."""
+    h, w = 30, 48
+    cfg = small_config(gen_blocks=2)
+    frames = M.synthetic_frames(2, h, w, seed=5, kind="smooth")
+    for amax in (1.5, 0.2):          # 0.2: exponent 10, everything above 0.4375 clips
+        wts = M.make_seeded_weights(cfg)
+        wts["generator/fp8_amax"] = np.full(2 * cfg.gen_blocks, amax, np.float32)
+        _fp8_case(cfg, wts, frames)
+    # and the clipping really happened: the saturated model differs visibly from the calibrated one
+    outs = []
+    for amax in (1.5, 0.2):
+        wts = M.make_seeded_weights(cfg)
+        wts["generator/fp8_amax"] = np.full(2 * cfg.gen_blocks, amax, np.float32)
+        rt = R.Runtime(M.serialize(cfg, wts), 0, R.DTYPE_FP8)
+        outs.append([rt.process_image(f).copy() for f in frames][-1])
+        rt.close()
+    assert _psnr(outs[0], outs[1]) < 55.0
+
+
+def test_fp8_model_header_selects_the_8bit_tower_and_is_deterministic():
+    cfg = small_config(compute_dtype=M.DTYPE_FP8)
+    wts = M.make_seeded_weights(cfg)
+    blob = M.serialize(cfg, wts)
+    frames = M.synthetic_frames(3, cfg.frame_height, cfg.frame_width, seed=5, kind="noise")
+    runs = []
+    for _ in range(2):
+        rt = R.Runtime(blob)                      # dtype from the header
+        assert rt.dtype == R.DTYPE_FP8
+        runs.append([rt.process_image(f).copy() for f in frames])
+        rt.close()
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    # an explicit 16-bit request overrides the header
+    rt = R.Runtime(blob, 0, R.DTYPE_F16)
+    assert rt.dtype == R.DTYPE_F16
+    rt.close()
