@@ -602,3 +602,33 @@ def test_fp8_model_header_selects_the_8bit_tower_and_is_deterministic():
     rt = R.Runtime(blob, 0, R.DTYPE_F16)
     assert rt.dtype == R.DTYPE_F16
     rt.close()
+
+
+def test_fp8_tower_bytes_do_not_depend_on_the_grid(monkeypatch):
+    """The arithmetic of a tile does not depend on which workgroup computes it, so every
+    launch geometry must give the same bytes.  At the PS2 size (1120 tiles: two full
+    rounds + a remainder at two workgroups per CU) this caught a race that showed as rare
+    stale tiles only with exactly that default grid; 256 workgroups (one per CU) is the
+    reference."""
+    cfg = M.PRESETS["ps2-quality"]
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames = M.synthetic_frames(6, cfg.frame_height, cfg.frame_width, seed=1234, kind="noise")
+    monkeypatch.setenv("JU_NO_GRAPH", "1")   # the grid override acts on new launches only
+
+    def run(grid):
+        if grid:
+            monkeypatch.setenv("JU_FP8_GRID", str(grid))
+        else:
+            monkeypatch.delenv("JU_FP8_GRID", raising=False)
+        rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+        outs = [rt.process_image(f).copy() for f in frames]
+        trunk = rt.read_tensor("trunk").copy()
+        rt.close()
+        return outs, trunk
+
+    ref, ref_trunk = run(256)
+    for grid in (None, None, 1024, 96):
+        outs, trunk = run(grid)
+        assert np.array_equal(trunk, ref_trunk), grid
+        for a, b in zip(outs, ref):
+            assert np.array_equal(a, b), grid
