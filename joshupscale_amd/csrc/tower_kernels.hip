@@ -242,7 +242,11 @@ __global__ __launch_bounds__(kTowerThreads, 1) void conv_tower_kernel(TowerParam
 		// transposes its 2 rows x 32 px x 64 ch through LDS (its own 8 KiB slice of
 		// the input buffer it has just finished with) and stores whole records,
 		// 16 B per lane, 1 KiB contiguous per instruction.
-		__syncthreads();  // every wave is done reading this tile's input (halo rows are shared)
+		// every wave is done reading this tile's input (halo rows are shared), and the next
+		// tile's DMA has landed.  Explicit wait: hipcc does not reliably count an LDS-DMA as
+		// something the barrier's fence must wait for (fp8_kernels.hip got vmcnt(23)).
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
 		{
 			unsigned char *slice = smT + buf * kTowerTileBytes + wave * 8192;
 #pragma unroll

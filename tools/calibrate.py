@@ -8,7 +8,13 @@ Tower: the resident kernel's calibration variant records the largest post-ReLU o
 of each of its layers per frame (ju_debug_set("tower_variant", 5)); flow net and
 generator input: max |x| of the materialised tensors (ju_read_tensor).  Needs a GPU.
 
-usage: tools/calibrate.py [--preset psp-quality] [--frames 16] [--kind smooth] > ranges.json
+With --write-fp8 OUT.jupw the ranges of the 48 block-convolution inputs are stored in the
+container as "generator/fp8_amax" (what the 8-bit tower reads, csrc/fp8.h) and its
+compute_dtype hint is set to fp8; --model calibrates an existing container instead of a
+seeded preset.
+
+usage: tools/calibrate.py [--preset psp-quality | --model in.jupw] [--frames 16] [--kind smooth]
+                          [--write-fp8 out.jupw] > ranges.json
 """
 import argparse
 import json
@@ -27,9 +33,15 @@ def main() -> int:
     ap.add_argument("--preset", default="psp-quality")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--kind", default="smooth", choices=["smooth", "noise"])
+    ap.add_argument("--model", help="calibrate this container instead of a seeded preset")
+    ap.add_argument("--write-fp8", metavar="OUT", help="write the container + generator/fp8_amax")
     args = ap.parse_args()
-    cfg = M.PRESETS[args.preset]
-    weights = M.make_seeded_weights(cfg)
+    if args.model:
+        cfg, weights = M.load(args.model)
+        weights.pop("generator/fp8_amax", None)
+    else:
+        cfg = M.PRESETS[args.preset]
+        weights = M.make_seeded_weights(cfg)
     rt = R.Runtime(M.serialize(cfg, weights), 0, R.DTYPE_BF16)
     lib = R.load_library()
     n_layers = 1 + 2 * cfg.gen_blocks
@@ -72,6 +84,13 @@ def main() -> int:
         "other_tensors": {n: scales(a) for n, a in others.items()},
         "weight_amax_unfolded": {n: round(a, 6) for n, a in w_amax.items()},
     }
+    if args.write_fp8:
+        import dataclasses
+        # input of block i's conv_1 = output of tower layer 2i (layer 0 = generator/conv_1),
+        # input of its conv_2 = output of layer 2i + 1
+        weights["generator/fp8_amax"] = np.asarray(tower[:2 * cfg.gen_blocks], np.float32)
+        M.save(args.write_fp8, dataclasses.replace(cfg, compute_dtype=M.DTYPE_FP8), weights)
+        report["written"] = args.write_fp8
     print(json.dumps(report, indent=1))
     return 0
 

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""8-bit tower against the fp16 engine on the same frames (developer tool, needs a GPU):
+where the trunk differs most, by tile / row / column / channel.  Found the stale-tile race
+described in DESIGN.md section 4b.   usage: tools/fp8_diag.py H W blocks [frames]"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
