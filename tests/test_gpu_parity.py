@@ -632,3 +632,13 @@ def test_fp8_tower_bytes_do_not_depend_on_the_grid(monkeypatch):
         assert np.array_equal(trunk, ref_trunk), grid
         for a, b in zip(outs, ref):
             assert np.array_equal(a, b), grid
+
+
+def test_fp8_rejects_a_calibration_tensor_of_the_wrong_length():
+    cfg = small_config(gen_blocks=2)
+    wts = M.make_seeded_weights(cfg)
+    wts["generator/fp8_amax"] = np.ones(3, np.float32)      # needs 2 * gen_blocks = 4
+    with pytest.raises(R.JoshUpscaleError):
+        R.Runtime(M.serialize(cfg, wts), 0, R.DTYPE_FP8)
+    rt = R.Runtime(M.serialize(cfg, wts), 0, R.DTYPE_F16)   # the 16-bit engine ignores it
+    rt.close()
