@@ -31,6 +31,7 @@ from joshupscale_amd import model_file as M  # noqa: E402
 from joshupscale_amd import runtime as R  # noqa: E402
 
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0  # HBM3E, same guide
 PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled e4m3 MFMA (same guide: twice the bf16 rate)
 
 
@@ -130,11 +131,30 @@ def main() -> int:
         # dominant kernel: the 3x3 64->64 convolution of the residual tower,
         # timed with HIP events on the engine's own stream
         fp8 = args.dtype == "fp8"
-        # (fp8: step 0 of the tower stage is the quantise kernel; time one convolution)
-        ms, launches, flops = rt.time_steps("tower#1" if fp8 else "tower", args.roofline_iters)
+        ms, launches, flops = rt.time_steps("tower", args.roofline_iters)
         flops_per_launch = flops / max(launches, 1)
-        peak = PEAK_FP8_TFLOPS if fp8 else PEAK_MFMA_TFLOPS
         achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = PEAK_MFMA_TFLOPS
+        fp8_roofline = None
+        if fp8:
+            # 8-bit tower: step 0 of the stage is the quantise kernel, then per block the first
+            # convolution (e4m3 in, e4m3 out: MFMA-bound by arithmetic) and the second (+ the
+            # fp16 residual stream in and out: memory-bound, and the one most time goes to)
+            ms1, _, fl1 = rt.time_steps("tower#1", args.roofline_iters)
+            ms2, _, _ = rt.time_steps("tower#2", args.roofline_iters)
+            px = h * w
+            bytes2 = px * (64 + 128 + 128 + 64) + 9 * 64 * 64   # t8 in, stream in/out, x8 out, weights
+            fp8_roofline = {
+                "kernel": "conv_tower_fp8_kernel<stream>: second 3x3 64->64 conv of a residual block, e4m3 operands, "
+                          "fp16 skip connection in and out",
+                "bound": "hbm", "achieved": bytes2 / (ms2 * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": bytes2 / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                "launch_ms": ms2, "launches_per_frame": cfg.gen_blocks, "bytes_per_launch": bytes2,
+                "first_conv": {"kernel": "conv_tower_fp8_kernel: first conv of a block (e4m3 in, e4m3 out)",
+                               "bound": "mfma", "launch_ms": ms1, "achieved": fl1 / (ms1 * 1e-3) / 1e12,
+                               "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fl1 / (ms1 * 1e-3) / 1e12 / PEAK_FP8_TFLOPS},
+            }
         total_flops = rt.time_steps("", 0)[2]
         # HBM traffic of the dominant kernel from the committed PMC summary (bench.py cannot
         # run rocprofv3 around itself); only used when it describes the kernel measured here
@@ -163,8 +183,7 @@ def main() -> int:
                 "whole_frame_tflops": total_flops * fps / world / 1e12,
             },
             "roofline": {
-                "kernel": "conv_tower_fp8_kernel 3x3 64->64 on e4m3 operands (one residual-block conv)" if fp8
-                          else "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch"
+                "kernel": "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch"
                           if launches == 1 else "conv_tower_kernel 3x3 64->64 (one residual-block conv)",
                 "bound": "mfma", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -173,6 +192,8 @@ def main() -> int:
                 "flops_per_launch": flops_per_launch,
             },
         }
+        if fp8_roofline:
+            result["roofline"] = fp8_roofline
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(blob, cfg, clip, args.cpu_seconds)
         print(json.dumps(result), flush=True)

@@ -8,7 +8,8 @@ import json, sys
 d = json.loads(sys.stdin.read())
 r = d["roofline"]
 print(json.dumps({"fps": round(d["value"], 1), "ms": round(d["ms_per_step"], 4), "dtype": d["dtype"],
-  "kernel": r["kernel"][:32], "launch_ms": round(r["launch_ms"], 4), "tflops": round(r["achieved"], 1), "frac": round(r["frac"], 4)}))'
+  "kernel": r["kernel"][:32], "launch_ms": round(r["launch_ms"], 4), "achieved": round(r["achieved"], 1), "unit": r["unit"],
+  "frac": round(r["frac"], 4), "first_conv": r.get("first_conv", {}).get("launch_ms")}))'
 }
 run "--preset ps2-quality --dtype fp8" X=1
 run "--preset ps2-quality --dtype fp16" X=1
