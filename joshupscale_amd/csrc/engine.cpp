@@ -448,7 +448,9 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	if (dt == 2) {
 		// JU_DTYPE_FP8: the 64->64 block convolutions run on e4m3 operands (fp8.h); the
 		// residual stream and every other layer stay fp16
-		if (c.genFilters != 64) throw std::invalid_argument("fp8 tower needs a 64-filter generator");
+		if (c.genFilters != 64 || c.genBlocks < 1) {
+			throw std::invalid_argument("fp8 tower needs a 64-filter generator with at least one residual block");
+		}
 		m_Fp8Tower = true;
 		dt = kF16;
 	}
