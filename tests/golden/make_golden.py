@@ -29,9 +29,9 @@ def blob_sha(cfg, wts) -> str:
     return hashlib.sha256(M.serialize(cfg, wts)).hexdigest()
 
 
-def small(name: str, cfg, n_frames: int, kind: str, seed: int) -> None:
+def small(name: str, cfg, n_frames: int, kind: str, seed: int, fp8_tower: bool = False) -> None:
     wts = M.make_seeded_weights(cfg, seed=42)
-    sess = O.Session(wts, oracle_config(cfg))
+    sess = O.Session(wts, oracle_config(cfg, fp8_tower=fp8_tower))
     frames = M.synthetic_frames(n_frames, cfg.frame_height, cfg.frame_width, seed=seed, kind=kind)
     outs, raws, flows = [], [], []
     for t in range(n_frames):
@@ -75,5 +75,7 @@ if __name__ == "__main__":
     small("small_resnet", small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2,
                                        frame_height=34, frame_width=50), 4, "smooth", 12)
     small("small_noise", small_config(gen_blocks=2), 3, "noise", 13)
+    # the 8-bit tower's restatement (BASELINE.json config 5; scheme of csrc/fp8.h)
+    small("small_fp8", small_config(gen_blocks=4), 3, "smooth", 14, fp8_tower=True)
     if a.full:
         full()

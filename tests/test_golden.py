@@ -21,6 +21,21 @@ def load(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
 
 
+def test_numpy_oracle_reproduces_the_fp8_golden():
+    """Pins the 8-bit restatement (e4m3 rounding, scale rules, where it quantises): any
+    change to it shows here before it silently moves the GPU parity target."""
+    g = load("small_fp8")
+    cfg = small_config(gen_blocks=4)
+    wts = M.make_seeded_weights(cfg, seed=42)
+    assert hashlib.sha256(M.serialize(cfg, wts)).hexdigest() == str(g["model_sha256"])
+    sess = O.Session(wts, oracle_config(cfg, fp8_tower=True))
+    for t, frame in enumerate(g["frames"]):
+        assert np.array_equal(sess.run(frame), g["outputs"][t]), t
+    assert np.abs(sess.last.output_raw - g["output_raw_last"]).max() < 1e-6
+    plain = O.Session(wts, oracle_config(cfg))
+    assert not np.array_equal(plain.run(g["frames"][0]), g["outputs"][0])   # it IS a different model
+
+
 @pytest.mark.parametrize("name", sorted(SMALL))
 def test_numpy_oracle_reproduces_small_goldens(name):
     g = load(name)

@@ -642,3 +642,19 @@ def test_fp8_rejects_a_calibration_tensor_of_the_wrong_length():
         R.Runtime(M.serialize(cfg, wts), 0, R.DTYPE_FP8)
     rt = R.Runtime(M.serialize(cfg, wts), 0, R.DTYPE_F16)   # the 16-bit engine ignores it
     rt.close()
+
+
+def test_fp8_committed_golden_vectors():
+    """The 8-bit engine against the committed outputs of the 8-bit oracle."""
+    g = np.load(os.path.join(GOLD, "small_fp8.npz"))
+    cfg = small_config(gen_blocks=4)
+    wts = M.make_seeded_weights(cfg)
+    blob = M.serialize(cfg, wts)
+    assert hashlib.sha256(blob).hexdigest() == str(g["model_sha256"])
+    rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+    for t, frame in enumerate(g["frames"]):
+        out = rt.process_image(frame)
+        assert (out[..., 3] == 0).all()
+        st = u8_stats(out, g["outputs"][t])
+        assert st["psnr"] >= 55.0 and st["max"] <= 6, (t, st)
+    rt.close()
