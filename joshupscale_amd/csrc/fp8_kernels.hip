@@ -362,9 +362,16 @@ void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
 	k.pitch = towerPitch(q.W);
 	k.tilesX = (q.W + 31) / 32;
 	k.numTiles = k.tilesX * ((q.H + 7) / 8);
+	// CU count of the current device, looked up once per device (49 launches per frame)
+	static std::atomic<int> cuCache[64];
 	int dev = 0, cus = 256;
-	if (hipGetDevice(&dev) == hipSuccess) {
-		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+		cus = cuCache[dev].load(std::memory_order_relaxed);
+		if (cus == 0) {
+			cus = 256;
+			(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			cuCache[dev].store(cus, std::memory_order_relaxed);
+		}
 	}
 	int grid = k.numTiles < 2 * cus ? k.numTiles : 2 * cus;  // two workgroups per CU
 	// the kernel's XCD tile order needs a multiple of 8: round up when everything fits one
