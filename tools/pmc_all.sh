@@ -4,22 +4,26 @@
 # and chip-level MFMA busy share: SQ_VALU_MFMA_BUSY_CYCLES (summed over SIMDs) /
 # (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs).
 # --pmc runs use --kernel-trace only.  Output: gpurun_out/pmc_per_kernel.json
+# usage: bash tools/pmc_all.sh [extra bench.py arguments, e.g. --preset ps2-quality --dtype fp8]
 R=$GRAFT_REPO_ROOT
+EXTRA="$*"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pa$i
-  timeout 250 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pa$i -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --roofline-iters 1 > $R/gpurun_out/pa$i.log 2>&1
+  timeout 250 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pa$i -- python3 $R/bench.py $EXTRA --steps 8 --warmup 2 --no-cpu-baseline --roofline-iters 1 > $R/gpurun_out/pa$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, os, collections, json, re
 R=os.environ['GRAFT_REPO_ROOT']
 def short(k):
     k=k.split('(')[0]
-    m=re.search(r'(\d+)(tower_resident_kernel|conv_mfma_kernel|tail_fused_kernel|warp_pack_kernel|pack_frames_kernel|upsample2_kernel|maxpool2_kernel)(.*)', k)
+    m=re.search(r'(\d+)(tower_resident_kernel|conv_tower_fp8_kernel|conv_tower_kernel|quantize_tower_kernel|conv_mfma_kernel|tail_fused_kernel|warp_pack_kernel|pack_frames_kernel|upsample2_kernel|maxpool2_kernel)(.*)', k)
     if not m: return None
     name=m.group(2)
+    if name=='conv_tower_fp8_kernel':
+        name+='<stream>' if 'Lb1E' in m.group(3) else '<first>'
     if name=='conv_mfma_kernel':
         p=re.search(r'Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)', m.group(3))
         if p: name+=f'<taps{p.group(1)},ck{p.group(2)},nb{p.group(3)},rw{p.group(4)},dbuf{p.group(5)}>'
