@@ -33,6 +33,7 @@ from joshupscale_amd import runtime as R  # noqa: E402
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0  # HBM3E, same guide
 PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled e4m3 MFMA (same guide: twice the bf16 rate)
+TRAFFIC_PROFILE = "r01_tower_traffic.json"  # PMC summary of the dominant kernel (tools/pmc_traffic.sh)
 
 
 def cpu_baseline(blob: bytes, cfg, frames: np.ndarray, budget_s: float) -> dict:
@@ -70,8 +71,12 @@ def main() -> int:
     args = ap.parse_args()
 
     rank, local_rank, world = jdist.env_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(
+            f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run "
+            f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py "
+            f"--gpus {args.gpus} ...` (one rank per GPU); a bare `python bench.py --gpus {args.gpus}` "
+            "would silently measure one GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -159,10 +164,13 @@ def main() -> int:
         # HBM traffic of the dominant kernel from the committed PMC summary (bench.py cannot
         # run rocprofv3 around itself); only used when it describes the kernel measured here
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_tower_traffic.json")
+        traffic_source = None
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
         if launches == 1 and not fp8 and args.preset == "psp-quality" and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("bytes_per_launch")
+            traffic_source = (f"committed profile profiles/{TRAFFIC_PROFILE} (rocprofv3 --pmc passes of this "
+                              "kernel, collected separately; NOT measured by this run)")
         result = {
             "metric": "frames/sec 480x270->1920x1080 recurrent SR" if args.preset.startswith("psp")
                       else f"frames/sec {w}x{h}->{4 * w}x{4 * h} recurrent SR",
@@ -177,6 +185,11 @@ def main() -> int:
                 "weights": "seeded random-init (seed 42), reference default architecture",
                 "streams": world, "parallelism": f"replicas x{world}",
                 "boundary": "ju_process (synchronous processImage)",
+                "submission": {"graph_replays": rt.stat("graph_replays"), "eager_runs": rt.stat("eager_runs"),
+                               "cached_graphs": rt.stat("direct_graphs"),
+                               "how": "one hipGraph per (input, output, binding set) tuple of device frames, "
+                                      "captured at the tuple's second use, replayed afterwards"},
+                "tower": "resident (one launch)" if rt.stat("resident_tower") else "per-layer launches",
                 "latency_ms": {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
                                "max": lat[-1], "frames": len(lat)},
                 "gflop_per_frame": total_flops / 1e9,
@@ -187,13 +200,18 @@ def main() -> int:
                           if launches == 1 else "conv_tower_kernel 3x3 64->64 (one residual-block conv)",
                 "bound": "mfma", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_tower_traffic.json)",
+                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                "traffic_source": traffic_source,
                 "launch_ms": ms, "launches_per_frame": launches,
                 "flops_per_launch": flops_per_launch,
             },
         }
         if fp8_roofline:
             result["roofline"] = fp8_roofline
+            result["config"]["fp8_scheme"] = (
+                "self-defined (csrc/fp8.h): e4m3 operands with power-of-two per-channel weight / per-tensor "
+                "activation scales, fp16 residual stream; the gfx950 counterpart of the reference's TensorRT INT8 "
+                "engines, not a restatement of them -- parity is against the oracle's restatement of THIS scheme")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(blob, cfg, clip, args.cpu_seconds)
         print(json.dumps(result), flush=True)

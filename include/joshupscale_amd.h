@@ -147,9 +147,16 @@ JU_API int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, siz
  * residual blocks, "flow", "warp", "gen_head", "tail", "pack", "" = all),
  * measured with HIP events on the runtime's own stream over `iters`
  * repetitions.  *launches = kernel launches per repetition, *flops = their
- * algorithmic FLOPs (2*MAC) per repetition. */
+ * algorithmic FLOPs (2*MAC) per repetition.  Timing runs the launches outside the frame
+ * sequence: the recurrent state is reset (as by ju_reset) before the call returns. */
 JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_per_launch,
     int *launches, double *flops);
+
+/* How the runtime has been executing: "graph_replays" / "eager_runs" (per-frame programs
+ * submitted as one hipGraph replay / as individual launches so far), "direct_graphs"
+ * (graphs cached for JU_LOC_DEVICE frame tuples), "resident_tower" / "resident_flow"
+ * (1 when the one-launch tower kernel is in use), "launches_per_frame". */
+JU_API int ju_get_stat(const ju_runtime *runtime, const char *key, double *value);
 
 /* Developer switches (timing ablations and fault injection; never needed by a
  * caller).  Keys: "tower_variant" 0..5 (0 = product kernel, 4 = phase profile, 5 =

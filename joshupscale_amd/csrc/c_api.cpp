@@ -195,6 +195,13 @@ int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_pe
 	});
 }
 
+int ju_get_stat(const ju_runtime *runtime, const char *key, double *value) {
+	return guarded([&] {
+		if (key == nullptr || value == nullptr) throw std::invalid_argument("ju_get_stat: null argument");
+		*value = engineOf(const_cast<ju_runtime *>(runtime)).stat(key);
+	});
+}
+
 int ju_debug_set(const char *key, int value) {
 	return guarded([&] {
 		const std::string k = key ? key : "";

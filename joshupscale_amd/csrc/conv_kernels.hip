@@ -430,7 +430,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 
 	// ---- epilogue with the 2x2 max-pool folded in (flow encoder, models.py:377-410):
 	// a wave owns rows 2j, 2j+1 (vertical max inside the lane), the horizontal
-	// partner pixel sits in the neighbouring lane.  ReLU commutes with max.  Both
+	// partner pixel sits in the neighbouring lane.  ReLU and LeakyReLU (slope >= 0:
+	// monotonic, checked by the loader) commute with max.  Both
 	// lanes of a pair end up with the pooled pixel; each stores half its channels.
 	if constexpr (RW == 2) {
 		if (p.pool) {
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 					for (int i = 0; i < 4; ++i) {
 						float m = fmaxf(acc[nb][0][4 * g + i], acc[nb][1][4 * g + i]);
 						m = fmaxf(m, __shfl_xor(m, 1));
-						v[i] = p.relu ? fmaxf(m, 0.0f) : m;
+						v[i] = p.relu == 1 ? fmaxf(m, 0.0f) : (p.relu == 2 ? leaky(m, p.slope) : m);
 					}
 					if (live && (g >> 1) == (px & 1)) {
 						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
@@ -485,9 +486,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
 					for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(r[i]);
 				}
-				if (p.relu) {
+				if (p.relu == 1) {
 #pragma unroll
 					for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+				} else if (p.relu == 2) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[i] = leaky(v[i], p.slope);
 				}
 				if (p.outF32) {
 					f32x4 o = {v[0], v[1], v[2], v[3]};

@@ -131,7 +131,12 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 	p.cin = cw.cinP;
 	p.cout = cw.cout;
 	p.taps = cw.taps;
-	p.relu = relu ? 1 : 0;
+	{  // the layer's activation (models.py:24-27): the flow net and the generator each have their own
+		const bool flowLayer = wname.rfind("flow/", 0) == 0;
+		const int act = flowLayer ? m_Config.flowActivation : m_Config.genActivation;
+		p.relu = relu ? (act == 1 ? 2 : 1) : 0;
+		p.slope = flowLayer ? m_Config.flowNegativeSlope : m_Config.genNegativeSlope;
+	}
 	p.outF32 = outF32 ? 1 : 0;
 	p.nb = cw.nb;
 	p.rw = cw.rw;
@@ -402,6 +407,7 @@ void Engine::buildProgram(int set) {
 		tf.sums = sums;
 		tf.H = H;
 		tf.W = W;
+		tf.slope = c.genActivation == 1 ? c.genNegativeSlope : -1.0f;
 		prog.push_back({"tail", 2.0 * H * W * (64.0 * 128 + 4 * 4 * 32 * 3), [=](hipStream_t s) {
 			                TailFusedLaunch t = tf;
 			                t.frame = io->in;
@@ -451,6 +457,10 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		if (c.genFilters != 64 || c.genBlocks < 1) {
 			throw std::invalid_argument("fp8 tower needs a 64-filter generator with at least one residual block");
 		}
+		if (c.genActivation != 0) {
+			throw std::invalid_argument("fp8 tower: the 8-bit scheme is defined for ReLU generators only "
+			                            "(its conv inputs are non-negative tensors); run this model in fp16 or bf16");
+		}
 		m_Fp8Tower = true;
 		dt = kF16;
 	}
@@ -480,7 +490,15 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		int cus = 0;
 		JU_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
 		// (the 8-bit tower has a per-layer kernel only)
-		const bool wanted = !(mode && std::string(mode) == "layers") && !m_Fp8Tower;
+		bool wanted = !(mode && std::string(mode) == "layers") && !m_Fp8Tower;
+		if (wanted && c.genActivation != 0) {
+			// the resident kernel's halo slots carry their epoch tag in the sign bits of
+			// post-ReLU values; a LeakyReLU model has no free bits there
+			logMessage(LogLevel::Info, "Engine",
+			    "generator activation is lrelu: the residual tower runs on the per-layer kernels "
+			    "(the resident tower kernel needs ReLU outputs)");
+			wanted = false;
+		}
 		if (wanted && c.genFilters == 64 && c.genBlocks >= 1 &&
 		    residentTowerGeometry(c.frameHeight, c.frameWidth, cus, &m_ResGX, &m_ResGY, &m_ResRH)) {
 			m_Resident = true;
@@ -491,14 +509,14 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 			m_ResMail = DeviceBuffer(residentMailboxBytes(m_ResGX, m_ResGY));
 			// word 0: launch generation; from byte 64: one flag word per region
 			m_ResFlags = DeviceBuffer(64 + (static_cast<std::size_t>(m_ResGX) * m_ResGY * 4 + 15) / 16 * 16);
-			JU_HIP(hipHostMalloc(reinterpret_cast<void **>(&m_ResErrorHost), 64, hipHostMallocMapped));
-			*m_ResErrorHost = 0;
-			JU_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&m_ResErrorDev), m_ResErrorHost, 0));
+			m_ResError = PinnedWords(64);
+			m_ResErrorDev = m_ResError.device();
 		}
 		m_TowerHostW.clear();
 		m_TowerHostW.shrink_to_fit();
 		const char *flowMode = std::getenv("JU_FLOW");
 		if (m_Resident && !(flowMode && std::string(flowMode) == "layers") && c.flowArch == 1 &&
+		    c.flowActivation == 0 &&
 		    c.flowResFilters == 64 && c.flowResBlocks >= 1 && 3 * c.numFlowInputs <= 64 &&
 		    residentTowerGeometry(PH, PW, cus, &m_FlowGX, &m_FlowGY, &m_FlowRH)) {
 			m_ResidentFlow = true;
@@ -595,6 +613,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_PreferDirect = !(direct && direct[0] == '0');
 	const char *noGraph = std::getenv("JU_NO_GRAPH");
 	m_UseGraph = !(noGraph && noGraph[0] == '1');
+	const char *directGraph = std::getenv("JU_DIRECT_GRAPH");
+	m_DirectGraph = !(directGraph && directGraph[0] == '0');
 	if (const char *spin = std::getenv("JU_SYNC_SPIN_US")) m_SpinUs = static_cast<unsigned>(std::atoi(spin));
 	if (m_UseGraph) {
 		for (int s = 0; s < 2; ++s) {
@@ -616,15 +636,15 @@ Engine::~Engine() {
 	try {
 		DeviceGuard g(m_Device);
 		(void)hipStreamSynchronize(m_Stream);
-		if (m_ResErrorHost) (void)hipHostFree(m_ResErrorHost);
 	} catch (...) {
 	}
 }
 
 unsigned Engine::takeResidentError() {
-	if (m_ResErrorHost == nullptr || *m_ResErrorHost == 0) return 0;
-	const unsigned code = *m_ResErrorHost;
-	*m_ResErrorHost = 0;
+	volatile unsigned *word = m_ResError.host();
+	if (word == nullptr || *word == 0) return 0;
+	const unsigned code = *word;
+	*word = 0;
 	return code;
 }
 
@@ -640,20 +660,34 @@ void Engine::fallbackToLayers(unsigned code) {
 	logMessage(LogLevel::Warning, "Engine", ss.str());
 	m_Resident = false;
 	m_ResidentFlow = false;
+	m_DirectGraphs.clear();  // they replay the resident program
 	for (int s = 0; s < 2; ++s) {
 		m_Graph[s] = GraphExec();
 		buildProgram(s);
 	}
 	if (m_UseGraph) {
-		// one eager pass sets the per-layer kernels' attributes before capture; it
-		// writes only scratch tensors and the binding sets' OUTPUT halves, which the
-		// caller's re-run (or the next frame) overwrites
+		// One eager pass per binding set FIRST: the per-layer tower kernels have never
+		// been launched on this device, and their first launch sets the dynamic-LDS
+		// attribute (hipFuncSetAttribute) -- not something to do inside a stream capture;
+		// launch errors also surface here.  On the staging buffers: the pass writes only
+		// scratch tensors and the binding sets' OUTPUT halves, which the caller's re-run
+		// (or the next frame) overwrites.
+		const FrameIO keep = m_IO;
+		m_IO.in = m_InStage.as<std::uint8_t>();
+		m_IO.inStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 4;
+		m_IO.out = m_OutStage.as<std::uint8_t>();
+		m_IO.outStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 16;
+		for (int s = 0; s < 2; ++s) {
+			for (const Step &st : m_Program[s]) st.run(m_Stream);
+		}
+		m_Stream.synchronize();
 		for (int s = 0; s < 2; ++s) {
 			m_Graph[s] = GraphExec::capture(m_Stream, [&] {
 				for (const Step &st : m_Program[s]) st.run(m_Stream);
 			});
 		}
 		m_Stream.synchronize();
+		m_IO = keep;
 	}
 }
 
@@ -772,9 +806,38 @@ void Engine::stageOut(const Frame &out) {
 void Engine::runProgram() {
 	if (m_UseGraph && !m_DirectIO && m_Graph[m_Idx].valid()) {
 		m_Graph[m_Idx].launch(m_Stream);
-	} else {
-		for (const Step &st : m_Program[m_Idx]) st.run(m_Stream);
+		++m_GraphReplays;
+		return;
 	}
+	if (m_UseGraph && m_DirectIO && m_DirectGraph) {
+		const DirectKey key{m_IO.in, m_IO.inStride, m_IO.out, m_IO.outStride, m_Idx};
+		auto it = m_DirectGraphs.find(key);
+		if (it == m_DirectGraphs.end()) {
+			if (m_DirectGraphs.size() >= kMaxDirectGraphs) {  // evict the least recently used tuple
+				auto victim = m_DirectGraphs.begin();
+				for (auto j = m_DirectGraphs.begin(); j != m_DirectGraphs.end(); ++j) {
+					if (j->second.lastUse < victim->second.lastUse) victim = j;
+				}
+				m_DirectGraphs.erase(victim);
+			}
+			it = m_DirectGraphs.emplace(key, DirectEntry{}).first;
+		}
+		DirectEntry &e = it->second;
+		e.lastUse = ++m_DirectClock;
+		if (!e.graph.valid() && ++e.seen >= 2) {
+			// second sighting of this tuple: record the launches (nothing executes here) ...
+			e.graph = GraphExec::capture(m_Stream, [&] {
+				for (const Step &st : m_Program[m_Idx]) st.run(m_Stream);
+			});
+		}
+		if (e.graph.valid()) {  // ... and replay
+			e.graph.launch(m_Stream);
+			++m_GraphReplays;
+			return;
+		}
+	}
+	for (const Step &st : m_Program[m_Idx]) st.run(m_Stream);
+	++m_EagerRuns;
 }
 
 void Engine::submit(const Frame &in, const Frame &out) {
@@ -821,8 +884,10 @@ void Engine::process(const Frame &in, const Frame &out) {
 	if (const unsigned code = takeResidentError()) {
 		// the frame's inputs (previous state, frame history) are intact: the step only
 		// wrote the other half of the ping-pong -- run it again on the per-layer path
-		fallbackToLayers(code);
+		// (submit() flipped m_Idx; the re-run needs the same binding set again.  If the
+		// fallback or the re-run throws, the failed frame must not count as a step either.)
 		m_Idx ^= 1;
+		fallbackToLayers(code);
 		submit(in, out);
 		m_Stream.synchronize();
 	}
@@ -950,7 +1015,34 @@ double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
 	}
 	t1.record(m_Stream);
 	t1.synchronize();
-	return static_cast<double>(Event::elapsedMs(t0, t1)) / (static_cast<double>(iters) * steps.size());
+	const double ms = static_cast<double>(Event::elapsedMs(t0, t1)) / (static_cast<double>(iters) * steps.size());
+	// The timed launches ran outside the frame sequence: scratch tensors, the output
+	// staging buffer and (with JU_TAIL=tower) the recurrent state were overwritten.  Start
+	// the stream from a clean state again, and do not leave a bounded-wait failure of the
+	// resident tower behind for the next process() to trip over.
+	const unsigned code = takeResidentError();
+	reset();
+	if (code) {
+		std::ostringstream ss;
+		ss << "timeSteps: the resident tower kernel reported a bounded-wait timeout (code 0x" << std::hex
+		   << code << "); the timing is invalid";
+		throw std::runtime_error(ss.str());
+	}
+	return ms;
+}
+
+double Engine::stat(const std::string &key) const {
+	if (key == "graph_replays") return static_cast<double>(m_GraphReplays);
+	if (key == "eager_runs") return static_cast<double>(m_EagerRuns);
+	if (key == "resident_tower") return m_Resident ? 1.0 : 0.0;
+	if (key == "resident_flow") return m_ResidentFlow ? 1.0 : 0.0;
+	if (key == "launches_per_frame") return static_cast<double>(m_Program[0].size());
+	if (key == "direct_graphs") {
+		double n = 0;
+		for (const auto &kv : m_DirectGraphs) n += kv.second.graph.valid() ? 1 : 0;
+		return n;
+	}
+	throw std::invalid_argument("unknown stat " + key);
 }
 
 }  // namespace ju

@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "hip_util.h"
@@ -73,10 +74,15 @@ public:
 	std::vector<std::string> tensorNames() const;
 	// Average device time (ms) of one launch of the steps carrying `tag`, measured
 	// with HIP events on the engine's own stream over `iters` repetitions of that
-	// group; *launches receives the number of kernel launches per repetition.
+	// group; *launches receives the number of kernel launches per repetition.  The timed
+	// launches overwrite scratch tensors and possibly the recurrent state: the stream is
+	// reset() afterwards (callers time AFTER their frames, as bench.py does).
 	double timeSteps(const std::string &tag, int iters, int *launches);
 	// FLOPs (2*MAC) of the steps carrying `tag` (one repetition).
 	double flopsOf(const std::string &tag) const;
+	// "graph_replays", "eager_runs", "direct_graphs", "resident_tower", "resident_flow",
+	// "launches_per_frame"
+	double stat(const std::string &key) const;
 
 private:
 	struct Tensor {
@@ -176,12 +182,45 @@ private:
 	std::vector<std::uint16_t> m_FlowTowerHostW;
 	std::vector<float> m_FlowTowerHostB;
 	DeviceBuffer m_FlowTowerW, m_FlowTowerB, m_FlowMail, m_FlowFlags;
-	unsigned *m_ResErrorHost = nullptr;  // pinned, device-visible
+	PinnedWords m_ResError;              // pinned, device-visible: word 0 = the tower's error report
 	unsigned *m_ResErrorDev = nullptr;
 	unsigned takeResidentError();        // 0 = none; clears it
 	void fallbackToLayers(unsigned code);
 	std::vector<Step> m_Program[2];
 	GraphExec m_Graph[2];
+	// Device-resident frames (JU_LOC_DEVICE, no staging): the kernels take the caller's
+	// pointers, so a captured graph is valid for ONE (input, output, strides, binding set)
+	// tuple.  Callers reuse a handful of frame buffers (OBS: one texture pair; bench.py:
+	// 16 inputs, 1 output), so the graphs are cached by that tuple: the second call with
+	// a tuple captures it, every later one replays it (the reference replays a captured
+	// graph for every location, tensorrt_backend.cc:222-264, 274).  Tuples seen once run
+	// eagerly, so a caller that hands over a fresh pointer every frame never pays a capture.
+	struct DirectKey {
+		const void *in;
+		std::ptrdiff_t inStride;
+		void *out;
+		std::ptrdiff_t outStride;
+		int idx;
+		bool operator<(const DirectKey &o) const {
+			return std::tie(in, inStride, out, outStride, idx) <
+			       std::tie(o.in, o.inStride, o.out, o.outStride, o.idx);
+		}
+	};
+	struct DirectEntry {
+		GraphExec graph;
+		unsigned seen = 0;
+		std::uint64_t lastUse = 0;
+	};
+	std::map<DirectKey, DirectEntry> m_DirectGraphs;
+	std::uint64_t m_DirectClock = 0;
+	bool m_DirectGraph = true;  // JU_DIRECT_GRAPH=0: device frames always launch eagerly
+	static constexpr std::size_t kMaxDirectGraphs = 64;
+	std::uint64_t m_GraphReplays = 0, m_EagerRuns = 0;  // introspection ("graph_replays" / "eager_runs")
+
+public:
+	// counters of how the per-frame program ran so far (tests, bench)
+	std::uint64_t graphReplays() const { return m_GraphReplays; }
+	std::uint64_t eagerRuns() const { return m_EagerRuns; }
 };
 
 }  // namespace ju

@@ -433,6 +433,7 @@ struct TailFusedParams {
 	std::ptrdiff_t outStride;
 	const unsigned *sums;
 	int H, W;
+	float slope;          // < 0: ReLU after convT1, else LeakyReLU(slope)
 };
 
 template <typename T>
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(TailFusedParams p) {
 	a2[0] = reinterpret_cast<const Vec8<T> *>(p.w2)[lane];
 	a2[1] = reinterpret_cast<const Vec8<T> *>(p.w2)[64 + lane];
 	const float b2v[3] = {p.b2[0], p.b2[1], p.b2[2]};
-	const TailRowArgs args{p.b1, p.frame, p.frameStride, p.state, p.outU8, p.outStride, p.H, p.W};
+	const TailRowArgs args{p.b1, p.frame, p.frameStride, p.state, p.outU8, p.outStride, p.H, p.W, p.slope};
 	__syncthreads();
 
 #pragma unroll
@@ -651,6 +652,7 @@ void launchTailFused(DType dt, const TailFusedLaunch &q, hipStream_t stream) {
 	p.sums = q.sums;
 	p.H = q.H;
 	p.W = q.W;
+	p.slope = q.slope;
 	if (dt == kF16) launchTailFusedT<f16>(p, stream);
 	else launchTailFusedT<bf16>(p, stream);
 }

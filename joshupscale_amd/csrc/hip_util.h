@@ -112,6 +112,50 @@ private:
 	std::size_t m_Bytes = 0;
 };
 
+// Pinned, device-visible host words (the resident tower's error report): released during
+// constructor unwinding like every other member.
+class PinnedWords {
+public:
+	PinnedWords() = default;
+	explicit PinnedWords(std::size_t bytes) {
+		JU_HIP(hipHostMalloc(&m_Host, bytes, hipHostMallocMapped));
+		for (std::size_t i = 0; i < bytes / sizeof(unsigned); ++i) static_cast<unsigned *>(m_Host)[i] = 0;
+		void *dev = nullptr;
+		const hipError_t e = hipHostGetDevicePointer(&dev, m_Host, 0);
+		if (e != hipSuccess) {
+			(void)hipHostFree(m_Host);
+			m_Host = nullptr;
+			throw HipError(e, "hipHostGetDevicePointer");
+		}
+		m_Dev = static_cast<unsigned *>(dev);
+	}
+	~PinnedWords() {
+		if (m_Host) (void)hipHostFree(m_Host);
+	}
+	PinnedWords(PinnedWords &&o) noexcept : m_Host(o.m_Host), m_Dev(o.m_Dev) {
+		o.m_Host = nullptr;
+		o.m_Dev = nullptr;
+	}
+	PinnedWords &operator=(PinnedWords &&o) noexcept {
+		if (this != &o) {
+			if (m_Host) (void)hipHostFree(m_Host);
+			m_Host = o.m_Host;
+			m_Dev = o.m_Dev;
+			o.m_Host = nullptr;
+			o.m_Dev = nullptr;
+		}
+		return *this;
+	}
+	PinnedWords(const PinnedWords &) = delete;
+	PinnedWords &operator=(const PinnedWords &) = delete;
+	volatile unsigned *host() const { return static_cast<volatile unsigned *>(m_Host); }
+	unsigned *device() const { return m_Dev; }
+
+private:
+	void *m_Host = nullptr;
+	unsigned *m_Dev = nullptr;
+};
+
 class Stream {
 public:
 	Stream() { JU_HIP(hipStreamCreateWithFlags(&m_Stream, hipStreamNonBlocking)); }

@@ -147,7 +147,14 @@ struct TailRowArgs {
 	std::uint8_t *outU8;
 	std::ptrdiff_t outStride;
 	int H, W;
+	float slope;          // activation after convT1: < 0 ReLU, else LeakyReLU(slope)
 };
+
+// LeakyReLU (reference models.py:24-27 "lrelu"): x < 0 ? slope * x : x, in f32 before the
+// rounding to the 16-bit type
+__device__ __forceinline__ float leaky(float v, float slope) {
+	return v < 0.0f ? v * slope : v;
+}
 
 template <typename T, typename FetchB>
 __device__ __forceinline__ void tailRow(FetchB fetchB, const unsigned char *smW, unsigned char *smMid,
@@ -181,10 +188,18 @@ __device__ __forceinline__ void tailRow(FetchB fetchB, const unsigned char *smW,
 	for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
-			Vec4<T> o = {static_cast<T>(acc[nb][4 * g + 0]), static_cast<T>(acc[nb][4 * g + 1]),
-			    static_cast<T>(acc[nb][4 * g + 2]), static_cast<T>(acc[nb][4 * g + 3])};
+			Vec4<T> o;
+			if (t.slope < 0.0f) {  // (uniform)
+				o = reluPacked<T>(Vec4<T>{static_cast<T>(acc[nb][4 * g + 0]), static_cast<T>(acc[nb][4 * g + 1]),
+				    static_cast<T>(acc[nb][4 * g + 2]), static_cast<T>(acc[nb][4 * g + 3])});
+			} else {
+				o = Vec4<T>{static_cast<T>(leaky(acc[nb][4 * g + 0], t.slope)),
+				    static_cast<T>(leaky(acc[nb][4 * g + 1], t.slope)),
+				    static_cast<T>(leaky(acc[nb][4 * g + 2], t.slope)),
+				    static_cast<T>(leaky(acc[nb][4 * g + 3], t.slope))};
+			}
 			*reinterpret_cast<Vec4<T> *>(smMid + nb * 2048 + px * 64 +
-			                             ((g ^ ((px >> 2) & 3)) << 4) + hh * 8) = reluPacked<T>(o);
+			                             ((g ^ ((px >> 2) & 3)) << 4) + hh * 8) = o;
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -33,7 +33,8 @@ struct ConvParams {
 	int H, W;
 	int cin, cout;
 	int taps;    // 9 (3x3 "same") or 1 (1x1)
-	int relu;    // apply max(x, 0)
+	int relu;    // activation: 0 none, 1 max(x, 0), 2 LeakyReLU (x < 0 ? slope * x : x)
+	float slope; // negative slope for relu == 2
 	int outF32;  // store f32 instead of the 16-bit type
 	// 2x2 max-pool fused into the epilogue: out is [H/2][W/2][cout] (dense or pitched
 	// in POOLED pixels).  Needs rw == 2, even H and W, no residual, 16-bit output.
@@ -231,7 +232,7 @@ void launchTemporalFilter(void *state, const void *preWarp, std::uint8_t *outU8,
 void launchTail(DType dt, const void *y, const float *w2, const float *b2,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *stateOut,
     std::uint8_t *outU8, std::ptrdiff_t outStride, int H, int W, const unsigned *sums,
-    hipStream_t stream);
+    hipStream_t stream);  // (the activation of convT1 is applied by the conv launch that makes y)
 
 // Fused tail: both transposed convs on the matrix cores + tanh + skip + clip + pack.
 // x: trunk addressed at pixel (0,0) with pitch xPitch (0 = dense); w1/b1: convT1 as a
@@ -251,6 +252,7 @@ struct TailFusedLaunch {
 	std::ptrdiff_t outStride;
 	const unsigned *sums;
 	int H, W;
+	float slope;  // activation after convT1: < 0 = ReLU, else LeakyReLU with this negative slope
 };
 void launchTailFused(DType dt, const TailFusedLaunch &p, hipStream_t stream);
 

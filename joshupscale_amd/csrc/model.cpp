@@ -63,6 +63,14 @@ ModelFile::ModelFile(const void *blob, std::size_t size) {
 	const int nTensors = u32(104);
 	c.temporalStrength = readLE<float>(b + 108);
 	c.temporalThreshold = readLE<float>(b + 112);
+	{
+		const auto acts = readLE<std::uint32_t>(b + 116);
+		c.flowActivation = static_cast<int>(acts & 0xffu);
+		c.genActivation = static_cast<int>((acts >> 8) & 0xffu);
+		if (acts >> 16) throw std::invalid_argument("Invalid model: unknown activation field");
+		c.flowNegativeSlope = readLE<float>(b + 120);
+		c.genNegativeSlope = readLE<float>(b + 124);
+	}
 	if (scale != 4) throw std::invalid_argument("Invalid model: scale must be 4");
 	if (nTensors < 0 || headerBytes + static_cast<std::size_t>(nTensors) * kEntryBytes > size) {
 		throw std::invalid_argument("Invalid model: truncated tensor table");
@@ -120,6 +128,17 @@ void validateConfig(const ModelConfig &c) {
 	    !(c.temporalThreshold >= 0.0f && c.temporalThreshold <= 1.0f)) {
 		bad("temporal filter strength/threshold must be in [0, 1]");
 	}
+	// ACTIVATIONS = {relu, lrelu} (models.py:24-27).  The slope must keep the activation
+	// monotonic (the flow encoder pools AFTER it in the reference and before it here).
+	auto checkAct = [&](int act, float slope, const char *what) {
+		if (act != 0 && act != 1) bad(std::string("unknown ") + what + " activation");
+		if (act == 1 && !(slope >= 0.0f && slope <= 1.0f)) {
+			bad(std::string(what) + " negative_slope must be in [0, 1]");
+		}
+		if (act == 0 && slope != 0.0f) bad(std::string(what) + " negative_slope set on a relu model");
+	};
+	checkAct(c.flowActivation, c.flowNegativeSlope, "flow");
+	checkAct(c.genActivation, c.genNegativeSlope, "generator");
 	if (c.flowArch == 0) {
 		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
 		const int PH = c.paddedHeight(), PW = c.paddedWidth();

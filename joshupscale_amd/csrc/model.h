@@ -32,6 +32,10 @@ struct ModelConfig {
 	// temporal moving-average output filter (frame_moving_avg.py); strength 0 = off
 	float temporalStrength = 0.0f;
 	float temporalThreshold = 0.1f;
+	// `activation` of the sub-model constructors (reference models.py:24-27, 261, 337, 489):
+	// 0 = relu, 1 = lrelu (keras LeakyReLU(negative_slope))
+	int flowActivation = 0, genActivation = 0;
+	float flowNegativeSlope = 0.0f, genNegativeSlope = 0.0f;
 
 	// reference scripts/training/models.py:735-744
 	int paddedHeight() const {

@@ -42,7 +42,8 @@ struct TowerParams {
 	void *out;         // allocation start
 	int H, W, pitch;   // pitch in pixels
 	int tilesX, numTiles;
-	int relu;
+	int relu;     // 0 none, 1 ReLU, 2 LeakyReLU(slope)
+	float slope;
 };
 
 // VARIANT is a timing-only ablation switch (tools/tower_ablation.py); 0 is the
@@ -263,9 +264,12 @@ __global__ __launch_bounds__(kTowerThreads, 1) void conv_tower_kernel(TowerParam
 #pragma unroll
 							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(resv[rw][nb][g][i]);
 						}
-						if (p.relu) {
+						if (p.relu == 1) {
 #pragma unroll
 							for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+						} else if (p.relu == 2) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] = leaky(v[i], p.slope);
 						}
 						Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]),
 						    static_cast<T>(v[2]), static_cast<T>(v[3])};
@@ -333,6 +337,7 @@ void launchTowerT(const ConvParams &p, hipStream_t stream) {
 	t.tilesX = (p.W + 31) / 32;
 	t.numTiles = t.tilesX * ((p.H + 7) / 8);
 	t.relu = p.relu;
+	t.slope = p.slope;
 	// The XCD remap in the kernel is a bijection only on grids that are a multiple
 	// of 8; surplus workgroups find no tile and exit after the weight prologue.
 	const int grid = ((t.numTiles < 256 ? t.numTiles : 256) + 7) / 8 * 8;
@@ -972,7 +977,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		a2[0] = reinterpret_cast<const Vec8<T> *>(p.tailW2)[lane];
 		a2[1] = reinterpret_cast<const Vec8<T> *>(p.tailW2)[64 + lane];
 		const float b2v[3] = {p.tailB2[0], p.tailB2[1], p.tailB2[2]};
-		const TailRowArgs args{p.tailB1, p.frame, p.frameStride, p.state, p.outU8, p.outStride, p.H, p.W};
+		// (the resident tower runs ReLU models only: its halo tags live in the sign bits)
+		const TailRowArgs args{p.tailB1, p.frame, p.frameStride, p.state, p.outU8, p.outStride, p.H, p.W, -1.0f};
 		const float bright = brightnessOf(p.sums, 1.0f / static_cast<float>(p.H * p.W));
 		__syncthreads();
 		for (int r = wave; r < rhv; r += 4) {

@@ -35,12 +35,35 @@ from typing import Dict, List, Mapping, Sequence, Tuple
 
 import numpy as np
 
-from .model_file import ModelConfig
+from .model_file import ACTIVATION, DEFAULT_NEGATIVE_SLOPE, ModelConfig
 
 BN_VARS = ("gamma", "beta", "moving_mean", "moving_variance")
 _BLOCK = re.compile(r"^block_(\d+)_(conv_1|bn_1|conv_2|bn_2)$")
 
 Layers = Mapping[str, Sequence[np.ndarray]]
+
+
+def activation_fields(activation) -> Tuple[str, float]:
+    """The reference's ``Activation`` spec (scripts/training/models.py:20, 36-60): a name
+    or ``{"name": ..., **layer kwargs}`` -> ``(container activation, negative_slope)``.
+    ``relu`` / ``lrelu`` are the reference's whole table (models.py:24-27); of the layer
+    kwargs only LeakyReLU's ``negative_slope`` (Keras 2 spelling: ``alpha``) is supported."""
+    if isinstance(activation, str):
+        name, args = activation, {}
+    elif isinstance(activation, dict):
+        name = activation["name"]
+        args = {k: v for k, v in activation.items() if k != "name"}
+    else:
+        raise TypeError("Unknown type")                       # models.py:55-56
+    if name not in ACTIVATION:
+        raise ValueError(f"Unknown activation: {name}")      # models.py:57-58
+    slope = DEFAULT_NEGATIVE_SLOPE
+    for key in ("negative_slope", "alpha"):
+        if key in args:
+            slope = float(args.pop(key))
+    if args or (name == "relu" and slope != DEFAULT_NEGATIVE_SLOPE):
+        raise ValueError(f"activation {name!r}: unsupported layer arguments {sorted(args) or ['negative_slope']}")
+    return name, slope
 
 
 def container_name(model: str, layer: str) -> str:
@@ -103,7 +126,8 @@ def container_weights(generator: Layers, flow: Layers, base: ModelConfig
     """Map the two sub-models' layers to container tensors.
 
     ``base`` supplies what the weights cannot tell (frame size, flow padding,
-    brightness flag, BatchNorm epsilon, compute dtype); filters, block counts,
+    brightness flag, BatchNorm epsilon, compute dtype, the two activations -- see
+    :func:`activation_fields`); filters, block counts,
     the flow architecture and the number of flow inputs are read off the shapes
     and override ``base``.
     """

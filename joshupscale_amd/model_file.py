@@ -26,7 +26,9 @@ Layout (all little endian):
     100 u32      compute_dtype hint (0 fp16, 1 bf16, 2 fp8 = e4m3 block convolutions over fp16)
     104 u32      n_tensors
     108 f32      temporal_strength (0 = filter off), temporal_threshold
-    116 u32      reserved[3]                        -> header_bytes = 128
+    116 u32      activations: bits 0-7 flow net, bits 8-15 generator (0 relu, 1 lrelu)
+    120 f32      flow negative_slope, generator negative_slope (read only for lrelu)
+                                                    -> header_bytes = 128
     table: n_tensors x { char name[92]; u32 ndim; u32 dims[4]; u64 offset;
                          u64 count }                (128 bytes each)
     data:  float32, each tensor 64-byte aligned, offsets from file start
@@ -50,6 +52,12 @@ DTYPE_FP8 = 2  # e4m3 block convolutions over fp16 (csrc/fp8.h)
 
 FLOW_ARCH = {"autoencoder": 0, "resnet": 1}
 FLOW_ARCH_INV = {v: k for k, v in FLOW_ARCH.items()}
+# ACTIVATIONS of scripts/training/models.py:24-27
+ACTIVATION = {"relu": 0, "lrelu": 1}
+ACTIVATION_INV = {v: k for k, v in ACTIVATION.items()}
+# keras.layers.LeakyReLU() default (Keras 3, tensorflow-cpu==2.18.0 of the reference's
+# requirements); a config may override it: {"name": "lrelu", "negative_slope": 0.2}
+DEFAULT_NEGATIVE_SLOPE = 0.3
 
 
 @dataclass
@@ -74,6 +82,12 @@ class ModelConfig:
     # strength 0 = off (the plain model).
     temporal_strength: float = 0.0
     temporal_threshold: float = 0.1
+    # `activation` of get_flow_* / get_generator_resnet (models.py:261, 337, 489):
+    # "relu" (the default) or "lrelu" with its negative_slope
+    flow_activation: str = "relu"
+    gen_activation: str = "relu"
+    flow_negative_slope: float = DEFAULT_NEGATIVE_SLOPE
+    gen_negative_slope: float = DEFAULT_NEGATIVE_SLOPE
 
     @property
     def padded_height(self) -> int:
@@ -185,8 +199,9 @@ def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray]) -> bytes:
     ff = list(cfg.flow_filters) + [0] * (8 - len(cfg.flow_filters))
     if len(cfg.flow_filters) > 8:
         raise ValueError("at most 8 flow filters")
+    acts = ACTIVATION[cfg.flow_activation] | ACTIVATION[cfg.gen_activation] << 8
     hdr = MAGIC + struct.pack(
-        "<2I4I4I4I8IfIIff3I", VERSION, HEADER_BYTES,
+        "<2I4I4I4I8IfIIffIff", VERSION, HEADER_BYTES,
         cfg.frame_height, cfg.frame_width, 4, cfg.num_flow_inputs,
         FLOW_ARCH[cfg.flow_arch], cfg.flow_pad_factor,
         int(cfg.normalize_brightness), cfg.gen_filters,
@@ -195,7 +210,9 @@ def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray]) -> bytes:
         # (filter off: both words stay zero, the file is byte-identical to one written
         # before the filter existed)
         cfg.temporal_strength, cfg.temporal_threshold if cfg.temporal_strength > 0 else 0.0,
-        0, 0, 0)
+        # (all-ReLU models: the three words stay zero, as before the field existed)
+        acts, cfg.flow_negative_slope if cfg.flow_activation == "lrelu" else 0.0,
+        cfg.gen_negative_slope if cfg.gen_activation == "lrelu" else 0.0)
     assert len(hdr) == HEADER_BYTES, len(hdr)
     off = HEADER_BYTES + ENTRY_BYTES * len(names)
     off = (off + 63) // 64 * 64
@@ -221,18 +238,21 @@ def deserialize(blob: bytes) -> Tuple[ModelConfig, Dict[str, np.ndarray]]:
     """Parse container bytes (the Python twin of csrc/model.cpp)."""
     if len(blob) < HEADER_BYTES or blob[:8] != MAGIC:
         raise ValueError("not a JoshUpscale-AMD model container")
-    vals = struct.unpack_from("<2I4I4I4I8IfIIff", blob, 8)
+    vals = struct.unpack_from("<2I4I4I4I8IfIIffIff", blob, 8)
     version, header_bytes = vals[0], vals[1]
     if version != VERSION:
         raise ValueError(f"unsupported container version {version}")
     (fh, fw, scale, nfi, arch, pad, nb, gf, gb, frf, frb, nff) = vals[2:14]
     ff = vals[14:22]
-    eps, cdt, nt, ts, tt = vals[22:27]
+    eps, cdt, nt, ts, tt, acts, fslope, gslope = vals[22:30]
     if scale != 4:
         raise ValueError("scale must be 4")
+    fact, gact = ACTIVATION_INV[acts & 0xff], ACTIVATION_INV[(acts >> 8) & 0xff]
     cfg = ModelConfig(fh, fw, nfi, FLOW_ARCH_INV[arch], tuple(ff[:nff]), frf,
                       frb, pad, gf, gb, bool(nb), eps, cdt, ts,
-                      tt if ts > 0 else ModelConfig.temporal_threshold)
+                      tt if ts > 0 else ModelConfig.temporal_threshold, fact, gact,
+                      fslope if fact == "lrelu" else DEFAULT_NEGATIVE_SLOPE,
+                      gslope if gact == "lrelu" else DEFAULT_NEGATIVE_SLOPE)
     w = {}
     for i in range(nt):
         name, ndim, d0, d1, d2, d3, off, cnt = struct.unpack_from(

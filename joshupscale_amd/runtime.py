@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
         "ju_time_steps": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, P(C.c_double),
                                     P(C.c_int), P(C.c_double)]),
         "ju_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
+        "ju_get_stat": (C.c_int, [C.c_void_p, C.c_char_p, P(C.c_double)]),
         "ju_version": (C.c_char_p, []),
     }
     for name, (res, args) in sigs.items():
@@ -208,6 +209,13 @@ class Runtime:
         _check(self._lib, self._lib.ju_read_tensor(
             self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.size, C.byref(n)))
         return arr
+
+    def stat(self, key: str) -> float:
+        """``ju_get_stat``: "graph_replays", "eager_runs", "direct_graphs",
+        "resident_tower", "resident_flow", "launches_per_frame"."""
+        v = C.c_double()
+        _check(self._lib, self._lib.ju_get_stat(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     def time_steps(self, tag: str, iters: int) -> Tuple[float, int, float]:
         """(ms per launch, launches per repetition, FLOPs per repetition)."""

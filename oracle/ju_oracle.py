@@ -70,6 +70,24 @@ class ModelConfig:
     # deployment is TensorRT INT8 (scripts/inference/tensorrt/quantize_int8.py) -- so
     # this restates the BUILD's scheme (joshupscale_amd/csrc/fp8.h) for parity checks.
     fp8_tower: bool = False
+    # `activation` of the sub-model constructors (models.py:24-27, 36-60, 261, 337, 489):
+    # "relu" -> keras.layers.ReLU(), "lrelu" -> keras.layers.LeakyReLU(negative_slope).
+    # 0.3 is Keras 3's LeakyReLU default (the reference pins tensorflow-cpu==2.18.0;
+    # Keras itself is not in the reference tree: stated assumption).
+    flow_activation: str = "relu"
+    gen_activation: str = "relu"
+    flow_negative_slope: float = 0.3
+    gen_negative_slope: float = 0.3
+
+    def act(self, part: str):
+        """Activation callable of the flow net (``part="flow"``) or the generator."""
+        name = self.flow_activation if part == "flow" else self.gen_activation
+        slope = self.flow_negative_slope if part == "flow" else self.gen_negative_slope
+        if name == "relu":
+            return relu
+        if name == "lrelu":
+            return lambda x: leaky_relu(x, slope)
+        raise ValueError(f"Unknown activation: {name}")   # models.py:57-58
 
     @property
     def padded_height(self) -> int:
@@ -126,6 +144,12 @@ def batch_norm(x: np.ndarray, gamma, beta, mean, var, eps: float) -> np.ndarray:
 def relu(x: np.ndarray) -> np.ndarray:
     """Default activation of every inference-path model (models.py:261, 337, 489)."""
     return np.maximum(x, 0)
+
+
+def leaky_relu(x: np.ndarray, negative_slope: float) -> np.ndarray:
+    """``layers.LeakyReLU(negative_slope)`` (models.py:24-27 "lrelu"):
+    ``x if x >= 0 else negative_slope * x``."""
+    return np.where(x >= 0, x, x * x.dtype.type(negative_slope))
 
 
 def max_pool_2x2(x: np.ndarray) -> np.ndarray:
@@ -259,23 +283,23 @@ def _rec(trace: Optional[dict], name: str, value: np.ndarray) -> None:
         trace[name] = value
 
 
-def _conv_bn_act(x, wts: Weights, conv: str, bn: str, eps: float) -> np.ndarray:
+def _conv_bn_act(x, wts: Weights, conv: str, bn: str, eps: float, act=relu) -> np.ndarray:
     y = conv2d_same(x, wts[conv + "/kernel"])
     y = batch_norm(y, wts[bn + "/gamma"], wts[bn + "/beta"],
                    wts[bn + "/moving_mean"], wts[bn + "/moving_variance"], eps)
-    return relu(y)
+    return act(y)
 
 
-def res_block(x, wts: Weights, name: str, eps: float) -> np.ndarray:
+def res_block(x, wts: Weights, name: str, eps: float, act=relu) -> np.ndarray:
     """``res_block`` (models.py:193-254):
     ``act(BN2(conv2(act(BN1(conv1(x))))) + x)``; FadeIn is the identity at
     inference once its counter has saturated (keras_layers.py:321-323)."""
-    y = _conv_bn_act(x, wts, name + "/conv_1", name + "/bn_1", eps)
+    y = _conv_bn_act(x, wts, name + "/conv_1", name + "/bn_1", eps, act)
     y = conv2d_same(y, wts[name + "/conv_2/kernel"])
     b = name + "/bn_2"
     y = batch_norm(y, wts[b + "/gamma"], wts[b + "/beta"],
                    wts[b + "/moving_mean"], wts[b + "/moving_variance"], eps)
-    return relu(y + x)
+    return act(y + x)
 
 
 # --------------------------------------------------------------------------
@@ -338,27 +362,28 @@ def flow_autoencoder(frames: Sequence[np.ndarray], wts: Weights,
     """``get_flow_autoencoder`` (models.py:334-481).  Returns the flow field
     ``[4*PH, 4*PW, 2]`` (channel 0 = dy, 1 = dx, in HR pixels)."""
     eps = cfg.bn_eps
+    act = cfg.act("flow")
     x = np.concatenate(list(frames), axis=2)  # models.py:373-375
     filters = cfg.flow_filters
     nblk = len(filters) // 2
     for i in range(nblk):  # down blocks, models.py:377-410, 450-451
         n = f"flow/block_{i + 1}"
-        x = _conv_bn_act(x, wts, n + "/conv_1", n + "/bn_1", eps)
+        x = _conv_bn_act(x, wts, n + "/conv_1", n + "/bn_1", eps, act)
         _rec(trace, n + "/a_1", x)
-        x = _conv_bn_act(x, wts, n + "/conv_2", n + "/bn_2", eps)
+        x = _conv_bn_act(x, wts, n + "/conv_2", n + "/bn_2", eps, act)
         _rec(trace, n + "/a_2", x)
         x = max_pool_2x2(x)
         _rec(trace, n + "/resample", x)
     for i in range(nblk, 2 * nblk):  # up blocks, models.py:412-447, 452-453
         n = f"flow/block_{i + 1}"
-        x = _conv_bn_act(x, wts, n + "/conv_1", n + "/bn_1", eps)
+        x = _conv_bn_act(x, wts, n + "/conv_1", n + "/bn_1", eps, act)
         _rec(trace, n + "/a_1", x)
-        x = _conv_bn_act(x, wts, n + "/conv_2", n + "/bn_2", eps)
+        x = _conv_bn_act(x, wts, n + "/conv_2", n + "/bn_2", eps, act)
         _rec(trace, n + "/a_2", x)
         x = resize_bilinear_tf1(x, 2)
         _rec(trace, n + "/resample", x)
     if len(filters) % 2:  # models.py:454-468
-        x = _conv_bn_act(x, wts, "flow/conv_1", "flow/bn_1", eps)
+        x = _conv_bn_act(x, wts, "flow/conv_1", "flow/bn_1", eps, act)
         _rec(trace, "flow/a_1", x)
     x = conv2d_same(x, wts["flow/conv_2/kernel"], wts["flow/conv_2/bias"])
     _rec(trace, "flow", x)  # head before depth-to-space: [PH, PW, 32]
@@ -369,10 +394,11 @@ def flow_resnet(frames: Sequence[np.ndarray], wts: Weights,
                 cfg: ModelConfig, trace: Optional[dict] = None) -> np.ndarray:
     """``get_flow_resnet`` (models.py:257-331)."""
     eps = cfg.bn_eps
+    act = cfg.act("flow")
     x = np.concatenate(list(frames), axis=2)
-    x = _conv_bn_act(x, wts, "flow/conv_1", "flow/bn_1", eps)
+    x = _conv_bn_act(x, wts, "flow/conv_1", "flow/bn_1", eps, act)
     for i in range(cfg.flow_res_blocks):
-        x = res_block(x, wts, f"flow/block_{i + 1}", eps)
+        x = res_block(x, wts, f"flow/block_{i + 1}", eps, act)
     x = conv2d_same(x, wts["flow/conv_2/kernel"], wts["flow/conv_2/bias"])
     _rec(trace, "flow", x)
     return depth_to_space(x, 4)
@@ -382,9 +408,12 @@ def generator(images: np.ndarray, pre_warp: np.ndarray, wts: Weights,
               cfg: ModelConfig, trace: Optional[dict] = None) -> np.ndarray:
     """``get_generator_resnet`` (models.py:484-595)."""
     eps = cfg.bn_eps
+    act = cfg.act("generator")
+    if cfg.fp8_tower and cfg.gen_activation != "relu":
+        raise ValueError("the 8-bit tower scheme is defined for ReLU generators only")
     x = np.concatenate([images, space_to_depth(pre_warp, 4)], axis=2)  # :523-530
     _rec(trace, "gen_in_ref", x)  # reference channel order, 51 channels
-    x = _conv_bn_act(x, wts, "generator/conv_1", "generator/bn_1", eps)
+    x = _conv_bn_act(x, wts, "generator/conv_1", "generator/bn_1", eps, act)
     _rec(trace, "gen_head", x)
     if cfg.fp8_tower:
         amax = wts.get("generator/fp8_amax")
@@ -394,13 +423,13 @@ def generator(images: np.ndarray, pre_warp: np.ndarray, wts: Weights,
         if cfg.fp8_tower:
             x = res_block_fp8(x, wts, f"generator/block_{i + 1}", eps, exps[2 * i], exps[2 * i + 1])
         else:
-            x = res_block(x, wts, f"generator/block_{i + 1}", eps)
+            x = res_block(x, wts, f"generator/block_{i + 1}", eps, act)
     _rec(trace, "trunk", x)
     x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_1/kernel"])
     b = "generator/bn_2"
-    x = relu(batch_norm(x, wts[b + "/gamma"], wts[b + "/beta"],
-                        wts[b + "/moving_mean"], wts[b + "/moving_variance"],
-                        eps))
+    x = act(batch_norm(x, wts[b + "/gamma"], wts[b + "/beta"],
+                       wts[b + "/moving_mean"], wts[b + "/moving_variance"],
+                       eps))                        # models.py:567-572
     _rec(trace, "tail_mid", x)  # [2H, 2W, 32]
     x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_2/kernel"],
                               wts["generator/conv_trans_2/bias"])

@@ -52,6 +52,8 @@ typedef struct {
 	int H, W, PH, PW, n_in, arch, pad, gen_filters, gen_blocks, res_filters, res_blocks;
 	int n_ff, ff[8];
 	float eps;
+	/* activation of the flow net / generator (models.py:24-27): negative slope, 0 = ReLU */
+	float flow_slope, gen_slope;
 	int n_tensors;
 	juo_tensor t[MAX_TENSORS];
 	/* recurrent state (zero-initialised: reference cuda.h:69-72) */
@@ -125,8 +127,14 @@ static void conv2d_same(const float *x, int H, int W, int cin, const float *k, i
 	}
 }
 
-/* BatchNormalization at inference + optional ReLU, in place (models.py:226-231). */
-static void bn_act(float *x, size_t pixels, int c, const juo *m, const char *bn, int relu) {
+/* keras ReLU (slope 0) / LeakyReLU(negative_slope) (models.py:24-27) */
+static inline float act_fn(float v, float slope) {
+	return v < 0.0f ? (slope == 0.0f ? 0.0f : v * slope) : v;
+}
+
+/* BatchNormalization at inference + optional activation (slope < 0: none), in place
+ * (models.py:226-231). */
+static void bn_act(float *x, size_t pixels, int c, const juo *m, const char *bn, float slope) {
 	const float *g = getf(m, bn, "/gamma"), *be = getf(m, bn, "/beta");
 	const float *mu = getf(m, bn, "/moving_mean"), *var = getf(m, bn, "/moving_variance");
 	float sc[256], sh[256];
@@ -139,13 +147,13 @@ static void bn_act(float *x, size_t pixels, int c, const juo *m, const char *bn,
 		float *p = x + (size_t)i * c;
 		for (int o = 0; o < c; ++o) {
 			float v = p[o] * sc[o] + sh[o];
-			p[o] = (relu && v < 0.0f) ? 0.0f : v;
+			p[o] = slope < 0.0f ? v : act_fn(v, slope);
 		}
 	}
 }
 
-static float *conv_bn_relu(const juo *m, const float *x, int H, int W, int cin, const char *conv,
-    const char *bn, int *cout_out) {
+static float *conv_bn_act(const juo *m, const float *x, int H, int W, int cin, const char *conv,
+    const char *bn, int *cout_out, float slope) {
 	char kn[200];
 	snprintf(kn, sizeof(kn), "%s/kernel", conv);
 	const juo_tensor *k = get(m, kn);
@@ -156,32 +164,29 @@ static float *conv_bn_relu(const juo *m, const float *x, int H, int W, int cin, 
 	}
 	float *y = (float *)malloc(sizeof(float) * (size_t)H * W * cout);
 	conv2d_same(x, H, W, cin, k->data, ks, cout, NULL, y);
-	bn_act(y, (size_t)H * W, cout, m, bn, 1);
+	bn_act(y, (size_t)H * W, cout, m, bn, slope);
 	*cout_out = cout;
 	return y;
 }
 
-/* res_block (models.py:193-254): relu(BN2(conv2(relu(BN1(conv1(x))))) + x) */
-static float *res_block(const juo *m, float *x, int H, int W, int c, const char *name) {
+/* res_block (models.py:193-254): act(BN2(conv2(act(BN1(conv1(x))))) + x) */
+static float *res_block(const juo *m, float *x, int H, int W, int c, const char *name, float slope) {
 	char c1[200], b1[200], c2[200], b2[200], kn[220];
 	snprintf(c1, sizeof(c1), "%s/conv_1", name);
 	snprintf(b1, sizeof(b1), "%s/bn_1", name);
 	snprintf(c2, sizeof(c2), "%s/conv_2", name);
 	snprintf(b2, sizeof(b2), "%s/bn_2", name);
 	int co;
-	float *t = conv_bn_relu(m, x, H, W, c, c1, b1, &co);
+	float *t = conv_bn_act(m, x, H, W, c, c1, b1, &co, slope);
 	snprintf(kn, sizeof(kn), "%s/kernel", c2);
 	const juo_tensor *k = get(m, kn);
 	float *y = (float *)malloc(sizeof(float) * (size_t)H * W * c);
 	conv2d_same(t, H, W, c, k->data, k->dims[0], c, NULL, y);
 	free(t);
-	bn_act(y, (size_t)H * W, c, m, b2, 0);
+	bn_act(y, (size_t)H * W, c, m, b2, -1.0f);
 	const size_t n = (size_t)H * W * c;
 #pragma omp parallel for schedule(static)
-	for (long i = 0; i < (long)n; ++i) {
-		const float v = y[i] + x[i];
-		y[i] = v < 0.0f ? 0.0f : v;
-	}
+	for (long i = 0; i < (long)n; ++i) y[i] = act_fn(y[i] + x[i], slope);
 	free(x);
 	return y;
 }
@@ -271,9 +276,9 @@ static float *flow_head(const juo *m, float *x) {
 			snprintf(b1, sizeof(b1), "flow/block_%d/bn_1", i + 1);
 			snprintf(n2, sizeof(n2), "flow/block_%d/conv_2", i + 1);
 			snprintf(b2, sizeof(b2), "flow/block_%d/bn_2", i + 1);
-			float *a1 = conv_bn_relu(m, x, h, w, c, n1, b1, &co);
+			float *a1 = conv_bn_act(m, x, h, w, c, n1, b1, &co, m->flow_slope);
 			free(x);
-			float *a2 = conv_bn_relu(m, a1, h, w, co, n2, b2, &co);
+			float *a2 = conv_bn_act(m, a1, h, w, co, n2, b2, &co, m->flow_slope);
 			free(a1);
 			c = co;
 			if (i < nb) {
@@ -288,19 +293,19 @@ static float *flow_head(const juo *m, float *x) {
 			}
 		}
 		if (m->n_ff % 2) {
-			float *a = conv_bn_relu(m, x, h, w, c, "flow/conv_1", "flow/bn_1", &co);
+			float *a = conv_bn_act(m, x, h, w, c, "flow/conv_1", "flow/bn_1", &co, m->flow_slope);
 			free(x);
 			x = a;
 			c = co;
 		}
 	} else {
-		float *a = conv_bn_relu(m, x, h, w, c, "flow/conv_1", "flow/bn_1", &co);
+		float *a = conv_bn_act(m, x, h, w, c, "flow/conv_1", "flow/bn_1", &co, m->flow_slope);
 		free(x);
 		x = a;
 		c = co;
 		for (int i = 0; i < m->res_blocks; ++i) {
 			snprintf(n1, sizeof(n1), "flow/block_%d", i + 1);
-			x = res_block(m, x, h, w, c, n1);
+			x = res_block(m, x, h, w, c, n1, m->flow_slope);
 		}
 	}
 	const juo_tensor *k = get(m, "flow/conv_2/kernel");
@@ -330,6 +335,12 @@ void *juo_create(const void *blob, size_t size) {
 	m->n_ff = (int)rd32(b + 60);
 	for (int i = 0; i < m->n_ff && i < 8; ++i) m->ff[i] = (int)rd32(b + 64 + 4 * i);
 	memcpy(&m->eps, b + 96, 4);
+	{ /* header word 116: activation codes (0 relu, 1 lrelu), 120 / 124: negative slopes */
+		const uint32_t acts = rd32(b + 116);
+		m->flow_slope = m->gen_slope = 0.0f;
+		if ((acts & 0xff) == 1) memcpy(&m->flow_slope, b + 120, 4);
+		if (((acts >> 8) & 0xff) == 1) memcpy(&m->gen_slope, b + 124, 4);
+	}
 	m->n_tensors = (int)rd32(b + 104);
 	if (rd32(b + 40) != 0 || rd32(b + 108) != 0 || m->n_tensors > MAX_TENSORS) { /* normalize_brightness, temporal filter: unsupported */
 		free(m->blob);
@@ -446,17 +457,17 @@ int juo_run(void *hdl, const uint8_t *frame, uint8_t *out) {
 	}
 	free(pre_warp);
 	int c;
-	float *g = conv_bn_relu(m, x, H, W, 51, "generator/conv_1", "generator/bn_1", &c);
+	float *g = conv_bn_act(m, x, H, W, 51, "generator/conv_1", "generator/bn_1", &c, m->gen_slope);
 	free(x);
 	char name[200];
 	for (int i = 0; i < m->gen_blocks; ++i) {
 		snprintf(name, sizeof(name), "generator/block_%d", i + 1);
-		g = res_block(m, g, H, W, c, name);
+		g = res_block(m, g, H, W, c, name, m->gen_slope);
 	}
 	const juo_tensor *k1 = get(m, "generator/conv_trans_1/kernel");
 	float *t1 = conv_transpose2(g, H, W, c, k1->data, k1->dims[2], NULL);
 	free(g);
-	bn_act(t1, (size_t)4 * H * W, k1->dims[2], m, "generator/bn_2", 1);
+	bn_act(t1, (size_t)4 * H * W, k1->dims[2], m, "generator/bn_2", m->gen_slope);
 	const juo_tensor *k2 = get(m, "generator/conv_trans_2/kernel");
 	float *t2 = conv_transpose2(t1, 2 * H, 2 * W, k1->dims[2], k2->data, 3,
 	    get(m, "generator/conv_trans_2/bias")->data);

@@ -40,3 +40,12 @@ def _torch_device_first(request):
             torch.cuda.init()
             torch.zeros(1, device="cuda").cpu()
     yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs leave the measured parity numbers behind (gpurun_out/parity_stats.json)."""
+    try:
+        import gpu_common
+        gpu_common.dump_stats()
+    except Exception:  # pragma: no cover - never fail a run over the report
+        pass

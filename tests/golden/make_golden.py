@@ -8,7 +8,8 @@ accidental change, give the C restatement and the HIP engine fixed targets, and
 travel to the GPU box as plain data.
 
     python tests/golden/make_golden.py            # small fixtures (seconds)
-    python tests/golden/make_golden.py --full     # + 270x480 fixture (~2 min)
+    python tests/golden/make_golden.py --full     # + the four full-size presets (~15 min)
+    python tests/golden/make_golden.py --preset psp-fast   # one full-size preset only
 """
 
 import argparse
@@ -44,38 +45,90 @@ def small(name: str, cfg, n_frames: int, kind: str, seed: int, fp8_tower: bool =
     print(name, "ok", os.path.getsize(os.path.join(HERE, name + ".npz")), "bytes")
 
 
-def full() -> None:
-    cfg = M.PRESETS["psp-quality"]
+FULL_PRESETS = {          # preset -> (golden file, frames)
+    "psp-quality": ("full_psp_quality", 3),
+    "psp-fast": ("full_psp_fast", 3),
+    "psp-quality-flowres": ("full_psp_quality_flowres", 3),
+    "ps2-quality": ("full_ps2_quality", 2),
+}
+
+
+def crops_for(h: int, w: int):
+    """Six 64x64 HR windows: the four corners, the centre and one off-centre spot."""
+    H, W = 4 * h, 4 * w
+    return [(0, 0), (0, W - 64), (H - 64, 0), (H - 64, W - 64), (H // 2 - 32, W // 2 - 32),
+            (H * 5 // 18 // 4 * 4, W * 5 // 8 // 4 * 4)]
+
+
+def full(preset: str = "psp-quality") -> None:
+    """Full-size fixture of one preset, generated TWICE: by the numpy float64 oracle and
+    by the independent PyTorch restatement (tests/torch_restatement.py).  Both whole-frame
+    SHA-256 digests are stored (the only independent anchor available: the reference ships
+    no vectors and cannot run here); the crops and means come from the numpy oracle."""
+    from torch_restatement import TorchSession
+    name, n = FULL_PRESETS[preset]
+    cfg = M.PRESETS[preset]
+    h, w = cfg.frame_height, cfg.frame_width
     wts = M.make_seeded_weights(cfg, seed=42)
     sess = O.Session(wts, oracle_config(cfg))
-    n = 3
-    frames = M.synthetic_frames(n, 270, 480, seed=777, kind="smooth")
-    crops_u8 = np.zeros((n, len(CROPS), 64, 64, 3), np.uint8)
-    crops_raw = np.zeros((n, len(CROPS), 64, 64, 3), np.float32)
+    tsess = TorchSession(wts, oracle_config(cfg))
+    frames = M.synthetic_frames(n, h, w, seed=777, kind="smooth")
+    crops = crops_for(h, w)
+    assert preset != "psp-quality" or crops == CROPS
+    crops_u8 = np.zeros((n, len(crops), 64, 64, 3), np.uint8)
+    crops_raw = np.zeros((n, len(crops), 64, 64, 3), np.float32)
     means = np.zeros((n, 3))
+    sha_np, sha_torch, n_diff, raw_diff = [], [], [], []
     for t in range(n):
         out = sess.run(frames[t])
-        for k, (y, x) in enumerate(CROPS):
+        tout = tsess.run(frames[t])
+        traw = tsess.output_raw[0].permute(1, 2, 0).numpy()
+        sha_np.append(hashlib.sha256(out.tobytes()).hexdigest())
+        sha_torch.append(hashlib.sha256(tout.tobytes()).hexdigest())
+        d = np.abs(out.astype(np.int32) - tout.astype(np.int32))
+        assert d.max() <= 1, "the two restatements disagree by more than a truncation boundary"
+        n_diff.append(int((d > 0).sum()))
+        raw_diff.append(float(np.abs(traw - sess.last.output_raw).max()))
+        for k, (y, x) in enumerate(crops):
             crops_u8[t, k] = out[y:y + 64, x:x + 64, :3]
             crops_raw[t, k] = sess.last.output_raw[y:y + 64, x:x + 64]
         means[t] = out[..., :3].reshape(-1, 3).mean(0)
-        print("full frame", t, means[t], flush=True)
+        print(preset, "frame", t, means[t], "bytes differing numpy/torch:", n_diff[-1],
+              "max |output_raw| diff:", raw_diff[-1], flush=True)
     np.savez_compressed(
-        os.path.join(HERE, "full_psp_quality.npz"), crops=np.array(CROPS), crops_u8=crops_u8,
+        os.path.join(HERE, name + ".npz"), crops=np.array(crops), crops_u8=crops_u8,
         crops_raw=crops_raw, means=means, frames_sha256=hashlib.sha256(frames.tobytes()).hexdigest(),
-        model_sha256=blob_sha(cfg, wts), seed=777, n_frames=n)
-    print("full ok")
+        model_sha256=blob_sha(cfg, wts), seed=777, n_frames=n,
+        out_sha256_numpy=np.array(sha_np), out_sha256_torch=np.array(sha_torch),
+        bytes_differing=np.array(n_diff), raw_max_diff=np.array(raw_diff))
+    print(preset, "ok")
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--full", action="store_true", help="every full-size preset (~15 min)")
+    ap.add_argument("--preset", action="append", choices=sorted(FULL_PRESETS),
+                    help="only this full-size preset (repeatable); skips the small fixtures")
+    ap.add_argument("--only", action="append", help="only this small fixture (repeatable)")
     a = ap.parse_args()
-    small("small_autoencoder", small_config(), 4, "smooth", 11)
-    small("small_resnet", small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2,
-                                       frame_height=34, frame_width=50), 4, "smooth", 12)
-    small("small_noise", small_config(gen_blocks=2), 3, "noise", 13)
-    # the 8-bit tower's restatement (BASELINE.json config 5; scheme of csrc/fp8.h)
-    small("small_fp8", small_config(gen_blocks=4), 3, "smooth", 14, fp8_tower=True)
+    if a.preset:
+        for p in a.preset:
+            full(p)
+        sys.exit(0)
+    smalls = {
+        "small_autoencoder": (small_config(), 4, "smooth", 11, False),
+        "small_resnet": (small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2,
+                                      frame_height=34, frame_width=50), 4, "smooth", 12, False),
+        "small_noise": (small_config(gen_blocks=2), 3, "noise", 13, False),
+        # the 8-bit tower's restatement (BASELINE.json config 5; scheme of csrc/fp8.h)
+        "small_fp8": (small_config(gen_blocks=4), 3, "smooth", 14, True),
+        # `activation: lrelu` models (reference models.py:24-27): both sub-models leaky
+        "small_lrelu": (small_config(flow_activation="lrelu", gen_activation="lrelu",
+                                     gen_negative_slope=0.2), 4, "smooth", 15, False),
+    }
+    for name, (cfg, n, kind, seed, fp8) in smalls.items():
+        if a.only is None or name in a.only:
+            small(name, cfg, n, kind, seed, fp8_tower=fp8)
     if a.full:
-        full()
+        for p in FULL_PRESETS:
+            full(p)

@@ -26,7 +26,10 @@ def oracle_config(cfg: M.ModelConfig, fp8_tower: bool = False) -> O.ModelConfig:
         bn_eps=float(np.float32(cfg.bn_eps)),
         temporal_strength=float(np.float32(cfg.temporal_strength)),
         temporal_threshold=float(np.float32(cfg.temporal_threshold)),
-        fp8_tower=fp8_tower)
+        fp8_tower=fp8_tower,
+        flow_activation=cfg.flow_activation, gen_activation=cfg.gen_activation,
+        flow_negative_slope=float(np.float32(cfg.flow_negative_slope)),
+        gen_negative_slope=float(np.float32(cfg.gen_negative_slope)))
 
 
 def small_config(**kw) -> M.ModelConfig:

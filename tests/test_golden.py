@@ -14,7 +14,10 @@ SMALL = {
     "small_resnet": small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2,
                                  frame_height=34, frame_width=50),
     "small_noise": small_config(gen_blocks=2),
+    "small_lrelu": small_config(flow_activation="lrelu", gen_activation="lrelu", gen_negative_slope=0.2),
 }
+FULL = {"psp-quality": "full_psp_quality", "psp-fast": "full_psp_fast",
+        "psp-quality-flowres": "full_psp_quality_flowres", "ps2-quality": "full_ps2_quality"}
 
 
 def load(name):
@@ -65,11 +68,28 @@ def test_c_restatement_matches_small_goldens(name):
     assert np.abs(cs.output_raw() - g["output_raw_last"]).max() < 5e-5
 
 
-def test_c_restatement_matches_full_size_golden_first_frame():
-    """One 480x270 frame of the BASELINE.json configuration (a few seconds)."""
+@pytest.mark.parametrize("preset", sorted(FULL))
+def test_full_size_goldens_were_generated_twice_and_agree(preset):
+    """Every full-size fixture was produced by BOTH restatements (numpy float64 oracle and
+    the independent PyTorch one, tests/golden/make_golden.py): whole-frame digests of each
+    are committed and must agree -- the only independent anchor available while the
+    reference itself cannot run here."""
+    g = load(FULL[preset])
+    cfg = M.PRESETS[preset]
+    assert len(g["out_sha256_numpy"]) == int(g["n_frames"]) == len(g["out_sha256_torch"])
+    assert [str(x) for x in g["out_sha256_numpy"]] == [str(x) for x in g["out_sha256_torch"]]
+    assert not g["bytes_differing"].any() and g["raw_max_diff"].max() < 1e-9
+    assert g["crops_u8"].shape == (int(g["n_frames"]), 6, 64, 64, 3)
+    H, W = 4 * cfg.frame_height, 4 * cfg.frame_width
+    assert all(0 <= y <= H - 64 and 0 <= x <= W - 64 for y, x in g["crops"])
+
+
+@pytest.mark.parametrize("preset", ["psp-quality", "psp-fast"])
+def test_c_restatement_matches_full_size_golden_first_frame(preset):
+    """One 480x270 frame of the BASELINE.json configurations (a few seconds each)."""
     from oracle.c_binding import CSession
-    g = load("full_psp_quality")
-    cfg = M.PRESETS["psp-quality"]
+    g = load(FULL[preset])
+    cfg = M.PRESETS[preset]
     blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=42))
     assert hashlib.sha256(blob).hexdigest() == str(g["model_sha256"])
     frames = M.synthetic_frames(int(g["n_frames"]), 270, 480, seed=int(g["seed"]), kind="smooth")

@@ -1,0 +1,171 @@
+"""Every BASELINE.json configuration at its FULL size, on both paths through the boundary
+(needs an MI355X): host frames (staging + graph replay, what the reference's AviSynth
+caller uses) and JU_LOC_DEVICE frames (no staging; the path bench.py times), in bf16 and
+fp16, against
+
+  * whole frames of the float32 C restatement (oracle/ju_oracle_c.c, run on this box's
+    host cores), and
+  * the committed crops of the float64 oracle, which were generated twice (numpy and the
+    independent PyTorch restatement; tests/golden/make_golden.py, tests/test_golden.py).
+
+Tolerances: tests/gpu_common.py.
+"""
+
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from gpu_common import GOLD, TOL, check_u8, make, record
+from helpers import M, u8_stats
+from joshupscale_amd import runtime as R
+
+pytestmark = pytest.mark.gpu
+
+FULL = {"psp-quality": "full_psp_quality", "psp-fast": "full_psp_fast",
+        "psp-quality-flowres": "full_psp_quality_flowres", "ps2-quality": "full_ps2_quality"}
+_C_REF = {}
+
+
+def c_reference(preset):
+    """Whole-frame outputs of the C restatement on the golden clip (computed once per preset)."""
+    if preset not in _C_REF:
+        from oracle.c_binding import CSession
+        g = np.load(os.path.join(GOLD, FULL[preset] + ".npz"))
+        cfg = M.PRESETS[preset]
+        blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+        assert hashlib.sha256(blob).hexdigest() == str(g["model_sha256"])
+        n = int(g["n_frames"])
+        frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=int(g["seed"]), kind="smooth")
+        assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
+        cs = CSession(blob, cfg.frame_height, cfg.frame_width)
+        outs = [cs.run(f).copy() for f in frames]
+        # the C restatement itself against the doubly-generated float64 crops: float32 vs
+        # float64 can only differ at a truncation boundary
+        for t in range(n):
+            for k, (y, x) in enumerate(g["crops"]):
+                d = np.abs(outs[t][y:y + 64, x:x + 64, :3].astype(int) - g["crops_u8"][t, k].astype(int))
+                assert d.max() <= 1 and np.mean(d > 0) < 0.01, (preset, t, k)
+        _C_REF[preset] = (g, frames, outs)
+    return _C_REF[preset]
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16])
+@pytest.mark.parametrize("preset", sorted(FULL))
+def test_full_size_preset_on_host_and_device_paths(preset, dtype):
+    import torch
+    g, frames, refs = c_reference(preset)
+    cfg = M.PRESETS[preset]
+    h, w = cfg.frame_height, cfg.frame_width
+    _, blob, rt = make(cfg, dtype)
+    assert (rt.input_width, rt.input_height, rt.output_width, rt.output_height) == (w, h, 4 * w, 4 * h)
+    n = len(frames)
+    # ---- host frames: staging + replay of the captured graph ----
+    host = []
+    for t in range(n):
+        out = rt.process_image(frames[t]).copy()
+        st = check_u8(out, refs[t], dtype, ("full", preset, "host", t))
+        got = np.stack([out[y:y + 64, x:x + 64] for y, x in g["crops"]])
+        ref = np.concatenate([g["crops_u8"][t], np.zeros(g["crops_u8"][t].shape[:3] + (1,), np.uint8)], -1)
+        check_u8(got, ref, dtype, ("full-crops", preset, t))
+        assert np.abs(out[..., :3].reshape(-1, 3).mean(0) - g["means"][t]).max() < 0.25
+        state = rt.read_tensor("state").reshape(4 * h, 4 * w, 4)
+        raw_err = max(np.abs(state[y:y + 64, x:x + 64, :3] - g["crops_raw"][t, k]).max()
+                      for k, (y, x) in enumerate(g["crops"]))
+        record(("full-raw", preset, t), dtype, {"raw": raw_err})
+        assert raw_err <= TOL[dtype]["raw"]
+        host.append(out)
+    assert rt.stat("graph_replays") == n and rt.stat("eager_runs") == 0
+    # ---- device frames: the kernels read / write the caller's memory; the path bench.py times ----
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(frames).to(dev)
+    d_out = torch.empty((4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(3):        # 1st pass eager (tuples seen once), 2nd captures, 3rd replays
+        rt.reset()
+        for t in range(n):
+            rt.process(rt.device_image(d_in[t].data_ptr(), w, h), rt.device_image(d_out.data_ptr(), 4 * w, 4 * h))
+            assert np.array_equal(d_out.cpu().numpy(), host[t]), (preset, "device", rep, t)
+    assert rt.stat("eager_runs") == n and rt.stat("direct_graphs") == n
+    assert rt.stat("graph_replays") == n + 2 * n
+    rt.close()
+
+
+def test_device_frame_graphs_equal_eager_launches(monkeypatch):
+    """Config 3 (psp-fast, fp16, latency-optimised graph capture): on device frames the
+    cached graph of a frame-buffer tuple replays exactly what the eager launches do, for a
+    clip whose buffers are reused, including bottom-up (negative stride) device frames."""
+    import torch
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames = M.synthetic_frames(4, h, w, seed=33, kind="smooth")
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(np.ascontiguousarray(frames[:, ::-1])).to(dev)     # stored bottom-up
+    d_out = torch.empty((2, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)   # two output buffers
+    torch.cuda.synchronize()
+
+    def run(rt, loops):
+        outs = []
+        for i in range(loops * 4):
+            t = i % 4
+            src = rt.device_image(d_in[t].data_ptr() + (h - 1) * w * 4, w, h, stride=-w * 4)
+            dst = rt.device_image(d_out[i % 2].data_ptr(), 4 * w, 4 * h)
+            rt.process(src, dst)
+            outs.append(d_out[i % 2].cpu().numpy())
+        return outs
+
+    monkeypatch.setenv("JU_DIRECT_GRAPH", "0")
+    eager_rt = R.Runtime(blob, 0, R.DTYPE_F16)
+    eager = run(eager_rt, 3)
+    assert eager_rt.stat("graph_replays") == 0 and eager_rt.stat("eager_runs") == 12
+    eager_rt.close()
+    monkeypatch.delenv("JU_DIRECT_GRAPH")
+    rt = R.Runtime(blob, 0, R.DTYPE_F16)
+    graph = run(rt, 3)
+    # 4 inputs x 2 outputs... tuple (t, i % 2, idx): t = i % 4 fixes i % 2 and the binding set
+    # alternates with i, so there are 4 tuples: seen in loop 1, captured in loop 2, replayed in 3
+    assert rt.stat("eager_runs") == 4 and rt.stat("graph_replays") == 8 and rt.stat("direct_graphs") == 4
+    for a, b in zip(eager, graph):
+        assert np.array_equal(a, b)
+    rt.close()
+
+
+def test_resident_failure_recovers_with_graphs_enabled():
+    """The default configuration (graphs on): a bounded wait of the resident tower expires
+    on an eagerly launched device frame; the engine runs the per-layer programs once
+    eagerly, captures them, re-runs the frame, and later host frames replay the new graphs."""
+    import torch
+    from helpers import small_config
+    cfg = small_config()
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames = M.synthetic_frames(5, 30, 48, seed=41, kind="smooth")
+    ref_rt = R.Runtime(blob, 0, R.DTYPE_BF16)
+    want = [ref_rt.process_image(f).copy() for f in frames]
+    ref_rt.close()
+    rt = R.Runtime(blob, 0, R.DTYPE_BF16)
+    assert rt.stat("resident_tower") == 1
+    lib = R.load_library()
+    seen = []
+    cb = R.LOG_CALLBACK(lambda tag, lvl, msg, user: seen.append((lvl, msg)))
+    lib.ju_set_log_callback(cb, None)
+    got = [rt.process_image(frames[0]).copy(), rt.process_image(frames[1]).copy()]   # graph replays
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(frames[2]).to(dev)
+    d_out = torch.empty((120, 192, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    assert lib.ju_debug_set(b"resident_fault", 1) == 0
+    try:
+        rt.process(rt.device_image(d_in.data_ptr(), 48, 30), rt.device_image(d_out.data_ptr(), 192, 120))
+    finally:
+        lib.ju_debug_set(b"resident_fault", 0)
+        lib.ju_set_log_callback(R.LOG_CALLBACK(0), None)
+    got.append(d_out.cpu().numpy())
+    assert rt.stat("resident_tower") == 0
+    replays = rt.stat("graph_replays")
+    got += [rt.process_image(f).copy() for f in frames[3:]]      # the re-captured per-layer graphs
+    assert rt.stat("graph_replays") == replays + 2
+    assert any(lvl == 1 and b"per-layer" in msg for lvl, msg in seen), seen
+    assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(want, got))
+    rt.close()

@@ -70,3 +70,24 @@ def test_errors_name_the_offending_layer():
     bad["conv_1"] = list(gen["conv_1"]) + [np.zeros(64, np.float32)]            # use_bias=True
     with pytest.raises(ValueError, match="generator/conv_1"):
         K.container_weights(bad, flow, cfg)
+
+
+def test_activation_spec_of_the_reference_configs():
+    """models.py:20, 36-60: a name, or {"name": ..., **LeakyReLU kwargs}."""
+    assert K.activation_fields("relu") == ("relu", M.DEFAULT_NEGATIVE_SLOPE)
+    assert K.activation_fields("lrelu") == ("lrelu", 0.3)
+    assert K.activation_fields({"name": "lrelu", "negative_slope": 0.2}) == ("lrelu", 0.2)
+    assert K.activation_fields({"name": "lrelu", "alpha": 0.1}) == ("lrelu", 0.1)
+    with pytest.raises(ValueError, match="Unknown activation"):
+        K.activation_fields("gelu")
+    with pytest.raises(TypeError):
+        K.activation_fields(3)
+    with pytest.raises(ValueError, match="unsupported"):
+        K.activation_fields({"name": "relu", "max_value": 6.0})
+    # the activation travels in `base` (the weights cannot tell it)
+    cfg = M.ModelConfig(frame_height=30, frame_width=48, flow_filters=(32, 64, 32), gen_blocks=2,
+                        flow_pad_factor=2, gen_activation="lrelu", gen_negative_slope=0.2)
+    gen, flow = K.layers_from_container(M.make_seeded_weights(cfg, seed=5))
+    cfg2, _ = K.container_weights(gen, flow, M.ModelConfig(
+        frame_height=30, frame_width=48, flow_pad_factor=2, gen_activation="lrelu", gen_negative_slope=0.2))
+    assert cfg2 == cfg

@@ -30,6 +30,7 @@ def patched(offset: int, fmt: str, *vals) -> bytes:
 def test_accepts_every_preset_and_variant(hip_library):
     for cfg in [CFG, small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2),
                 small_config(normalize_brightness=True), small_config(temporal_strength=0.25),
+                small_config(flow_activation="lrelu", gen_activation="lrelu", gen_negative_slope=0.2),
                 M.ModelConfig(gen_blocks=1), M.ModelConfig(frame_height=448, frame_width=640, gen_blocks=1)]:
         R.validate_model(M.serialize(cfg, M.make_seeded_weights(cfg)))
 
@@ -50,6 +51,11 @@ def test_header_fields_are_range_checked(hip_library):
     rejects(patched(96, "<f", float("nan")), "bn_eps")
     rejects(patched(100, "<I", 5), "compute dtype")
     rejects(patched(108, "<f", 1.5), "temporal")
+    rejects(patched(116, "<I", 2), "flow activation")          # ACTIVATIONS = {relu, lrelu}
+    rejects(patched(116, "<I", 0x0300), "generator activation")
+    rejects(patched(116, "<I", 0x10000), "activation field")
+    rejects(patched(116, "<If", 1, -0.5), "negative_slope")    # non-monotonic: rejected
+    rejects(patched(120, "<f", 0.3), "negative_slope set on a relu model")
     rejects(patched(104, "<I", 1 << 24), "truncated tensor table")
 
 

@@ -13,7 +13,8 @@ def test_roundtrip_all_presets():
         small = M.ModelConfig(**{**cfg.__dict__, "gen_blocks": 1, "flow_res_blocks": 1})
         w = M.make_seeded_weights(small)
         cfg2, w2 = M.deserialize(M.serialize(small, w))
-        floats = {"bn_eps": 0, "temporal_strength": 0, "temporal_threshold": 0}  # f32 in the header
+        floats = {"bn_eps": 0, "temporal_strength": 0, "temporal_threshold": 0,
+                  "flow_negative_slope": 0, "gen_negative_slope": 0}  # f32 in the header
         assert cfg2.__dict__ | floats == small.__dict__ | floats, name
         assert cfg2.bn_eps == pytest.approx(small.bn_eps)
         assert cfg2.temporal_threshold == pytest.approx(small.temporal_threshold)
@@ -29,6 +30,25 @@ def test_temporal_filter_fields_live_in_the_reserved_words():
     assert cfg2.temporal_strength == 0.25 and cfg2.temporal_threshold == pytest.approx(0.05)
     plain = M.serialize(M.ModelConfig(gen_blocks=1), M.make_seeded_weights(cfg))
     assert struct.unpack_from("<f", plain, 108) == (0.0,)      # filter off = a version-1 file as before
+
+
+def test_activation_fields_live_in_the_reserved_words():
+    """`activation` of the sub-model constructors (reference models.py:24-27, 261, 337, 489)."""
+    cfg = M.ModelConfig(gen_blocks=1, flow_activation="lrelu", gen_activation="lrelu",
+                        gen_negative_slope=0.2)
+    w = M.make_seeded_weights(cfg)
+    blob = M.serialize(cfg, w)
+    acts, fs, gs = struct.unpack_from("<Iff", blob, 116)
+    assert acts == 0x0101 and fs == pytest.approx(0.3) and gs == pytest.approx(0.2)
+    cfg2, _ = M.deserialize(blob)
+    assert (cfg2.flow_activation, cfg2.gen_activation) == ("lrelu", "lrelu")
+    assert cfg2.gen_negative_slope == pytest.approx(0.2) and cfg2.flow_negative_slope == pytest.approx(0.3)
+    mixed = M.ModelConfig(gen_blocks=1, gen_activation="lrelu")
+    assert struct.unpack_from("<Iff", M.serialize(mixed, w), 116) == (0x0100, 0.0, pytest.approx(0.3))
+    plain = M.serialize(M.ModelConfig(gen_blocks=1), w)
+    assert struct.unpack_from("<3I", plain, 116) == (0, 0, 0)   # all-ReLU = a file as before the field
+    with pytest.raises(KeyError):
+        M.serialize(M.ModelConfig(gen_blocks=1, gen_activation="gelu"), w)
 
 
 def test_header_layout_and_alignment():

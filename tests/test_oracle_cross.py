@@ -7,11 +7,16 @@ from helpers import M, O, err, oracle_config, small_config, u8_stats
 from torch_restatement import TorchSession
 
 
-@pytest.mark.parametrize("arch,pad,h,w", [("autoencoder", 8, 30, 48), ("resnet", 0, 20, 24),
-                                          ("autoencoder", 8, 17, 33)])
-def test_numpy_oracle_vs_torch_restatement(arch, pad, h, w):
+LRELU = dict(flow_activation="lrelu", gen_activation="lrelu", gen_negative_slope=0.2)
+
+
+@pytest.mark.parametrize("arch,pad,h,w,extra", [
+    ("autoencoder", 8, 30, 48, {}), ("resnet", 0, 20, 24, {}), ("autoencoder", 8, 17, 33, {}),
+    ("autoencoder", 8, 30, 48, LRELU), ("resnet", 0, 20, 24, LRELU),
+    ("autoencoder", 8, 17, 33, dict(gen_activation="lrelu"))])
+def test_numpy_oracle_vs_torch_restatement(arch, pad, h, w, extra):
     cfg = small_config(frame_height=h, frame_width=w, flow_arch=arch, flow_pad_factor=pad,
-                       flow_res_blocks=2)
+                       flow_res_blocks=2, **extra)
     wts = M.make_seeded_weights(cfg)
     s = O.Session(wts, oracle_config(cfg))
     ts = TorchSession(wts, oracle_config(cfg))
@@ -25,10 +30,11 @@ def test_numpy_oracle_vs_torch_restatement(arch, pad, h, w):
         assert (a[..., 3] == 0).all()
 
 
-@pytest.mark.parametrize("arch,pad", [("autoencoder", 8), ("resnet", 0)])
-def test_c_restatement_vs_numpy_oracle(arch, pad):
+@pytest.mark.parametrize("arch,pad,extra", [("autoencoder", 8, {}), ("resnet", 0, {}),
+                                            ("autoencoder", 8, LRELU), ("resnet", 0, LRELU)])
+def test_c_restatement_vs_numpy_oracle(arch, pad, extra):
     from oracle.c_binding import CSession
-    cfg = small_config(flow_arch=arch, flow_pad_factor=pad, flow_res_blocks=2)
+    cfg = small_config(flow_arch=arch, flow_pad_factor=pad, flow_res_blocks=2, **extra)
     wts = M.make_seeded_weights(cfg)
     s = O.Session(wts, oracle_config(cfg))
     cs = CSession(M.serialize(cfg, wts), cfg.frame_height, cfg.frame_width)
@@ -50,3 +56,17 @@ def test_x_byte_is_ignored_by_the_oracle():
     a = O.Session(wts, oracle_config(cfg)).run(f)
     b = O.Session(wts, oracle_config(cfg)).run(g)
     assert np.array_equal(a, b)
+
+
+def test_lrelu_changes_the_result_and_relu_is_the_default():
+    """The activation really is a model parameter (reference models.py:24-27, 261, 337, 489)."""
+    frames = M.synthetic_frames(2, 30, 48, kind="smooth")
+    wts = M.make_seeded_weights(small_config())
+    outs = {}
+    for key, extra in [("relu", {}), ("lrelu", LRELU), ("gen-only", dict(gen_activation="lrelu"))]:
+        cfg = small_config(**extra)
+        s = O.Session(wts, oracle_config(cfg))
+        outs[key] = [s.run(f) for f in frames][-1]
+    assert not np.array_equal(outs["relu"], outs["lrelu"])
+    assert not np.array_equal(outs["lrelu"], outs["gen-only"])
+    assert oracle_config(small_config()).gen_activation == "relu"

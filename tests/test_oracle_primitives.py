@@ -161,3 +161,16 @@ def test_temporal_filter_gate_and_weights():
     pw = gen + 0.125
     edge = O.temporal_filter(gen, pw, s, float(np.mean(np.abs(gen - pw))))
     assert np.allclose(edge, (s / 2) * pw + (1 - s / 2) * gen, atol=1e-15)
+
+
+def test_leaky_relu_known_answers():
+    """keras.layers.LeakyReLU(negative_slope) (reference models.py:24-27 "lrelu")."""
+    x = np.array([-2.0, -0.5, 0.0, 0.25, 3.0])
+    assert np.allclose(O.leaky_relu(x, 0.3), [-0.6, -0.15, 0.0, 0.25, 3.0])
+    assert np.array_equal(O.leaky_relu(x, 0.0), O.relu(x))
+    assert np.array_equal(O.leaky_relu(x, 1.0), x)
+    cfg = O.ModelConfig(gen_activation="lrelu", gen_negative_slope=0.2)
+    assert np.allclose(cfg.act("generator")(x), [-0.4, -0.1, 0.0, 0.25, 3.0])
+    assert np.array_equal(cfg.act("flow")(x), O.relu(x))          # per sub-model
+    with pytest.raises(ValueError, match="Unknown activation"):
+        O.ModelConfig(flow_activation="gelu").act("flow")

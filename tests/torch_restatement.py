@@ -36,14 +36,23 @@ def _bn(x, w, name, eps):
                         training=False, eps=eps)
 
 
-def _cba(x, w, c, b, eps):
-    return F.relu(_bn(_conv(x, w, c), w, b, eps))
+def _act(cfg, part):
+    """keras ReLU / LeakyReLU(negative_slope) (reference models.py:24-27) as torch ops."""
+    name = getattr(cfg, part + "_activation", "relu")
+    if name == "relu":
+        return F.relu
+    slope = getattr(cfg, part + "_negative_slope")
+    return lambda x: F.leaky_relu(x, negative_slope=slope)
 
 
-def _res(x, w, n, eps):
-    y = _cba(x, w, n + "/conv_1", n + "/bn_1", eps)
+def _cba(x, w, c, b, eps, act=F.relu):
+    return act(_bn(_conv(x, w, c), w, b, eps))
+
+
+def _res(x, w, n, eps, act=F.relu):
+    y = _cba(x, w, n + "/conv_1", n + "/bn_1", eps, act)
     y = _bn(_conv(y, w, n + "/conv_2"), w, n + "/bn_2", eps)
-    return F.relu(y + x)
+    return act(y + x)
 
 
 def _up_tf1(x, s):
@@ -103,21 +112,22 @@ class TorchSession:
 
     def _flow(self, frames):
         w, cfg, eps = self.w, self.cfg, self.cfg.bn_eps
+        act = _act(cfg, "flow")
         x = torch.cat(frames, dim=1)
         if cfg.flow_arch == "autoencoder":
             f = cfg.flow_filters
             nb = len(f) // 2
             for i in range(2 * nb):
                 n = f"flow/block_{i + 1}"
-                x = _cba(x, w, n + "/conv_1", n + "/bn_1", eps)
-                x = _cba(x, w, n + "/conv_2", n + "/bn_2", eps)
+                x = _cba(x, w, n + "/conv_1", n + "/bn_1", eps, act)
+                x = _cba(x, w, n + "/conv_2", n + "/bn_2", eps, act)
                 x = F.max_pool2d(x, 2) if i < nb else _up_tf1(x, 2)
             if len(f) % 2:
-                x = _cba(x, w, "flow/conv_1", "flow/bn_1", eps)
+                x = _cba(x, w, "flow/conv_1", "flow/bn_1", eps, act)
         else:
-            x = _cba(x, w, "flow/conv_1", "flow/bn_1", eps)
+            x = _cba(x, w, "flow/conv_1", "flow/bn_1", eps, act)
             for i in range(cfg.flow_res_blocks):
-                x = _res(x, w, f"flow/block_{i + 1}", eps)
+                x = _res(x, w, f"flow/block_{i + 1}", eps, act)
         x = _conv(x, w, "flow/conv_2", bias=True)
         return _d2s_dcr(x, 4)
 
@@ -133,11 +143,12 @@ class TorchSession:
         flow = flow[:, :, pt * 4:pt * 4 + 4 * h, pl * 4:pl * 4 + 4 * wd]
         pre_warp = _warp(self.pre_gen, flow)
         x = torch.cat([cur, _s2d(pre_warp, 4)], dim=1)
-        x = _cba(x, w, "generator/conv_1", "generator/bn_1", eps)
+        act = _act(cfg, "gen")
+        x = _cba(x, w, "generator/conv_1", "generator/bn_1", eps, act)
         for i in range(cfg.gen_blocks):
-            x = _res(x, w, f"generator/block_{i + 1}", eps)
+            x = _res(x, w, f"generator/block_{i + 1}", eps, act)
         k1 = _t(w["generator/conv_trans_1/kernel"]).permute(3, 2, 0, 1)
-        x = F.relu(_bn(F.conv_transpose2d(x, k1, stride=2), w, "generator/bn_2", eps))
+        x = act(_bn(F.conv_transpose2d(x, k1, stride=2), w, "generator/bn_2", eps))
         k2 = _t(w["generator/conv_trans_2/kernel"]).permute(3, 2, 0, 1)
         x = F.conv_transpose2d(x, k2, _t(w["generator/conv_trans_2/bias"]), stride=2)
         x = (torch.tanh(x) + _up_tf1(cur, 4)).clamp(-0.5, 0.5)

@@ -56,9 +56,19 @@ def main() -> int:
     built = ref_models.create_models(config.get("models", config))
     gen, flow = built[args.generator], built[args.flow]
     h, w = (int(x) for x in args.frame_size.lower().split("x"))
+    # the `activation` argument of each sub-model's config entry (models.py:261, 337, 489)
+    entries = config.get("models", config)
+
+    def activation_of(entry_name):
+        entry = entries.get(entry_name, {}) if isinstance(entries, dict) else {}
+        return keras_import.activation_fields(entry.get("activation", "relu"))
+
+    (gact, gslope), (fact, fslope) = activation_of(args.generator), activation_of(args.flow)
     base = M.ModelConfig(frame_height=h, frame_width=w, flow_pad_factor=args.flow_pad,
                          normalize_brightness=args.normalize_brightness, bn_eps=args.bn_eps,
-                         compute_dtype=M.DTYPE_F16 if args.fp16 else M.DTYPE_BF16)
+                         compute_dtype=M.DTYPE_F16 if args.fp16 else M.DTYPE_BF16,
+                         flow_activation=fact, gen_activation=gact,
+                         flow_negative_slope=fslope, gen_negative_slope=gslope)
     cfg, weights = keras_import.container_weights(keras_layers(gen), keras_layers(flow), base)
     M.save(args.output, cfg, weights)
     n = sum(v.size for v in weights.values())
