@@ -9,7 +9,7 @@ OBJ        := build/obj
 CXXFLAGS   := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wall -Wextra \
               -Wno-unused-parameter
 HIPFLAGS   := --offload-arch=$(ARCH) $(CXXFLAGS)
-SRCS_CPP   := model.cpp engine.cpp c_api.cpp core_api.cpp log.cpp
+SRCS_CPP   := model.cpp engine.cpp c_api.cpp core_api.cpp log.cpp comm.cpp
 SRCS_HIP   := conv_kernels.hip tower_kernels.hip frame_kernels.hip fp8_kernels.hip
 OBJS       := $(addprefix $(OBJ)/,$(SRCS_CPP:.cpp=.o)) $(addprefix $(OBJ)/,$(SRCS_HIP:.hip=.o))
 
@@ -29,7 +29,7 @@ $(OBJ)/%.o: $(CSRC)/%.cpp Makefile $(wildcard $(CSRC)/*.h) include/joshupscale_a
 
 $(OUT)/libJoshUpscale.so: $(OBJS)
 	@mkdir -p $(OUT)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,--exclude-libs,ALL
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,--exclude-libs,ALL -ldl
 
 harness: $(OUT)/libJoshUpscale.so tools/plugin_harness.cpp
 	g++ -O2 -std=c++17 -Iinclude tools/plugin_harness.cpp -o build/plugin_harness \

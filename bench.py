@@ -184,6 +184,7 @@ def main() -> int:
                             f"{'HBM' if args.location == 'device' else 'host memory (PCIe-inclusive)'}",
                 "weights": "seeded random-init (seed 42), reference default architecture",
                 "streams": world, "parallelism": f"replicas x{world}",
+                "model_broadcast": dict(jdist.LAST_BROADCAST),
                 "boundary": "ju_process (synchronous processImage)",
                 "submission": {"graph_replays": rt.stat("graph_replays"), "eager_runs": rt.stat("eager_runs"),
                                "cached_graphs": rt.stat("direct_graphs"),

@@ -130,6 +130,24 @@ JU_API void ju_set_log_callback(ju_log_callback callback, void *user);
 JU_API int ju_get_gl_device_index(int *out_device);
 JU_API int ju_get_gl_image(uint32_t gl_texture, int type, ju_image *out_image);
 
+/* ---- multi-GPU start-up (BASELINE.json config 4; no reference counterpart: the reference
+ * has no distributed code).  N GPUs = N independent streams, one process per GPU; the ONLY
+ * collective is the broadcast of the model container from rank 0, so that one rank reads
+ * the file.  RCCL (librccl, opened at first use) over xGMI.  The launcher carries the
+ * JU_COMM_ID_BYTES id from the rank that called ju_comm_unique_id to the others
+ * (bench.py: through torch.distributed's rendezvous). ---------------------------------- */
+typedef struct ju_comm ju_comm;
+#define JU_COMM_ID_BYTES 128
+JU_API int ju_comm_unique_id(void *id_out /* JU_COMM_ID_BYTES */);
+JU_API int ju_comm_create(const void *id, int rank, int world_size, int device_id, ju_comm **out_comm);
+/* ncclBroadcast of `size` bytes (uint8) from `root`'s buffer into every rank's buffer. */
+JU_API int ju_comm_broadcast(ju_comm *comm, void *bytes, size_t size, int root);
+/* In-place maximum over ranks of one double (the bench's max-over-ranks elapsed time). */
+JU_API int ju_comm_allreduce_max(ju_comm *comm, double *value);
+/* ncclCommCount: the number of ranks this communicator really spans. */
+JU_API int ju_comm_count(const ju_comm *comm, int *count);
+JU_API void ju_comm_destroy(ju_comm *comm);
+
 /* ---- introspection (tests and bench.py; no reference counterpart) ---------- */
 
 /* Compute dtype actually in use (JU_DTYPE_F16 / JU_DTYPE_BF16 / JU_DTYPE_FP8). */

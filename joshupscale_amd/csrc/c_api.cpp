@@ -51,6 +51,15 @@ int guarded(F &&f) {
 	}
 }
 
+}  // namespace
+
+// exception mapping for the other translation units of the C ABI (comm.cpp)
+int juGuarded(void (*fn)(void *), void *ctx) {
+	return guarded([&] { fn(ctx); });
+}
+
+namespace {
+
 ju::Frame toFrame(const ju_image *img) {
 	if (img == nullptr) throw std::invalid_argument("image is NULL");
 	if (img->location > JU_LOC_GRAPHICS_RESOURCE) {

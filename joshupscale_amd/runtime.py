@@ -96,6 +96,12 @@ def load_library() -> C.CDLL:
         "ju_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
         "ju_get_stat": (C.c_int, [C.c_void_p, C.c_char_p, P(C.c_double)]),
         "ju_version": (C.c_char_p, []),
+        "ju_comm_unique_id": (C.c_int, [C.c_void_p]),
+        "ju_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, P(C.c_void_p)]),
+        "ju_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+        "ju_comm_allreduce_max": (C.c_int, [C.c_void_p, P(C.c_double)]),
+        "ju_comm_count": (C.c_int, [C.c_void_p, P(C.c_int)]),
+        "ju_comm_destroy": (None, [C.c_void_p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -223,6 +229,57 @@ class Runtime:
         _check(self._lib, self._lib.ju_time_steps(
             self._h, tag.encode(), iters, C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """``ju_comm_unique_id``: the RCCL communicator id rank 0 hands to the other ranks."""
+    lib = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib, lib.ju_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """``ju_comm``: the C layer's RCCL communicator (one rank per GPU).  Its one job is the
+    start-up broadcast of the model container (BASELINE.json config 4)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world_size: int, device: int):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be COMM_ID_BYTES long")
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.rank, self.world_size = rank, world_size
+        _check(self._lib, self._lib.ju_comm_create(unique_id, rank, world_size, device, C.byref(self._h)))
+
+    def broadcast(self, blob: Optional[bytes], size: int, root: int = 0) -> bytes:
+        """Every rank passes ``size``; ``root`` also the bytes.  Returns the bytes."""
+        buf = C.create_string_buffer(bytes(blob), size) if self.rank == root else C.create_string_buffer(size)
+        _check(self._lib, self._lib.ju_comm_broadcast(self._h, buf, size, root))
+        return buf.raw
+
+    def allreduce_max(self, value: float) -> float:
+        v = C.c_double(value)
+        _check(self._lib, self._lib.ju_comm_allreduce_max(self._h, C.byref(v)))
+        return v.value
+
+    def count(self) -> int:
+        n = C.c_int()
+        _check(self._lib, self._lib.ju_comm_count(self._h, C.byref(n)))
+        return n.value
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.ju_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
 
 
 def host_image(arr: np.ndarray) -> JuImage:

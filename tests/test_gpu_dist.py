@@ -1,0 +1,54 @@
+"""The multi-GPU start-up path on one MI355X: the C layer's RCCL communicator with a
+single rank, in-process and through bench.py under torch.distributed.run (which is how the
+driver launches N > 1).  A scaling curve needs an N-GPU node; this pins the plumbing."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from helpers import M, ROOT
+from joshupscale_amd import runtime as R
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_rccl_communicator_single_rank():
+    uid = R.comm_unique_id()
+    assert len(uid) == R.COMM_ID_BYTES and any(uid)
+    comm = R.Comm(uid, 0, 1, 0)
+    assert comm.count() == 1                                  # ncclCommCount
+    cfg = M.ModelConfig(frame_height=30, frame_width=48, gen_blocks=1)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    assert comm.broadcast(blob, len(blob), root=0) == blob     # ncclBroadcast, uint8
+    assert comm.allreduce_max(2.5) == 2.5
+    with pytest.raises(R.JoshUpscaleError):
+        comm.broadcast(blob, len(blob), root=3)
+    comm.close()
+    with pytest.raises(R.JoshUpscaleError):
+        R.Comm(uid, 2, 1, 0)                                   # rank outside the world
+
+
+def test_bench_under_torchrun_uses_the_native_broadcast():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--preset", "psp-fast",
+           "--dtype", "fp16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 100
+    mb = res["config"]["model_broadcast"]
+    assert mb["how"].startswith("rccl") and mb["ranks_seen"] == 1 and mb["bytes"] > 1 << 20
+    assert res["config"]["submission"]["graph_replays"] > 0
+    # launched the wrong way, the bench refuses instead of measuring one GPU
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert bad.returncode != 0 and "torch.distributed.run" in (bad.stderr + bad.stdout)
