@@ -98,27 +98,30 @@ JOSHUPSCALE_EXPORT GraphicsResourceImage *getGLImage(std::uint32_t glTexture,
 // getters compiled into the CALLER.
 struct Runtime {
 	virtual ~Runtime() {}
-	virtual void processImage(const Image &lowRes, const Image &highRes) = 0;
+	virtual void processImage(const Image &inputImage, const Image &outputImage) = 0;
 
-	std::size_t getInputWidth() const { return m_Size[0]; }
-	std::size_t getInputHeight() const { return m_Size[1]; }
-	std::size_t getOutputWidth() const { return m_Size[2]; }
-	std::size_t getOutputHeight() const { return m_Size[3]; }
+	std::size_t getInputWidth() const { return m_InputWidth; }
+	std::size_t getInputHeight() const { return m_InputHeight; }
+	std::size_t getOutputWidth() const { return m_OutputWidth; }
+	std::size_t getOutputHeight() const { return m_OutputHeight; }
 
 protected:
-	// input width, input height, output width, output height (four consecutive
-	// size_t, the layout of the reference's four separate members)
-	std::size_t m_Size[4] = {0, 0, 0, 0};
+	// the reference's member names and order (core.h:84-88): they are ABI, the inline
+	// getters above are compiled into the caller
+	std::size_t m_InputWidth = 0;
+	std::size_t m_InputHeight = 0;
+	std::size_t m_OutputWidth = 0;
+	std::size_t m_OutputHeight = 0;
 };
 
 // Caller owns the result and destroys it with `delete`.  `model` names a .jupw
 // container (joshupscale_amd/model_file.py); TensorRT engines are rejected with
 // std::invalid_argument.
-JOSHUPSCALE_EXPORT Runtime *createRuntime(int device, const std::filesystem::path &model);
+JOSHUPSCALE_EXPORT Runtime *createRuntime(int deviceId, const std::filesystem::path &modelPath);
 
-// Only valid inside a catch block: formats the exception being handled as
-// "Type: what()" with nested exceptions indented (reference
-// core/src/exception.cc:51-79).
+// Only valid inside a catch block: formats the exception being handled exactly as the
+// reference does (core/src/exception.cc:51-79): "Type: what()", each nested exception
+// after "\n  ", no trailing newline, "Unknown error" for a non-std exception.
 JOSHUPSCALE_EXPORT std::string getExceptionString();
 
 }  // namespace core

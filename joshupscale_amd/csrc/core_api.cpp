@@ -49,7 +49,7 @@ struct HipRuntime final : Runtime {
 	HipRuntime(int deviceId, const std::filesystem::path &modelPath) {
 		const int rc = ju_create(deviceId, modelPath.string().c_str(), &m_Handle);
 		if (rc != JU_OK) raise(rc);
-		ju_get_size(m_Handle, &m_Size[0], &m_Size[1], &m_Size[2], &m_Size[3]);
+		ju_get_size(m_Handle, &m_InputWidth, &m_InputHeight, &m_OutputWidth, &m_OutputHeight);
 	}
 	~HipRuntime() override {
 		ju_destroy(m_Handle);
@@ -77,15 +77,28 @@ std::string demangled(const char *name) {
 	return status == 0 && p ? std::string(p.get()) : std::string(name);
 }
 
-void describe(std::ostream &os, const std::exception &e, int depth) {
-	os << std::string(static_cast<std::size_t>(depth) * 2, ' ') << demangled(typeid(e).name())
-	   << ": " << e.what() << '\n';
+// "Type: what()"; a nested exception follows after "\n  " (the same two spaces at every
+// depth, no trailing newline): the format of the reference's printException
+// (core/src/exception.cc:51-79), which callers log verbatim.
+void describeCurrent(std::ostream &os);
+
+void describe(std::ostream &os, const std::exception &e) {
+	os << demangled(typeid(e).name()) << ": " << e.what();
 	try {
 		std::rethrow_if_nested(e);
-	} catch (const std::exception &inner) {
-		describe(os, inner, depth + 1);
 	} catch (...) {
-		os << std::string(static_cast<std::size_t>(depth + 1) * 2, ' ') << "unknown exception\n";
+		os << "\n  ";
+		describeCurrent(os);
+	}
+}
+
+void describeCurrent(std::ostream &os) {
+	try {
+		throw;  // re-raise the exception currently being handled
+	} catch (const std::exception &e) {
+		describe(os, e);
+	} catch (...) {
+		os << "Unknown error";
 	}
 }
 
@@ -112,13 +125,7 @@ Runtime *createRuntime(int deviceId, const std::filesystem::path &modelPath) {
 
 std::string getExceptionString() {
 	std::ostringstream ss;
-	try {
-		throw;  // re-raise the exception currently being handled
-	} catch (const std::exception &e) {
-		describe(ss, e, 0);
-	} catch (...) {
-		ss << "unknown exception\n";
-	}
+	describeCurrent(ss);
 	return ss.str();
 }
 

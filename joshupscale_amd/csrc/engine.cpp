@@ -432,10 +432,11 @@ void Engine::buildProgram(int set) {
 	if (c.temporalStrength > 0.0f) {
 		const void *preWarp = T("pre_warp");
 		unsigned long long *acc = m_TemporalAcc.as<unsigned long long>();
-		const float strength = c.temporalStrength, threshold = c.temporalThreshold;
+		const TemporalParams tp{c.temporalStrength, c.temporalThreshold, c.temporalGain, c.temporalWindow,
+		    c.temporalL2 ? 1 : 0, c.temporalLimit ? 1 : 0, c.temporalLuma ? 1 : 0};
 		prog.push_back({"temporal", 0.0, [=](hipStream_t s) {
 			                launchTemporalFilter(stateOut, preWarp, io->out, io->outStride, H, W, sums,
-			                    acc, strength, threshold, s);
+			                    acc, tp, s);
 		                }});
 	}
 }
@@ -566,7 +567,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	addTensor("gen_in", lr * 64);
 	if (c.temporalStrength > 0.0f) {
 		addTensor("pre_warp", lr * 16 * 4);  // f16 [4H][4W][4]
-		m_TemporalAcc = DeviceBuffer(8);
+		m_TemporalAcc = DeviceBuffer(8 * temporalAccWords(H, W, c.temporalWindow));
 	}
 	addTowerTensor("trunk_a", H, W, c.genFilters);
 	addTowerTensor("trunk_b", H, W, c.genFilters);
@@ -666,20 +667,19 @@ void Engine::fallbackToLayers(unsigned code) {
 		buildProgram(s);
 	}
 	if (m_UseGraph) {
-		// One eager pass per binding set FIRST: the per-layer tower kernels have never
-		// been launched on this device, and their first launch sets the dynamic-LDS
-		// attribute (hipFuncSetAttribute) -- not something to do inside a stream capture;
-		// launch errors also surface here.  On the staging buffers: the pass writes only
-		// scratch tensors and the binding sets' OUTPUT halves, which the caller's re-run
-		// (or the next frame) overwrites.
+		// One eager pass FIRST: the per-layer tower kernels have never been launched on
+		// this device, and their first launch sets the dynamic-LDS attribute
+		// (hipFuncSetAttribute) -- not something to do inside a stream capture; launch
+		// errors also surface here.  Only the CURRENT binding set's program, on the staging
+		// buffers: it writes scratch tensors and the OUTPUT half of the state ping-pong,
+		// which the caller's re-run overwrites; the other set's program (same kernels,
+		// other pointers) would overwrite the INPUT half the re-run still needs.
 		const FrameIO keep = m_IO;
 		m_IO.in = m_InStage.as<std::uint8_t>();
 		m_IO.inStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 4;
 		m_IO.out = m_OutStage.as<std::uint8_t>();
 		m_IO.outStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 16;
-		for (int s = 0; s < 2; ++s) {
-			for (const Step &st : m_Program[s]) st.run(m_Stream);
-		}
+		for (const Step &st : m_Program[m_Idx]) st.run(m_Stream);
 		m_Stream.synchronize();
 		for (int s = 0; s < 2; ++s) {
 			m_Graph[s] = GraphExec::capture(m_Stream, [&] {

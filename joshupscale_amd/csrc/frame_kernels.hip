@@ -269,48 +269,125 @@ __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ 
 // generator output written by the tail already is the result).
 constexpr double kTemporalScale = 4294967296.0;  // 2^32
 
+struct TemporalGeom {
+	int HH, WW;          // HR frame
+	int window;          // 0: global
+	int GH, GW;          // gate grid (1 x 1 when global)
+	int padY, padX;      // leading zero padding of the windowed mean (:208-215)
+	float strength, threshold, gain;
+	int l2, limit, luma;
+	int lrPixels;
+};
+
+// one element's contribution to the gate statistic (:157-187, 219-222)
+__device__ __forceinline__ float temporalTerm(float gen, float pw, int ch, const TemporalGeom &g) {
+	if (g.limit) pw = fmaxf(fminf(pw, 0.5f), -0.5f);
+	float d = gen - pw;
+	d = g.l2 ? d * d : fabsf(d);
+	if (g.luma) {
+		const float k = (ch == 0 ? 0.1140f : (ch == 1 ? 0.5870f : 0.2989f)) * 3.0f;  // LUMA_NORM (:95-96)
+		d *= g.l2 ? k * k : k;
+	}
+	return d;
+}
+
 __global__ __launch_bounds__(256) void temporal_reduce_kernel(const f16 *__restrict__ state,
-    const f16 *__restrict__ preWarp, size_t nPix, int lrPixels, const unsigned *__restrict__ sums,
+    const f16 *__restrict__ preWarp, TemporalGeom g, const unsigned *__restrict__ sums,
     unsigned long long *__restrict__ acc) {
-	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(lrPixels));
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(g.lrPixels));
+	const size_t nPix = (size_t)g.HH * g.WW;
+	if (g.window == 0) {
+		float s = 0.f;
+		for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nPix; i += (size_t)gridDim.x * 256) {
+			const Vec4<f16> gv = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
+			const Vec4<f16> q = *reinterpret_cast<const Vec4<f16> *>(preWarp + i * 4);
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				s += temporalTerm(static_cast<float>(gv[c]) + bright, static_cast<float>(q[c]), c, g);
+			}
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+		if ((threadIdx.x & 63) == 0) {
+			atomicAdd(acc, static_cast<unsigned long long>(static_cast<double>(s) * kTemporalScale + 0.5));
+		}
+		return;
+	}
+	// windowed: one thread per HR pixel; integer (fixed-point) atomics per window, so the
+	// sums do not depend on the order.  A wave whose 64 pixels fall into one window
+	// (the common case: rows are contiguous) reduces first and issues one atomic.
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	float s = 0.f;
-	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nPix; i += (size_t)gridDim.x * 256) {
-		const Vec4<f16> g = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
+	int widx = -1;
+	if (i < nPix) {
+		const int y = static_cast<int>(i / g.WW), x = static_cast<int>(i - (size_t)y * g.WW);
+		widx = ((y + g.padY) / g.window) * g.GW + (x + g.padX) / g.window;
+		const Vec4<f16> gv = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
 		const Vec4<f16> q = *reinterpret_cast<const Vec4<f16> *>(preWarp + i * 4);
 #pragma unroll
 		for (int c = 0; c < 3; ++c) {
-			s += fabsf(static_cast<float>(g[c]) + bright - static_cast<float>(q[c]));
+			s += temporalTerm(static_cast<float>(gv[c]) + bright, static_cast<float>(q[c]), c, g);
 		}
 	}
+	unsigned long long fx = static_cast<unsigned long long>(static_cast<double>(s) * kTemporalScale + 0.5);
+	const int first = __shfl(widx, 0);
+	if (__all(widx == first)) {
 #pragma unroll
-	for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-	if ((threadIdx.x & 63) == 0) {
-		atomicAdd(acc, static_cast<unsigned long long>(static_cast<double>(s) * kTemporalScale + 0.5));
+		for (int off = 32; off > 0; off >>= 1) fx += __shfl_xor(fx, off);
+		if ((threadIdx.x & 63) == 0 && first >= 0) atomicAdd(acc + first, fx);
+	} else if (widx >= 0) {
+		atomicAdd(acc + widx, fx);
 	}
+}
+
+// gate value of one grid cell: sign(m - t) or tanh(gain * (m - t)) (:223-238)
+__device__ __forceinline__ float temporalGate(const unsigned long long *acc, int cell, double denom,
+    const TemporalGeom &g) {
+	const double mean = static_cast<double>(acc[cell]) / kTemporalScale / denom;
+	const double d = mean - static_cast<double>(g.threshold);
+	if (g.gain == 0.0f) return d > 0.0 ? 1.0f : (d < 0.0 ? -1.0f : 0.0f);
+	return tanhf(static_cast<float>(d) * g.gain);
 }
 
 __global__ __launch_bounds__(256) void temporal_blend_kernel(f16 *__restrict__ state,
     const f16 *__restrict__ preWarp, std::uint8_t *__restrict__ outU8, std::ptrdiff_t outStride,
-    int HH, int WW, int lrPixels, const unsigned *__restrict__ sums,
-    const unsigned long long *__restrict__ acc, float strength, float threshold) {
-	const double mean = static_cast<double>(*acc) / kTemporalScale / (3.0 * HH * WW);
-	const double d = mean - static_cast<double>(threshold);
-	const float c = d > 0.0 ? 1.0f : (d < 0.0 ? -1.0f : 0.0f);  // Sign (:229-232)
-	if (c > 0.0f) return;                                        // scene cut: out = gen
-	const float half = 0.5f * strength;
+    TemporalGeom g, const unsigned *__restrict__ sums, const unsigned long long *__restrict__ acc) {
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= (size_t)g.HH * g.WW) return;
+	const int y = static_cast<int>(i / g.WW), x = static_cast<int>(i - (size_t)y * g.WW);
+	float c;
+	if (g.window == 0) {
+		c = temporalGate(acc, 0, 3.0 * g.HH * g.WW, g);
+		// hard gate, scene cut: out = gen exactly, which the tail already wrote (with
+		// --limit too: the weight of pre_warp is 0)
+		if (g.gain == 0.0f && c > 0.0f) return;
+	} else {
+		// Resize(linear, asymmetric) of the gate grid by `window`, then the un-pad slice
+		// (:239-270): src = dst / window, lo = floor, hi = min(lo + 1, n - 1)
+		const double denom = 3.0 * g.window * g.window;
+		const float sy = static_cast<float>(y + g.padY) / static_cast<float>(g.window);
+		const float sx = static_cast<float>(x + g.padX) / static_cast<float>(g.window);
+		const int y0 = static_cast<int>(sy), x0 = static_cast<int>(sx);
+		const int y1 = min(y0 + 1, g.GH - 1), x1 = min(x0 + 1, g.GW - 1);
+		const float fy = sy - static_cast<float>(y0), fx = sx - static_cast<float>(x0);
+		const float c00 = temporalGate(acc, y0 * g.GW + x0, denom, g), c01 = temporalGate(acc, y0 * g.GW + x1, denom, g);
+		const float c10 = temporalGate(acc, y1 * g.GW + x0, denom, g), c11 = temporalGate(acc, y1 * g.GW + x1, denom, g);
+		const float top = c00 + (c01 - c00) * fx, bot = c10 + (c11 - c10) * fx;
+		c = top + (bot - top) * fy;
+	}
+	const float half = 0.5f * g.strength;
 	const float m1 = half - c * half;         // weight of pre_warp (:272-279)
 	const float m2 = c * half + 1.0f - half;  // weight of the generator output (:280-285)
-	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(lrPixels));
-	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-	if (i >= (size_t)HH * WW) return;
-	const int y = static_cast<int>(i / WW), x = static_cast<int>(i - (size_t)y * WW);
-	const Vec4<f16> g = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
+	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(g.lrPixels));
+	const Vec4<f16> gv = *reinterpret_cast<const Vec4<f16> *>(state + i * 4);
 	const Vec4<f16> q = *reinterpret_cast<const Vec4<f16> *>(preWarp + i * 4);
 	Vec4<f16> st;
 	unsigned packed = 0;
 #pragma unroll
 	for (int ch = 0; ch < 3; ++ch) {
-		const float r = static_cast<float>(q[ch]) * m1 + (static_cast<float>(g[ch]) + bright) * m2;
+		float pw = static_cast<float>(q[ch]);
+		if (g.limit) pw = fmaxf(fminf(pw, 0.5f), -0.5f);
+		const float r = pw * m1 + (static_cast<float>(gv[ch]) + bright) * m2;
 		st[ch] = static_cast<f16>(r - bright);
 		const unsigned u = static_cast<unsigned>((r + 0.5f) * 255.0f);  // postprocess, truncating
 		packed |= (u & 0xff) << (8 * ch);
@@ -604,19 +681,47 @@ void launchWarpPack(DType dt, const void *state, const float *flow, const std::u
 	hipCheckLaunch("warp_pack");
 }
 
+namespace {
+TemporalGeom temporalGeom(int H, int W, const TemporalParams &tp) {
+	TemporalGeom g{};
+	g.HH = 4 * H;
+	g.WW = 4 * W;
+	g.window = tp.window;
+	g.GH = g.GW = 1;
+	if (tp.window > 0) {
+		g.GH = (g.HH + tp.window - 1) / tp.window;
+		g.GW = (g.WW + tp.window - 1) / tp.window;
+		g.padY = (g.GH * tp.window - g.HH) / 2;
+		g.padX = (g.GW * tp.window - g.WW) / 2;
+	}
+	g.strength = tp.strength;
+	g.threshold = tp.threshold;
+	g.gain = tp.gain;
+	g.l2 = tp.l2;
+	g.limit = tp.limit;
+	g.luma = tp.luma;
+	g.lrPixels = H * W;
+	return g;
+}
+}  // namespace
+
+std::size_t temporalAccWords(int H, int W, int window) {
+	if (window <= 0) return 1;
+	return static_cast<std::size_t>((4 * H + window - 1) / window) * ((4 * W + window - 1) / window);
+}
+
 void launchTemporalFilter(void *state, const void *preWarp, std::uint8_t *outU8,
     std::ptrdiff_t outStride, int H, int W, const unsigned *sums, unsigned long long *acc,
-    float strength, float threshold, hipStream_t stream) {
-	const int HH = 4 * H, WW = 4 * W;
-	const size_t nPix = (size_t)HH * WW;
-	hipError_t e = hipMemsetAsync(acc, 0, sizeof(unsigned long long), stream);
+    const TemporalParams &tp, hipStream_t stream) {
+	const TemporalGeom g = temporalGeom(H, W, tp);
+	const size_t nPix = (size_t)g.HH * g.WW;
+	hipError_t e = hipMemsetAsync(acc, 0, sizeof(unsigned long long) * g.GH * g.GW, stream);
 	if (e != hipSuccess) throw std::runtime_error(std::string("hipMemsetAsync: ") + hipGetErrorString(e));
-	hipLaunchKernelGGL(temporal_reduce_kernel, dim3(2048), dim3(256), 0, stream,
-	    static_cast<const f16 *>(state), static_cast<const f16 *>(preWarp), nPix, H * W, sums, acc);
+	hipLaunchKernelGGL(temporal_reduce_kernel, dim3(tp.window > 0 ? blocksFor(nPix) : 2048), dim3(256), 0,
+	    stream, static_cast<const f16 *>(state), static_cast<const f16 *>(preWarp), g, sums, acc);
 	hipCheckLaunch("temporal_reduce");
 	hipLaunchKernelGGL(temporal_blend_kernel, dim3(blocksFor(nPix)), dim3(256), 0, stream,
-	    static_cast<f16 *>(state), static_cast<const f16 *>(preWarp), outU8, outStride, HH, WW,
-	    H * W, sums, acc, strength, threshold);
+	    static_cast<f16 *>(state), static_cast<const f16 *>(preWarp), outU8, outStride, g, sums, acc);
 	hipCheckLaunch("temporal_blend");
 }
 

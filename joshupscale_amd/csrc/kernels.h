@@ -216,13 +216,21 @@ void launchWarpPack(DType dt, const void *state, const float *flow,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *out, int H, int W, int PW,
     int padTop, int padLeft, const unsigned *sums, void *preWarpOut, hipStream_t stream);
 
-// Temporal moving-average output filter with the global scene-cut gate of
-// scripts/inference/onnx/frame_moving_avg.py:146-302 (default mode).  state: the new
-// HR state written by the tail (f16 [4H][4W][4], generator output minus brightness),
-// rewritten in place together with the u8 frame; acc: 8 bytes of scratch.
+// Temporal moving-average output filter with the scene-cut gate of
+// scripts/inference/onnx/frame_moving_avg.py:146-302, every mode of that script: global or
+// windowed gate (window in HR pixels), sign or tanh(gain * .) gate, L1 / L2 norm, limited
+// pre_warp, luma weighting.  state: the new HR state written by the tail (f16 [4H][4W][4],
+// generator output minus brightness), rewritten in place together with the u8 frame;
+// acc: temporalAccWords(...) 64-bit words of scratch (one 32.32 fixed-point sum per window).
+struct TemporalParams {
+	float strength, threshold, gain;
+	int window;   // 0 = one global mean
+	int l2, limit, luma;
+};
+std::size_t temporalAccWords(int H, int W, int window);
 void launchTemporalFilter(void *state, const void *preWarp, std::uint8_t *outU8,
     std::ptrdiff_t outStride, int H, int W, const unsigned *sums, unsigned long long *acc,
-    float strength, float threshold, hipStream_t stream);
+    const TemporalParams &tp, hipStream_t stream);
 
 // ---- generator tail ---------------------------------------------------------
 // y     : [H][W][128] 16-bit = relu(BN(convT1)) with channel (a*2+b)*32 + o

@@ -71,6 +71,15 @@ ModelFile::ModelFile(const void *blob, std::size_t size) {
 		c.flowNegativeSlope = readLE<float>(b + 120);
 		c.genNegativeSlope = readLE<float>(b + 124);
 	}
+	if (headerBytes >= 160) {  // extended temporal-filter fields (model_file.py)
+		c.temporalWindow = u32(128);
+		c.temporalGain = readLE<float>(b + 132);
+		const auto flags = readLE<std::uint32_t>(b + 136);
+		if (flags >> 3) throw std::invalid_argument("Invalid model: unknown temporal filter flags");
+		c.temporalL2 = (flags & 1u) != 0;
+		c.temporalLimit = (flags & 2u) != 0;
+		c.temporalLuma = (flags & 4u) != 0;
+	}
 	if (scale != 4) throw std::invalid_argument("Invalid model: scale must be 4");
 	if (nTensors < 0 || headerBytes + static_cast<std::size_t>(nTensors) * kEntryBytes > size) {
 		throw std::invalid_argument("Invalid model: truncated tensor table");
@@ -128,6 +137,8 @@ void validateConfig(const ModelConfig &c) {
 	    !(c.temporalThreshold >= 0.0f && c.temporalThreshold <= 1.0f)) {
 		bad("temporal filter strength/threshold must be in [0, 1]");
 	}
+	if (c.temporalWindow < 0 || c.temporalWindow > 4096) bad("temporal filter window must be in 0..4096");
+	if (!(c.temporalGain >= 0.0f && c.temporalGain <= 1e6f)) bad("temporal filter gain must be in [0, 1e6]");
 	// ACTIVATIONS = {relu, lrelu} (models.py:24-27).  The slope must keep the activation
 	// monotonic (the flow encoder pools AFTER it in the reference and before it here).
 	auto checkAct = [&](int act, float slope, const char *what) {

@@ -32,6 +32,11 @@ struct ModelConfig {
 	// temporal moving-average output filter (frame_moving_avg.py); strength 0 = off
 	float temporalStrength = 0.0f;
 	float temporalThreshold = 0.1f;
+	// its other switches (frame_moving_avg.py:99-110): --window (HR pixels, 0 = global gate),
+	// --gain (0 = sign gate), --norm L2, --limit, --luma-normalize
+	int temporalWindow = 0;
+	float temporalGain = 0.0f;
+	bool temporalL2 = false, temporalLimit = false, temporalLuma = false;
 	// `activation` of the sub-model constructors (reference models.py:24-27, 261, 337, 489):
 	// 0 = relu, 1 = lrelu (keras LeakyReLU(negative_slope))
 	int flowActivation = 0, genActivation = 0;

@@ -29,6 +29,11 @@ Layout (all little endian):
     116 u32      activations: bits 0-7 flow net, bits 8-15 generator (0 relu, 1 lrelu)
     120 f32      flow negative_slope, generator negative_slope (read only for lrelu)
                                                     -> header_bytes = 128
+    -- only when the temporal filter uses a non-default mode, header_bytes = 160: --
+    128 u32      temporal_window (HR pixels, 0 = global gate)
+    132 f32      temporal_gain (0 = sign gate, else tanh(gain * (m - t)))
+    136 u32      temporal flags: bit 0 L2 norm, bit 1 limit pre_warp, bit 2 luma weighting
+    140 u32      reserved[5]
     table: n_tensors x { char name[92]; u32 ndim; u32 dims[4]; u64 offset;
                          u64 count }                (128 bytes each)
     data:  float32, each tensor 64-byte aligned, offsets from file start
@@ -88,6 +93,19 @@ class ModelConfig:
     gen_activation: str = "relu"
     flow_negative_slope: float = DEFAULT_NEGATIVE_SLOPE
     gen_negative_slope: float = DEFAULT_NEGATIVE_SLOPE
+    # the other switches of frame_moving_avg.py (:99-110): --window, --gain, --norm,
+    # --limit, --luma-normalize (defaults = that script's defaults)
+    temporal_window: int = 0
+    temporal_gain: float = 0.0
+    temporal_norm: str = "L1"
+    temporal_limit: bool = False
+    temporal_luma: bool = False
+
+    @property
+    def temporal_extended(self) -> bool:
+        return self.temporal_strength > 0 and (
+            self.temporal_window != 0 or self.temporal_gain != 0.0 or self.temporal_norm != "L1"
+            or self.temporal_limit or self.temporal_luma)
 
     @property
     def padded_height(self) -> int:
@@ -200,8 +218,14 @@ def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray]) -> bytes:
     if len(cfg.flow_filters) > 8:
         raise ValueError("at most 8 flow filters")
     acts = ACTIVATION[cfg.flow_activation] | ACTIVATION[cfg.gen_activation] << 8
+    ext = b""
+    if cfg.temporal_extended:
+        flags = ({"L1": 0, "L2": 1}[cfg.temporal_norm] | int(cfg.temporal_limit) << 1
+                 | int(cfg.temporal_luma) << 2)
+        ext = struct.pack("<IfI5I", cfg.temporal_window, cfg.temporal_gain, flags, 0, 0, 0, 0, 0)
+    header_bytes = HEADER_BYTES + len(ext)
     hdr = MAGIC + struct.pack(
-        "<2I4I4I4I8IfIIffIff", VERSION, HEADER_BYTES,
+        "<2I4I4I4I8IfIIffIff", VERSION, header_bytes,
         cfg.frame_height, cfg.frame_width, 4, cfg.num_flow_inputs,
         FLOW_ARCH[cfg.flow_arch], cfg.flow_pad_factor,
         int(cfg.normalize_brightness), cfg.gen_filters,
@@ -214,7 +238,8 @@ def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray]) -> bytes:
         acts, cfg.flow_negative_slope if cfg.flow_activation == "lrelu" else 0.0,
         cfg.gen_negative_slope if cfg.gen_activation == "lrelu" else 0.0)
     assert len(hdr) == HEADER_BYTES, len(hdr)
-    off = HEADER_BYTES + ENTRY_BYTES * len(names)
+    hdr += ext
+    off = header_bytes + ENTRY_BYTES * len(names)
     off = (off + 63) // 64 * 64
     table = b""
     blobs = []
@@ -227,8 +252,8 @@ def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray]) -> bytes:
         blobs.append((off, a.tobytes()))
         off = (off + a.nbytes + 63) // 64 * 64
     out = bytearray(off)
-    out[:HEADER_BYTES] = hdr
-    out[HEADER_BYTES:HEADER_BYTES + len(table)] = table
+    out[:header_bytes] = hdr
+    out[header_bytes:header_bytes + len(table)] = table
     for o, b in blobs:
         out[o:o + len(b)] = b
     return bytes(out)
@@ -253,6 +278,11 @@ def deserialize(blob: bytes) -> Tuple[ModelConfig, Dict[str, np.ndarray]]:
                       tt if ts > 0 else ModelConfig.temporal_threshold, fact, gact,
                       fslope if fact == "lrelu" else DEFAULT_NEGATIVE_SLOPE,
                       gslope if gact == "lrelu" else DEFAULT_NEGATIVE_SLOPE)
+    if header_bytes >= 160:
+        win, gain, flags = struct.unpack_from("<IfI", blob, 128)
+        cfg.temporal_window, cfg.temporal_gain = win, gain
+        cfg.temporal_norm = "L2" if flags & 1 else "L1"
+        cfg.temporal_limit, cfg.temporal_luma = bool(flags & 2), bool(flags & 4)
     w = {}
     for i in range(nt):
         name, ndim, d0, d1, d2, d3, off, cnt = struct.unpack_from(

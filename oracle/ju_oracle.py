@@ -65,6 +65,14 @@ class ModelConfig:
     # script: window 0, gain 0, L1, no limit, no luma weighting); strength 0 = absent
     temporal_strength: float = 0.0
     temporal_threshold: float = 0.1
+    # the script's other switches (frame_moving_avg.py:99-110): --window (scene detection
+    # window in HR pixels, 0 = one global mean), --gain (0 = hard sign gate, else
+    # tanh(gain * (m - t))), --norm L1|L2, --limit (clip pre_warp to +-0.5), --luma-normalize
+    temporal_window: int = 0
+    temporal_gain: float = 0.0
+    temporal_norm: str = "L1"
+    temporal_limit: bool = False
+    temporal_luma: bool = False
     # BASELINE.json config 5: the 64->64 block convolutions of the generator on 8-bit
     # (OCP e4m3) operands.  Not a reference feature as such -- the reference's 8-bit
     # deployment is TensorRT INT8 (scripts/inference/tensorrt/quantize_int8.py) -- so
@@ -468,23 +476,56 @@ class StepOutputs:
 
 
 def temporal_filter(gen: np.ndarray, pre_warp: np.ndarray, strength: float,
-                    threshold: float) -> np.ndarray:
-    """Moving-average output filter with a global scene-cut gate: the graph that
+                    threshold: float, window: int = 0, gain: float = 0.0, norm: str = "L1",
+                    limit: bool = False, luma: bool = False,
+                    trace: Optional[dict] = None) -> np.ndarray:
+    """Moving-average output filter with a scene-cut gate: the graph that
     scripts/inference/onnx/frame_moving_avg.py:146-302 splices in place of the
     generator's clip output (its consumers -- postprocess AND the fed-back
-    ``output_raw`` -- see the filtered tensor), in that script's default mode
-    (``--window 0 --gain 0 --norm L1``, :163-206, :229-236, :272-296):
+    ``output_raw`` -- see the filtered tensor).  ``gen`` / ``pre_warp`` are HR ``[H, W, 3]``.
 
-        m     = mean(|gen - pre_warp|)                 over every element
-        c     = sign(m - threshold)                    -1 still scene, +1 scene cut
-        out   = pre_warp * (s/2 - c*s/2) + gen * (c*s/2 + 1 - s/2)
+        p     = clip(pre_warp, -0.5, 0.5) if limit else pre_warp            (:157-166)
+        d     = |gen - p| (L1) or (gen - p)^2 (L2)                           (:170-181)
+        d    *= BGR_LUMA*3 (once for L1, twice for L2) if luma               (:95-96, 184-187, 219-222)
+        window == 0:  m = mean(d) over every element, one scalar            (:183-205)
+        window  > 0:  m = per window x window block mean over the 3 channels of the
+                      zero-padded frame (padding split (x-y)//2 leading; divisor always
+                      3*window^2), a [ceil(H/window), ceil(W/window)] grid  (:207-228)
+        c     = sign(m - threshold) if gain == 0 else tanh(gain * (m - threshold))   (:229-238)
+        window > 0:   c is resized back by `window` with asymmetric linear interpolation
+                      (ONNX Resize linear/asymmetric == TF1 bilinear) and un-padded  (:239-270)
+        out   = p * (s/2 - c*s/2) + gen * (c*s/2 + 1 - s/2)                 (:272-296)
 
     so a still scene blends ``s`` of the warped previous output into the new frame
     and a scene cut passes the generator output through."""
-    m = np.mean(np.abs(gen - pre_warp))
-    c = np.sign(m - threshold)
+    p = np.clip(pre_warp, -0.5, 0.5) if limit else pre_warp
+    d = gen - p
+    d = np.abs(d) if norm == "L1" else d * d
+    if norm not in ("L1", "L2"):
+        raise ValueError(f"Unknown norm type {norm}")
+    if luma:
+        k = BGR_LUMA.astype(gen.dtype) * 3
+        d = d * (k if norm == "L1" else k * k)
+    gain_coef = 1.0 if gain == 0 else gain
+    if window == 0:
+        m = np.mean(d)
+        _rec(trace, "temporal_mean", m)
+        z = gain_coef * (m - threshold)
+        c = np.sign(z) if gain == 0 else np.tanh(z)
+    else:
+        h, w, _ = d.shape
+        oh, ow = (h + window - 1) // window * window, (w + window - 1) // window * window
+        py, px = (oh - h) // 2, (ow - w) // 2
+        padded = np.zeros((oh, ow, 3), d.dtype)
+        padded[py:py + h, px:px + w] = d
+        m = padded.reshape(oh // window, window, ow // window, window, 3).sum(axis=(1, 3, 4)) \
+            / (3.0 * window * window)
+        _rec(trace, "temporal_mean", m)
+        z = gain_coef * (m - threshold)
+        cg = np.sign(z) if gain == 0 else np.tanh(z)
+        c = resize_bilinear_tf1(cg[..., None], window)[py:py + h, px:px + w]
     half = strength / 2
-    return pre_warp * (half - c * half) + gen * (c * half + 1 - half)
+    return p * (half - c * half) + gen * (c * half + 1 - half)
 
 
 def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
@@ -523,9 +564,10 @@ def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
     _rec(trace, "flow_in", np.concatenate(frames, axis=2))
     output_raw = generator(cur, pre_warp, wts, cfg, trace)        # :804
     if cfg.temporal_strength > 0:
-        _rec(trace, "temporal_mean", np.mean(np.abs(output_raw - pre_warp)))
         output_raw = temporal_filter(output_raw, pre_warp, cfg.temporal_strength,
-                                     cfg.temporal_threshold)
+                                     cfg.temporal_threshold, cfg.temporal_window,
+                                     cfg.temporal_gain, cfg.temporal_norm, cfg.temporal_limit,
+                                     cfg.temporal_luma, trace)
     output = postprocess(output_raw)                              # :805-807
     if cfg.normalize_brightness:
         output_raw = output_raw - brightness                      # :809-810

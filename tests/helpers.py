@@ -27,6 +27,9 @@ def oracle_config(cfg: M.ModelConfig, fp8_tower: bool = False) -> O.ModelConfig:
         temporal_strength=float(np.float32(cfg.temporal_strength)),
         temporal_threshold=float(np.float32(cfg.temporal_threshold)),
         fp8_tower=fp8_tower,
+        temporal_window=cfg.temporal_window, temporal_gain=float(np.float32(cfg.temporal_gain)),
+        temporal_norm=cfg.temporal_norm, temporal_limit=cfg.temporal_limit,
+        temporal_luma=cfg.temporal_luma,
         flow_activation=cfg.flow_activation, gen_activation=cfg.gen_activation,
         flow_negative_slope=float(np.float32(cfg.flow_negative_slope)),
         gen_negative_slope=float(np.float32(cfg.gen_negative_slope)))

@@ -371,6 +371,95 @@ def test_temporal_filter_variant(dtype):
     rt.close()
 
 
+TEMPORAL_MODES = [
+    dict(temporal_window=16),                                        # windowed sign gate
+    dict(temporal_window=16, temporal_gain=40.0),                    # windowed tanh gate
+    dict(temporal_gain=25.0),                                        # global tanh gate
+    dict(temporal_norm="L2", temporal_luma=True),                    # global, L2, luma-weighted
+    dict(temporal_window=24, temporal_gain=30.0, temporal_norm="L2", temporal_limit=True,
+         temporal_luma=True),                                        # everything at once (ragged windows)
+    dict(temporal_limit=True),
+]
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
+@pytest.mark.parametrize("mode", TEMPORAL_MODES, ids=lambda m: "-".join(f"{k[9:]}{v}" for k, v in m.items()))
+def test_temporal_filter_modes(mode, dtype):
+    """The other switches of scripts/inference/onnx/frame_moving_avg.py:99-110, 157-270:
+    --window (per-block gate, resized back with asymmetric linear interpolation), --gain
+    (tanh gate), --norm L2, --limit, --luma-normalize.  Still / cut / still clip; the
+    threshold is put into the widest gap of the gate statistics the oracle sees, so that a
+    hard (sign) gate decides the same way on both sides."""
+    a = M.synthetic_frames(1, 30, 48, seed=21, kind="smooth")
+    b = M.synthetic_frames(1, 30, 48, seed=22, kind="noise")
+    frames = np.concatenate([a, a, a, b, b, b])
+    base = dict(temporal_strength=0.5, **mode)
+    wts = M.make_seeded_weights(small_config(**base))
+    probe = O.Session(wts, oracle_config(small_config(temporal_threshold=1.0, **base)))   # never cuts
+    stats = []
+    for f in frames:
+        tr = {}
+        probe.run(f, trace=tr)
+        stats.append(np.asarray(tr["temporal_mean"], np.float64).ravel())
+    allm = np.sort(np.concatenate(stats))
+    lo, hi = int(0.2 * len(allm)), max(int(0.8 * len(allm)), int(0.2 * len(allm)) + 2)
+    gaps = allm[lo + 1:hi] - allm[lo:hi - 1]
+    k = lo + int(np.argmax(gaps))
+    thr = float(np.float32(0.5 * (allm[k] + allm[k + 1])))
+    assert 0.0 < thr < 1.0
+    if not mode.get("temporal_gain"):
+        assert allm[k + 1] - allm[k] > 0.02 * thr, "no clear gap for a hard gate"
+    cfg = small_config(temporal_threshold=thr, **base)
+    _, blob, rt = make(cfg, dtype)
+    sess = O.Session(wts, oracle_config(cfg))
+    plain = O.Session(wts, oracle_config(small_config()))
+    default_mode = O.Session(wts, oracle_config(small_config(temporal_strength=0.5, temporal_threshold=thr)))
+    differs = differs_default = False
+    for t, f in enumerate(frames):
+        ref = sess.run(f)
+        out = rt.process_image(f)
+        check_u8(out, ref, dtype, ("temporal-mode", sorted(mode), t))
+        state = rt.read_tensor("state").reshape(120, 192, 4)[..., :3]
+        assert err(state, sess.state.pre_gen)["max_abs"] <= TOL[dtype]["raw"]
+        differs |= not np.array_equal(ref, plain.run(f))
+        differs_default |= not np.array_equal(ref, default_mode.run(f))
+    assert differs, "the filter must change the result"
+    assert differs_default or mode == dict(temporal_limit=True), "the mode must differ from the default mode"
+    rt.close()
+
+
+def test_keras_import_runs_through_the_engine():
+    """SURVEY 8f rank 1, end to end: Keras-ordered layer dictionaries (what
+    tools/export_jupw_from_keras.py collects with layer.get_weights()) -> container_weights
+    -> .jupw bytes -> ju_create_from_memory -> frames.  The imported model must produce the
+    frames of the same weights written directly, and match the oracle; an lrelu generator
+    (its activation travels in `base`) takes the per-layer path."""
+    from joshupscale_amd import keras_import as K
+    cfg = small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2, frame_height=34,
+                       frame_width=50, gen_activation="lrelu", gen_negative_slope=0.2)
+    wts = M.make_seeded_weights(cfg, seed=9)
+    gen_layers, flow_layers = K.layers_from_container(wts)
+    # a Keras model lists layers in creation order, not sorted: shuffle to be sure nothing depends on it
+    rng = np.random.default_rng(0)
+    gen_layers = {k: gen_layers[k] for k in rng.permutation(sorted(gen_layers))}
+    flow_layers = {k: flow_layers[k] for k in rng.permutation(sorted(flow_layers))}
+    act, slope = K.activation_fields({"name": "lrelu", "negative_slope": 0.2})
+    base = M.ModelConfig(frame_height=34, frame_width=50, flow_pad_factor=0, gen_activation=act,
+                         gen_negative_slope=slope)
+    cfg2, wts2 = K.container_weights(gen_layers, flow_layers, base)
+    assert cfg2 == cfg
+    rt = R.Runtime(M.serialize(cfg2, wts2), 0, R.DTYPE_F16)
+    direct = R.Runtime(M.serialize(cfg, wts), 0, R.DTYPE_F16)
+    assert rt.stat("resident_tower") == 0
+    sess = O.Session(wts, oracle_config(cfg))
+    for t, f in enumerate(M.synthetic_frames(3, 34, 50, seed=19, kind="smooth")):
+        out = rt.process_image(f)
+        assert np.array_equal(out, direct.process_image(f))
+        check_u8(out, sess.run(f), R.DTYPE_F16, ("keras-import", t))
+    rt.close()
+    direct.close()
+
+
 def test_long_sequence_does_not_drift():
     """The engine is recurrent: 16-bit rounding of the state could accumulate.  48
     frames of a moving scene against the float64 oracle: the error of the last

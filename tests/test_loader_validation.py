@@ -31,6 +31,8 @@ def test_accepts_every_preset_and_variant(hip_library):
     for cfg in [CFG, small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2),
                 small_config(normalize_brightness=True), small_config(temporal_strength=0.25),
                 small_config(flow_activation="lrelu", gen_activation="lrelu", gen_negative_slope=0.2),
+                small_config(temporal_strength=0.5, temporal_window=16, temporal_gain=4.0, temporal_norm="L2",
+                             temporal_limit=True, temporal_luma=True),
                 M.ModelConfig(gen_blocks=1), M.ModelConfig(frame_height=448, frame_width=640, gen_blocks=1)]:
         R.validate_model(M.serialize(cfg, M.make_seeded_weights(cfg)))
 

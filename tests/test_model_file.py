@@ -13,7 +13,7 @@ def test_roundtrip_all_presets():
         small = M.ModelConfig(**{**cfg.__dict__, "gen_blocks": 1, "flow_res_blocks": 1})
         w = M.make_seeded_weights(small)
         cfg2, w2 = M.deserialize(M.serialize(small, w))
-        floats = {"bn_eps": 0, "temporal_strength": 0, "temporal_threshold": 0,
+        floats = {"bn_eps": 0, "temporal_strength": 0, "temporal_threshold": 0, "temporal_gain": 0,
                   "flow_negative_slope": 0, "gen_negative_slope": 0}  # f32 in the header
         assert cfg2.__dict__ | floats == small.__dict__ | floats, name
         assert cfg2.bn_eps == pytest.approx(small.bn_eps)
@@ -49,6 +49,25 @@ def test_activation_fields_live_in_the_reserved_words():
     assert struct.unpack_from("<3I", plain, 116) == (0, 0, 0)   # all-ReLU = a file as before the field
     with pytest.raises(KeyError):
         M.serialize(M.ModelConfig(gen_blocks=1, gen_activation="gelu"), w)
+
+
+def test_extended_temporal_fields_grow_the_header():
+    """--window / --gain / --norm / --limit / --luma-normalize of frame_moving_avg.py: only a
+    non-default mode makes the header 160 bytes; everything else stays a 128-byte header."""
+    w = M.make_seeded_weights(M.ModelConfig(gen_blocks=1))
+    cfg = M.ModelConfig(gen_blocks=1, temporal_strength=0.5, temporal_window=16, temporal_gain=4.0,
+                        temporal_norm="L2", temporal_limit=True, temporal_luma=True)
+    blob = M.serialize(cfg, w)
+    assert struct.unpack_from("<I", blob, 12) == (160,)
+    assert struct.unpack_from("<IfI", blob, 128) == (16, 4.0, 7)
+    cfg2, w2 = M.deserialize(blob)
+    assert (cfg2.temporal_window, cfg2.temporal_gain, cfg2.temporal_norm, cfg2.temporal_limit,
+            cfg2.temporal_luma) == (16, 4.0, "L2", True, True)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+    default = M.serialize(M.ModelConfig(gen_blocks=1, temporal_strength=0.5), w)
+    assert struct.unpack_from("<I", default, 12) == (128,)
+    off = M.serialize(M.ModelConfig(gen_blocks=1, temporal_window=16), w)     # filter off: fields unused
+    assert struct.unpack_from("<I", off, 12) == (128,)
 
 
 def test_header_layout_and_alignment():

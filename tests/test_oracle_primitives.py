@@ -174,3 +174,56 @@ def test_leaky_relu_known_answers():
     assert np.array_equal(cfg.act("flow")(x), O.relu(x))          # per sub-model
     with pytest.raises(ValueError, match="Unknown activation"):
         O.ModelConfig(flow_activation="gelu").act("flow")
+
+
+def test_temporal_filter_modes_known_answers():
+    """frame_moving_avg.py:157-296 on hand-made tensors."""
+    rng = np.random.default_rng(3)
+    gen = rng.uniform(-0.5, 0.5, (8, 12, 3))
+    pw = gen + 0.2                                  # |d| = 0.2 everywhere
+    s = 0.5
+    # global sign gate: mean 0.2 > threshold 0.1 -> scene cut -> generator output
+    assert np.allclose(O.temporal_filter(gen, pw, s, 0.1), gen)
+    # still scene (threshold above the mean): s of pre_warp blended in
+    assert np.allclose(O.temporal_filter(gen, pw, s, 0.3), pw * s + gen * (1 - s))
+    # exactly at the threshold: sign(0) = 0 -> half of s
+    assert np.allclose(O.temporal_filter(np.zeros((4, 4, 3)), np.full((4, 4, 3), 0.25), s, 0.25),
+                       0.25 * (s / 2))
+    # tanh gate: c = tanh(gain * (m - t))
+    c = np.tanh(10.0 * (0.2 - 0.3))
+    assert np.allclose(O.temporal_filter(gen, pw, s, 0.3, gain=10.0),
+                       pw * (s / 2 - c * s / 2) + gen * (c * s / 2 + 1 - s / 2))
+    # L2 norm: mean of d^2 = 0.04
+    tr = {}
+    O.temporal_filter(gen, pw, s, 0.3, norm="L2", trace=tr)
+    assert np.isclose(tr["temporal_mean"], 0.04)
+    # luma weighting: each channel's term times BGR_LUMA*3 (squared for L2)
+    O.temporal_filter(gen, pw, s, 0.3, luma=True, trace=tr)
+    assert np.isclose(tr["temporal_mean"], 0.2 * np.mean(O.BGR_LUMA * 3))
+    O.temporal_filter(gen, pw, s, 0.3, norm="L2", luma=True, trace=tr)
+    assert np.isclose(tr["temporal_mean"], 0.04 * np.mean((O.BGR_LUMA * 3) ** 2))
+    # limit: pre_warp is clipped to +-0.5 before everything else
+    far = np.full((4, 4, 3), 2.0)
+    out = O.temporal_filter(np.zeros((4, 4, 3)), far, s, 1.0, limit=True)
+    assert np.allclose(out, 0.5 * s)
+    # windowed gate: 8x12 frame, window 4 -> 2x3 grid of block means (no padding here);
+    # left two thirds still, right third cut -> per-pixel gate, linearly interpolated
+    d = np.zeros((8, 12, 3))
+    d[:, 8:] = 0.4
+    tr = {}
+    out = O.temporal_filter(np.zeros((8, 12, 3)), d, 1.0, 0.2, window=4, trace=tr)
+    assert tr["temporal_mean"].shape == (2, 3)
+    assert np.allclose(tr["temporal_mean"], [[0, 0, 0.4], [0, 0, 0.4]])
+    # gate grid [-1, -1, +1] resized x4 asymmetric-linear: columns 0..4 = -1, then a ramp
+    # -1 -> +1 over columns 4..8, then +1; out = pre_warp * (1/2 - c/2)
+    cexp = np.concatenate([np.full(5, -1.0), [-0.5, 0.0, 0.5], np.full(4, 1.0)])
+    assert np.allclose(out[..., 0], d[..., 0] * (0.5 - cexp / 2)[None, :])
+    # ragged frame: 6x10 with window 4 pads to 8x12 (1 px leading on each axis); the
+    # divisor stays 3*window^2
+    tr = {}
+    O.temporal_filter(np.zeros((6, 10, 3)), np.full((6, 10, 3), 0.3), 1.0, 0.5, window=4, trace=tr)
+    assert tr["temporal_mean"].shape == (2, 3)
+    assert np.isclose(tr["temporal_mean"][0, 0], 0.3 * (3 * 3) / 16)    # 3x3 real pixels of 4x4
+    assert np.isclose(tr["temporal_mean"][0, 1], 0.3 * (3 * 4) / 16)
+    with pytest.raises(ValueError, match="Unknown norm"):
+        O.temporal_filter(gen, pw, s, 0.1, norm="L3")
