@@ -279,6 +279,16 @@ struct TemporalGeom {
 	int lrPixels;
 };
 
+// Clears the gate accumulators.  A kernel, not hipMemsetAsync: the per-frame program is
+// replayed from a captured hipGraph, and the memset NODE of a 768-byte clear was observed
+// to leave words uncleared on replay under the HIP 7.0 runtime that PyTorch bundles (the
+// process uses that runtime whenever torch is imported first, as bench.py and the tests
+// do); eager launches and the ROCm 7.2 runtime were fine.  A kernel node has no such mode.
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long *__restrict__ p, int n) {
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) p[i] = 0ull;
+}
+
 // one element's contribution to the gate statistic (:157-187, 219-222)
 __device__ __forceinline__ float temporalTerm(float gen, float pw, int ch, const TemporalGeom &g) {
 	if (g.limit) pw = fmaxf(fminf(pw, 0.5f), -0.5f);
@@ -715,8 +725,9 @@ void launchTemporalFilter(void *state, const void *preWarp, std::uint8_t *outU8,
     const TemporalParams &tp, hipStream_t stream) {
 	const TemporalGeom g = temporalGeom(H, W, tp);
 	const size_t nPix = (size_t)g.HH * g.WW;
-	hipError_t e = hipMemsetAsync(acc, 0, sizeof(unsigned long long) * g.GH * g.GW, stream);
-	if (e != hipSuccess) throw std::runtime_error(std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+	hipLaunchKernelGGL(zero_words_kernel, dim3(blocksFor((size_t)g.GH * g.GW)), dim3(256), 0, stream, acc,
+	    g.GH * g.GW);
+	hipCheckLaunch("zero_words");
 	hipLaunchKernelGGL(temporal_reduce_kernel, dim3(tp.window > 0 ? blocksFor(nPix) : 2048), dim3(256), 0,
 	    stream, static_cast<const f16 *>(state), static_cast<const f16 *>(preWarp), g, sums, acc);
 	hipCheckLaunch("temporal_reduce");
