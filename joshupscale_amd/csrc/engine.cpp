@@ -42,6 +42,74 @@ Engine::Operand Engine::operand(const std::string &name) {
 	return o;
 }
 
+namespace {
+int padTo16(int c) { return (c + 15) / 16 * 16; }
+}  // namespace
+
+// Which units of the flow auto-encoder (models.py:334-481) run as one launch each.
+void Engine::planFlowUnits() {
+	m_FlowUnits.clear();
+	const ModelConfig &c = m_Config;
+	if (c.flowArch != 0) return;
+	const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+	const bool hasHeadConv = c.flowFilters.size() % 2 != 0;
+	m_FlowUnits.resize(2 * nb + 1);
+	if (!m_FlowFused) return;
+	int cin = 3 * c.numFlowInputs;
+	int h = c.paddedHeight(), w = c.paddedWidth();
+	bool prevUps = false;  // the previous unit ends with a bilinear x2
+	for (int i = 0; i < 2 * nb; ++i) {
+		const int f = c.flowFilters[i];
+		const bool pool = i < nb;
+		if (prevUps) {
+			h *= 2;
+			w *= 2;
+		}
+		FlowUnit &u = m_FlowUnits[i];
+		const bool even = h % 2 == 0 && w % 2 == 0;
+		if ((!pool || (m_FusedPool && even)) && (!prevUps || even)) {
+			if (prevUps && flowBlockSupported(padTo16(cin), f, true, pool, false)) {
+				u.fused = u.upsIn = true;
+			} else if (flowBlockSupported(padTo16(cin), f, false, pool, false)) {
+				u.fused = true;
+			}
+		}
+		if (pool) {
+			h /= 2;
+			w /= 2;
+		}
+		prevUps = !pool;
+		cin = f;
+	}
+	if (hasHeadConv) {  // flow/conv_1 (BN, act) + flow/conv_2 (bias, 32 channels, f32 flow head)
+		if (prevUps) {
+			h *= 2;
+			w *= 2;
+		}
+		const int f = c.flowFilters.back();
+		FlowUnit &u = m_FlowUnits[2 * nb];
+		const bool even = h % 2 == 0 && w % 2 == 0;
+		if (f == 32) {
+			if (prevUps && even && flowBlockSupported(padTo16(cin), f, true, false, true)) {
+				u.fused = u.upsIn = true;
+			} else if (flowBlockSupported(padTo16(cin), f, false, false, true)) {
+				u.fused = true;
+			}
+		}
+	}
+}
+
+bool Engine::flowConvIsFused(const std::string &name) const {
+	if (m_Config.flowArch != 0 || m_FlowUnits.empty()) return false;
+	const int nb = static_cast<int>(m_Config.flowFilters.size()) / 2;
+	if (name == "flow/conv_1" || name == "flow/conv_2") return m_FlowUnits[2 * nb].fused;
+	if (name.rfind("flow/block_", 0) == 0) {
+		const int k = std::atoi(name.c_str() + 11);
+		return k >= 1 && k <= 2 * nb && m_FlowUnits[k - 1].fused;
+	}
+	return false;
+}
+
 Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &f,
     const std::vector<int> &cinMap, int H, int W) {
 	ConvWeights cw;
@@ -53,6 +121,9 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 	if ((towerLayer && f.cout == 64) || flowBlock || name == "generator/conv_trans_1") {
 		cw.nb = 2;  // the tower kernels and the fused tail read the 64-cout-block layout
 		cw.rw = 2;
+	} else if (flowConvIsFused(name)) {
+		cw.nb = 1;  // flow_block_kernel: one 32-cout block of fragments per wave
+		cw.rw = 1;
 	} else {
 		convTiling(H, W, f.cout, &cw.nb, &cw.rw);
 	}
@@ -196,6 +267,7 @@ void Engine::buildProgram(int set) {
 	// ---- flow net ----
 	Operand cur{packedOut, 0};
 	int h = PH, w = PW;
+	bool flowHeadDone = false;  // the fused head block wrote the flow tensor
 	if (c.flowArch == 0) {
 		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
 		// the decoder's bilinear x2 is folded into the staging of the conv that follows
@@ -207,10 +279,69 @@ void Engine::buildProgram(int set) {
 			return m_FusedUpsample && it != m_Convs.end() && cin % 64 == 0 && it->second.nb == 1 &&
 			       it->second.cout <= 32;
 		};
+		// one launch for a whole block (both convs, pool, preceding upsample) where planned
+		const int flowAct = c.flowActivation == 1 ? 2 : 1;
+		auto addBlockStep = [&](const std::string &convA, const std::string &convB, const void *in, void *out,
+		                        int bh, int bw, bool ups, bool pool, bool outF32, int act2) {
+			const ConvWeights &wa = m_Convs.at(convA), &wb = m_Convs.at(convB);
+			FlowBlockLaunch fb{};
+			fb.in = in;
+			fb.w1 = wa.w.get();
+			fb.b1 = wa.bias.as<float>();
+			fb.w2 = wb.w.get();
+			fb.b2 = wb.bias.as<float>();
+			fb.out = out;
+			fb.H = bh;
+			fb.W = bw;
+			fb.cin = wa.cinP;
+			fb.cmid = wa.cout;
+			fb.upsample = ups;
+			fb.pool = pool;
+			fb.outF32 = outF32;
+			fb.act1 = flowAct;
+			fb.act2 = act2;
+			fb.slope = c.flowNegativeSlope;
+			prog.push_back({"flow", 2.0 * bh * bw * 9.0 * (double(wa.cinReal) * wa.cout + double(wb.cinReal) * wb.cout),
+			    [dt, fb](hipStream_t s) { launchFlowBlock(dt, fb, s); }});
+		};
+		auto unitUpsIn = [&](int k) { return k < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[k].fused && m_FlowUnits[k].upsIn; };
 		bool upsampleNext = false;  // `cur` is half resolution: the next conv upsamples it
 		for (int i = 0; i < 2 * nb; ++i) {
 			const std::string n = "flow/block_" + std::to_string(i + 1);
 			const int f = c.flowFilters[i];
+			if (m_FlowUnits[i].fused) {
+				const bool pool = i < nb;
+				if (upsampleNext != m_FlowUnits[i].upsIn) throw std::logic_error("flow plan out of step");
+				addBlockStep(n + "/conv_1", n + "/conv_2", cur.ptr, T(pool ? n + "/resample" : n + "/a_2"), h, w,
+				    upsampleNext, pool, false, flowAct);
+				upsampleNext = false;
+				if (pool) {
+					h /= 2;
+					w /= 2;
+					cur = Operand{T(n + "/resample"), 0};
+				} else {
+					const void *src = T(n + "/a_2");
+					void *dst = T(n + "/resample");
+					if (unitUpsIn(i + 1)) {  // the next unit expands it while staging
+						upsampleNext = true;
+						cur = Op(n + "/a_2");
+					} else {
+						const std::string next = i + 1 < 2 * nb ? "flow/block_" + std::to_string(i + 2) + "/conv_1"
+						                         : (c.flowFilters.size() % 2 ? "flow/conv_1" : "");
+						if (fusesUpsample(next, f) && !(i + 1 < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[i + 1].fused)) {
+							upsampleNext = true;
+							cur = Op(n + "/a_2");
+						} else {
+							prog.push_back({"flow", 0.0,
+							    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
+							cur = Operand{dst, 0};
+						}
+					}
+					h *= 2;
+					w *= 2;
+				}
+				continue;
+			}
 			addConvStep(&prog, "flow", n + "/conv_1", cur, none, Op(n + "/a_1"), h, w, true, false,
 			    false, false, upsampleNext);
 			upsampleNext = false;
@@ -230,7 +361,8 @@ void Engine::buildProgram(int set) {
 			} else {
 				const std::string next = i + 1 < 2 * nb ? "flow/block_" + std::to_string(i + 2) + "/conv_1"
 				                         : (c.flowFilters.size() % 2 ? "flow/conv_1" : "");  // not the head
-				if (fusesUpsample(next, f)) {
+				const bool nextFused = i + 1 < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[i + 1].fused;
+				if (unitUpsIn(i + 1) || (!nextFused && fusesUpsample(next, f))) {
 					upsampleNext = true;
 					cur = Op(n + "/a_2");
 				} else {
@@ -243,10 +375,17 @@ void Engine::buildProgram(int set) {
 			}
 		}
 		if (c.flowFilters.size() % 2) {
-			addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/a_1"), h, w, true, false,
-			    false, false, upsampleNext);
-			upsampleNext = false;
-			cur = Op("flow/a_1");
+			if (m_FlowUnits[2 * nb].fused) {  // flow/conv_1 + flow/conv_2 -> the f32 flow head, one launch
+				if (upsampleNext != m_FlowUnits[2 * nb].upsIn) throw std::logic_error("flow plan out of step");
+				addBlockStep("flow/conv_1", "flow/conv_2", cur.ptr, T("flow"), h, w, upsampleNext, false, true, 0);
+				upsampleNext = false;
+				flowHeadDone = true;
+			} else {
+				addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/a_1"), h, w, true, false,
+				    false, false, upsampleNext);
+				upsampleNext = false;
+				cur = Op("flow/a_1");
+			}
 		}
 		if (upsampleNext) throw std::logic_error("flow head cannot take a half-resolution input");
 	} else if (m_ResidentFlow) {
@@ -290,7 +429,7 @@ void Engine::buildProgram(int set) {
 		}
 		cur = Op(xs[a]);
 	}
-	addConvStep(&prog, "flow", "flow/conv_2", cur, none, Op("flow"), h, w, false, true);
+	if (!flowHeadDone) addConvStep(&prog, "flow", "flow/conv_2", cur, none, Op("flow"), h, w, false, true);
 	// ---- warp + space-to-depth + concat ----
 	{
 		const float *flow = static_cast<const float *>(T("flow"));
@@ -482,6 +621,9 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_FusedPool = !(poolMode && std::string(poolMode) == "split");
 	const char *upMode = std::getenv("JU_UPSAMPLE");
 	m_FusedUpsample = !(upMode && std::string(upMode) == "split");
+	const char *flowConv = std::getenv("JU_FLOW_CONV");
+	m_FlowFused = !(flowConv && std::string(flowConv) == "generic") && m_FusedUpsample;
+	planFlowUnits();
 
 	buildWeights(model);
 

@@ -163,6 +163,17 @@ private:
 	std::vector<int> m_Fp8Exp;
 	DeviceBuffer m_TailW2, m_TailB2, m_TailW2Frag;
 	DeviceBuffer m_TemporalAcc;  // 32.32 fixed-point sum of |gen - pre_warp| (temporal filter)
+	// flow auto-encoder: which blocks run as ONE launch (flow_block_kernel: both convs, the
+	// pool, and the preceding bilinear x2).  Unit k < 2*nb = block k+1, the last = the head
+	// pair flow/conv_1 + flow/conv_2.  JU_FLOW_CONV=generic: none.
+	struct FlowUnit {
+		bool fused = false;
+		bool upsIn = false;  // its input is the half-resolution tensor (upsample folded into staging)
+	};
+	std::vector<FlowUnit> m_FlowUnits;
+	bool m_FlowFused = true;
+	void planFlowUnits();
+	bool flowConvIsFused(const std::string &name) const;
 	bool m_FusedUpsample = true;  // flow decoder: bilinear x2 folded into the next conv's staging
 	bool m_FusedPool = true;  // max-pool folded into the flow encoder's conv epilogues
 	bool m_FusedTail = true;  // JU_TAIL=split: convT1 as a conv launch + the VALU tail kernel

@@ -1,0 +1,570 @@
+// gfx950 (CDNA4, MI355X): the flow auto-encoder's blocks as ONE launch each
+// (reference scripts/training/models.py:334-481: conv-BN-act, conv-BN-act, then
+// MaxPool2D / UpscaleLayer; and the head pair flow/conv_1 + flow/conv_2).
+//
+//  * flow_block_kernel   conv A (3x3, CIN -> CMID) -> activation -> conv B (3x3, CMID ->
+//                        CMID) -> [activation] -> [2x2 max-pool] in one workgroup per
+//                        30-pixel-wide tile: the intermediate tensor lives in LDS only
+//                        (one-pixel recompute ring), optional TF1 bilinear x2 of the
+//                        INPUT folded into the tile staging.
+//
+// Why: as separate launches these layers are latency chains, not arithmetic (5.9-16 us
+// per launch for 0.9-4.8 GFLOP, 3-7 % MFMA busy): both MFMA
+// operands came from LDS (1-1.5 KB of LDS reads per MFMA), tiles were staged through
+// registers with two barriers per channel chunk, and every launch paid ~2-3 us of
+// boundary.  Here
+//   - weights are the MFMA A operand straight from registers (one cout block x one
+//     64-channel chunk = 36 fragments = 144 VGPRs per wave, loaded once per wave with
+//     plain 16-byte global loads from L2: no LDS traffic for weights at all),
+//   - activations are staged once per tile with LDS-DMA (global_load_lds, no VGPR
+//     round trip), pixel-major with the 16-byte chunk index XOR-swizzled by the column,
+//     and feed the B operand at 0.67 ds_read_b128 per MFMA (4 input-row fragments per
+//     (dx, k-step) macro-step serve 6 MFMAs of a row pair), hand-issued one macro-step
+//     ahead with counted lgkmcnt waits (the scheme of tower_resident_kernel),
+//   - outputs leave through an LDS transpose as whole 64-byte / 128-byte half records,
+//     16 B per lane,
+//   - the pair's intermediate activation never touches HBM, and a block is one kernel
+//     boundary instead of two or three.
+// The arithmetic per output element is that of conv_mfma_kernel (fp32 accumulation from
+// the bias, activation in f32, one rounding to the 16-bit type); only the fp32 summation
+// order differs.  JU_FLOW_CONV=generic keeps the per-layer kernels (tests compare both).
+#include "kernel_common.h"
+
+namespace ju {
+
+namespace {
+
+constexpr int kFbW = 34;     // LDS tile width: 32 MFMA columns + 2
+constexpr int kFbOutW = 30;  // final output columns per tile (conv B's 32 columns minus its ring)
+
+__device__ __forceinline__ void fbGlds16(const void *g, void *l) {
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+	    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+// XOR swizzle of the 16-byte chunk index by the tile column, for a pixel record of PB
+// bytes (P = PB / 16 chunks): the 16 lanes of a ds_read_b128 group read one logical chunk
+// of 16 consecutive columns and must fall on 16 distinct 16-byte slots of a 256-byte
+// bank row.
+template <int PB>
+__device__ __forceinline__ unsigned fbSwz(unsigned col) {
+	if constexpr (PB == 128) return (col >> 1) & 7u;
+	else if constexpr (PB == 64) return (col >> 2) & 3u;
+	else return (col >> 3) & 1u;
+}
+
+// One row pair (2 output rows x 32 columns x 32 couts) over one staged channel chunk:
+// 9 taps x KS k-steps; per macro-step (dx, ks) the 4 input-row fragments feed 6 MFMAs
+// (dy = 0..2 x row 0..1).  rowAddr: LDS byte address of input row 0 of the pair, column 0.
+template <typename T, int KS, int PB>
+struct FbPair {
+	static constexpr int RS = kFbW * PB;  // LDS row stride in bytes
+	static constexpr int NMAC = 3 * KS;
+
+	template <int J>
+	static __device__ __forceinline__ void rd(Vec8<T> &dst, unsigned a) {
+		asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a), "n"(RS * J));
+	}
+	static __device__ __forceinline__ void issue(Vec8<T> (&fb)[4], unsigned rowAddr,
+	    const unsigned (&colOff)[3], const unsigned (&colSwz)[3], int hh, int m, int j) {
+		const int dx = m / KS, ks = m % KS;
+		const unsigned a = rowAddr + colOff[dx] + ((static_cast<unsigned>(ks * 2 + hh) ^ colSwz[dx]) << 4);
+		if (j == 0) rd<0>(fb[0], a);
+		else if (j == 1) rd<1>(fb[1], a);
+		else if (j == 2) rd<2>(fb[2], a);
+		else rd<3>(fb[3], a);
+	}
+	template <int N>
+	static __device__ __forceinline__ void waitLgkm() {
+		static_assert(N >= 0 && N <= 4, "lgkmcnt");
+		if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+		else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+		else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+		else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+		else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	}
+
+	static __device__ __forceinline__ void run(unsigned rowAddr, const unsigned (&colOff)[3],
+	    const unsigned (&colSwz)[3], int hh, const Vec8<T> (&w)[9 * KS], f32x16 (&acc)[2]) {
+		Vec8<T> fb[2][4];
+		// start from an empty LGKM counter: the counted waits below must see only this
+		// loop's own reads
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int j = 0; j < 4; ++j) issue(fb[0], rowAddr, colOff, colSwz, hh, 0, j);
+#pragma unroll
+		for (int m = 0; m < NMAC; ++m) {
+			const int set = m & 1;
+			const bool more = m + 1 < NMAC;
+			const int dx = m / KS, ks = m % KS;
+#pragma unroll
+			for (int k = 0; k < 6; ++k) {
+				// MFMA k = (dy, r) = (k >> 1, k & 1) needs fragment r + dy; fragments are read
+				// (and return) in order 0..3
+				const int dy = k >> 1, r = k & 1;
+				const int need = r + dy;
+				const bool fresh = k == 0 || k == 1 || k == 3 || k == 5;
+				if (fresh) {
+					// outstanding allowed = younger reads of this step + next step's issued so far
+					const int allowed = (3 - need) + (more ? (k < 4 ? k : 4) : 0);
+					if (allowed >= 4) waitLgkm<4>();
+					else if (allowed == 3) waitLgkm<3>();
+					else if (allowed == 2) waitLgkm<2>();
+					else if (allowed == 1) waitLgkm<1>();
+					else waitLgkm<0>();
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				acc[r] = mfma32(w[(dy * 3 + dx) * KS + ks], fb[set][need], acc[r]);
+				if (more && k < 4) issue(fb[set ^ 1], rowAddr, colOff, colSwz, hh, m + 1, k);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	}
+};
+
+struct FlowBlockParams {
+	const void *in;   // NHWC [H][W][CIN]; UPS: the half-resolution tensor [H/2][W/2][CIN]
+	const void *w1;   // packConvWeights(nb = 1): [CMID/32][CIN/CK][9][CK/16][2][32][8]
+	const float *b1;  // [CMID]
+	const void *w2;   // [CMID/32][1][9][CMID/16][2][32][8]
+	const float *b2;  // [CMID]
+	void *out;        // [H][W][CMID] (POOL: [H/2][W/2][CMID]); f32 when OUTF32
+	int H, W;         // the block's resolution (the upsampled one with UPS)
+	int act1, act2;   // 0 none, 1 ReLU, 2 LeakyReLU(slope)
+	float slope;
+};
+
+__device__ __forceinline__ float fbAct(float v, int act, float slope) {
+	return act == 1 ? fmaxf(v, 0.0f) : (act == 2 ? leaky(v, slope) : v);
+}
+
+template <int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTF32>
+struct FbGeom {
+	static constexpr int CK1 = CIN >= 64 ? 64 : CIN;   // channels per staged plane
+	static constexpr int NPL = CIN / CK1;               // planes (64-channel chunks) of the input
+	static constexpr int PBX = CK1 * 2;                 // bytes per pixel per plane
+	static constexpr int KS1 = CK1 / 16;
+	static constexpr int XR = TH + 4;                   // input rows
+	static constexpr int TR = TH + 2;                   // intermediate rows
+	static constexpr int XPLANE = XR * kFbW * PBX;
+	static constexpr int PBT = CMID * 2;
+	static constexpr int KS2 = CMID / 16;
+	static constexpr int NCB = CMID / 32;               // cout blocks of both convs
+	static constexpr int TBYTES = TR * kFbW * PBT;
+	// low-resolution patch under the tile (UPS): rows (y0-2)/2 .. +XR/2, one more for the
+	// lower / right bilinear neighbour
+	static constexpr int LR = XR / 2 + 1, LC = kFbW / 2 + 1;
+	static constexpr int LBYTES = UPS ? NPL * LR * LC * PBX : 0;
+	static constexpr int OFF_X = 0;
+	static constexpr int OFF_T = NPL * XPLANE;
+	static constexpr int TREGION = TBYTES > LBYTES ? TBYTES : LBYTES;  // the patch is dead before T is written
+	// output staging per wave: 32 couts of a row pair (or of its pooled row)
+	static constexpr int ESZ = OUTF32 ? 4 : 2;
+	static constexpr int RBW = 32 * ESZ;                // bytes per pixel per cout block
+	static constexpr int STAGE_PX = POOL ? 16 : 64;
+	static constexpr int STAGE_WAVE = STAGE_PX * RBW;
+	static constexpr bool STAGE_IN_X = NPL * XPLANE >= 4 * STAGE_WAVE;  // X is dead once conv A is done
+	static constexpr int OFF_STAGE = STAGE_IN_X ? OFF_X : OFF_T + TREGION;
+	static constexpr int LDS = OFF_T + TREGION + (STAGE_IN_X ? 0 : 4 * STAGE_WAVE);
+	static_assert(CIN == 16 || CIN == 32 || CIN == 64 || CIN == 128, "input channels");
+	static_assert(CMID == 32 || CMID == 64, "block filters");
+	static_assert(TH % 2 == 0 && TH >= 2, "row pairs");
+	static constexpr bool FITS = LDS <= 160 * 1024;
+};
+
+template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTF32>
+__global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
+	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTF32>;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6;
+	const int lane = tid & 63;
+	const int px = lane & 31;
+	const int hh = lane >> 5;
+	const int x0 = blockIdx.x * kFbOutW;  // first output column of the tile
+	const int y0 = blockIdx.y * TH;       // first output row
+	const T *__restrict__ in = static_cast<const T *>(p.in);
+	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (__attribute__((address_space(3))) unsigned char *)smem));
+
+	// wave -> jobs: cout block cb (both convs have CMID couts), row pairs pstart, +pstep, ...
+	constexpr int NCB = G::NCB;
+	const int cb = NCB == 2 ? (wave & 1) : 0;
+	const int pstart = NCB == 2 ? (wave >> 1) : wave;
+	constexpr int PSTEP = NCB == 2 ? 2 : 4;
+
+	// ---- conv A weights: A fragments of this wave's cout block, straight to registers ----
+	Vec8<T> wa[G::NPL][9 * G::KS1];
+	{
+		const unsigned char *wsrc = static_cast<const unsigned char *>(p.w1) +
+		                            (size_t)cb * G::NPL * (9 * G::KS1 * 1024) + lane * 16;
+#pragma unroll
+		for (int pl = 0; pl < G::NPL; ++pl) {
+#pragma unroll
+			for (int f = 0; f < 9 * G::KS1; ++f) {
+				wa[pl][f] = *reinterpret_cast<const Vec8<T> *>(wsrc + (size_t)(pl * 9 * G::KS1 + f) * 1024);
+			}
+		}
+	}
+
+	// ---- stage the input tile ----
+	// X pixel (r, k) = image (y0 - 2 + r, x0 - 2 + k); pixels outside the image are the
+	// convolution's zero padding.
+	const bool border = y0 - 2 < 0 || y0 + TH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
+	constexpr int LPP = G::PBX / 16;  // lanes (16-byte chunks) per pixel
+	if constexpr (!UPS) {
+		if (border) {  // interior tiles are overwritten completely
+			for (int i = tid; i < G::NPL * G::XPLANE / 16; i += 256) {
+				reinterpret_cast<uint4 *>(smem + G::OFF_X)[i] = make_uint4(0, 0, 0, 0);
+			}
+			__syncthreads();
+		}
+		constexpr int NPXI = 1024 / G::PBX;  // pixels per wave-instruction
+		constexpr int NPIX = G::XR * kFbW;
+		constexpr int NINSTR = (NPIX + NPXI - 1) / NPXI;
+#pragma unroll
+		for (int pl = 0; pl < G::NPL; ++pl) {
+			for (int i = wave; i < NINSTR; i += 4) {
+				const int q = i * NPXI + lane / LPP;
+				const int r = q / kFbW, k = q - r * kFbW;
+				const int gy = y0 - 2 + r, gx = x0 - 2 + k;
+				const unsigned c = static_cast<unsigned>(lane % LPP) ^ fbSwz<G::PBX>(k);
+				if (q < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+					fbGlds16(in + ((size_t)gy * p.W + gx) * CIN + pl * 64 + c * 8,
+					    smem + G::OFF_X + pl * G::XPLANE + i * 1024);
+				}
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+	} else {
+		// low-resolution patch (coordinates clamped into the tensor), then the TF1 bilinear
+		// x2 (keras_layers.py:46-52: src = dst / 2, edge clamp) with upsample2_kernel's
+		// arithmetic, one parity class per pass
+		unsigned char *smL = smem + G::OFF_T;
+		const int lh = p.H >> 1, lw = p.W >> 1;
+		const int ly0 = (y0 >> 1) - 1, lx0 = (x0 >> 1) - 1;
+		constexpr int NPXI = 1024 / G::PBX;
+		constexpr int NPIX = G::LR * G::LC;
+		constexpr int NINSTR = (NPIX + NPXI - 1) / NPXI;
+#pragma unroll
+		for (int pl = 0; pl < G::NPL; ++pl) {
+			for (int i = wave; i < NINSTR; i += 4) {
+				const int q = min(i * NPXI + lane / LPP, NPIX - 1);
+				const int r = q / G::LC, k = q - r * G::LC;
+				const int cy = min(max(ly0 + r, 0), lh - 1), cx = min(max(lx0 + k, 0), lw - 1);
+				if (i * NPXI + lane / LPP < NPIX) {
+					fbGlds16(in + ((size_t)cy * lw + cx) * CIN + pl * 64 + (lane % LPP) * 8,
+					    smL + pl * (NPIX * G::PBX) + i * 1024);
+				}
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		constexpr int NEL = G::NPL * G::XR * kFbW * LPP;
+		for (int e = tid; e < NEL; e += 256) {
+			const int c = e % LPP;
+			const int q = (e / LPP) % (G::XR * kFbW);
+			const int pl = e / (LPP * G::XR * kFbW);
+			const int r = q / kFbW, k = q - r * kFbW;
+			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
+			Vec8<T> o;
+			if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+				const int yy0 = gy >> 1, xx0 = gx >> 1;
+				const int yy1 = min(yy0 + 1, lh - 1), xx1 = min(xx0 + 1, lw - 1);
+				const unsigned char *base = smL + pl * (NPIX * G::PBX) + c * 16;
+				auto at = [&](int yy, int xx) {
+					return *reinterpret_cast<const Vec8<T> *>(base + ((yy - ly0) * G::LC + (xx - lx0)) * G::PBX);
+				};
+				const Vec8<T> tl = at(yy0, xx0);
+				const bool oddY = gy & 1, oddX = gx & 1;
+				if (!oddY && !oddX) {
+					o = tl;
+				} else if (!oddY) {
+					const Vec8<T> tr = at(yy0, xx1);
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
+						o[j] = static_cast<T>(a + (b2 - a) * 0.5f);
+					}
+				} else if (!oddX) {
+					const Vec8<T> bl = at(yy1, xx0);
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						const float a = static_cast<float>(tl[j]), d = static_cast<float>(bl[j]);
+						o[j] = static_cast<T>(a + (d - a) * 0.5f);
+					}
+				} else {
+					const Vec8<T> tr = at(yy0, xx1), bl = at(yy1, xx0), br = at(yy1, xx1);
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
+						const float d = static_cast<float>(bl[j]), e2 = static_cast<float>(br[j]);
+						const float top = a + (b2 - a) * 0.5f;
+						const float bot = d + (e2 - d) * 0.5f;
+						o[j] = static_cast<T>(top + (bot - top) * 0.5f);
+					}
+				}
+			} else {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) o[j] = static_cast<T>(0.f);
+			}
+			*reinterpret_cast<Vec8<T> *>(smem + G::OFF_X + pl * G::XPLANE + q * G::PBX +
+			                             ((static_cast<unsigned>(c) ^ fbSwz<G::PBX>(k)) << 4)) = o;
+		}
+		__syncthreads();  // X complete; the patch (aliasing T) is dead
+	}
+
+	// ---- conv A: (TH + 2) rows x 32 columns -> T (LDS), zero outside the image ----
+	unsigned colOffA[3], colSwzA[3];
+#pragma unroll
+	for (int dx = 0; dx < 3; ++dx) {
+		colOffA[dx] = (px + dx) * G::PBX;
+		colSwzA[dx] = fbSwz<G::PBX>(px + dx);
+	}
+	{
+		constexpr int NPAIR = G::TR / 2;
+		constexpr int MAXP = (NPAIR + PSTEP - 1) / PSTEP;
+		// several planes: every pair's accumulators live across the planes; one plane:
+		// one pair at a time
+		constexpr int HOLD = G::NPL > 1 ? MAXP : 1;
+		f32x16 acc[HOLD][2];
+		auto initAcc = [&](f32x16(&a)[2]) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const f32x4 bg = *reinterpret_cast<const f32x4 *>(p.b1 + cb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) a[r][4 * g + i] = bg[i];
+				}
+			}
+		};
+		auto epilogueA = [&](const f32x16(&a)[2], int pair) {
+			// T pixel (tr, px) = image (y0 - 1 + tr, x0 - 1 + px); chunk = cb * 4 + g
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int tr = 2 * pair + r;
+				const int gy = y0 - 1 + tr, gx = x0 - 1 + px;
+				const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					Vec4<T> o = pack4<T>(fbAct(a[r][4 * g + 0], p.act1, p.slope), fbAct(a[r][4 * g + 1], p.act1, p.slope),
+					    fbAct(a[r][4 * g + 2], p.act1, p.slope), fbAct(a[r][4 * g + 3], p.act1, p.slope));
+					if (!inside) o = Vec4<T>{static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f)};
+					const unsigned c = static_cast<unsigned>(cb * 4 + g) ^ fbSwz<G::PBT>(px);
+					*reinterpret_cast<Vec4<T> *>(smem + G::OFF_T + (tr * kFbW + px) * G::PBT + (c << 4) + hh * 8) = o;
+				}
+			}
+		};
+		if constexpr (G::NPL == 1) {
+			for (int pair = pstart; pair < NPAIR; pair += PSTEP) {
+				initAcc(acc[0]);
+				FbPair<T, G::KS1, G::PBX>::run(ldsBase + G::OFF_X + (2 * pair) * (kFbW * G::PBX), colOffA, colSwzA,
+				    hh, wa[0], acc[0]);
+				epilogueA(acc[0], pair);
+			}
+		} else {
+#pragma unroll
+			for (int s = 0; s < HOLD; ++s) initAcc(acc[s]);
+#pragma unroll
+			for (int pl = 0; pl < G::NPL; ++pl) {
+#pragma unroll
+				for (int s = 0; s < HOLD; ++s) {
+					const int pair = pstart + s * PSTEP;
+					if (pair < NPAIR) {
+						FbPair<T, G::KS1, G::PBX>::run(
+						    ldsBase + G::OFF_X + pl * G::XPLANE + (2 * pair) * (kFbW * G::PBX), colOffA, colSwzA, hh,
+						    wa[pl], acc[s]);
+					}
+				}
+			}
+#pragma unroll
+			for (int s = 0; s < HOLD; ++s) {
+				const int pair = pstart + s * PSTEP;
+				if (pair < NPAIR) epilogueA(acc[s], pair);
+			}
+		}
+	}
+
+	// ---- conv B weights (registers of conv A's fragments are free now) ----
+	Vec8<T> wb[9 * G::KS2];
+	{
+		const unsigned char *wsrc = static_cast<const unsigned char *>(p.w2) + (size_t)cb * (9 * G::KS2 * 1024) + lane * 16;
+#pragma unroll
+		for (int f = 0; f < 9 * G::KS2; ++f) wb[f] = *reinterpret_cast<const Vec8<T> *>(wsrc + (size_t)f * 1024);
+	}
+	__syncthreads();  // T complete, X dead
+
+	// ---- conv B: TH rows x 32 columns (30 valid) -> [activation] -> [pool] -> global ----
+	unsigned colOffB[3], colSwzB[3];
+#pragma unroll
+	for (int dx = 0; dx < 3; ++dx) {
+		colOffB[dx] = (px + dx) * G::PBT;
+		colSwzB[dx] = fbSwz<G::PBT>(px + dx);
+	}
+	unsigned char *stage = smem + G::OFF_STAGE + wave * G::STAGE_WAVE;
+	constexpr int NCH = G::RBW / 16;  // 16-byte chunks per staged pixel
+	for (int pair = pstart; pair < TH / 2; pair += PSTEP) {
+		f32x16 acc[2];
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			const f32x4 bg = *reinterpret_cast<const f32x4 *>(p.b2 + cb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = bg[i];
+			}
+		}
+		FbPair<T, G::KS2, G::PBT>::run(ldsBase + G::OFF_T + (2 * pair) * (kFbW * G::PBT), colOffB, colSwzB, hh, wb, acc);
+		if constexpr (POOL) {
+			// rows y0 + 2 pair, + 1 (y0 even) and columns px, px ^ 1 (x0 even): vertical max in
+			// the lane, horizontal with the neighbouring lane; the activation is monotonic
+			// (loader-checked), so pooling the f32 values first is the reference's
+			// act-then-pool; both lanes hold the pooled pixel, each stages half its channels
+			const int pp = px >> 1;
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				float v[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					float m = fmaxf(acc[0][4 * g + i], acc[1][4 * g + i]);
+					m = fmaxf(m, __shfl_xor(m, 1));
+					v[i] = fbAct(m, p.act2, p.slope);
+				}
+				if ((g >> 1) == (px & 1)) {
+					const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(pp) & (NCH - 1));
+					*reinterpret_cast<Vec4<T> *>(stage + pp * G::RBW + (c << 4) + hh * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int pi = r * 32 + px;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					float v[4];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[i] = fbAct(acc[r][4 * g + i], p.act2, p.slope);
+					if constexpr (OUTF32) {
+						const unsigned c = static_cast<unsigned>(2 * g + hh) ^ (static_cast<unsigned>(pi) & (NCH - 1));
+						*reinterpret_cast<f32x4 *>(stage + pi * G::RBW + (c << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+					} else {
+						const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(pi) & (NCH - 1));
+						*reinterpret_cast<Vec4<T> *>(stage + pi * G::RBW + (c << 4) + hh * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
+					}
+				}
+			}
+		}
+		// same-wave exchange through LDS: order the writes before the reads
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		{
+			unsigned char *outp = static_cast<unsigned char *>(p.out);
+			constexpr int PXI = 64 / NCH;  // pixels per wave-instruction
+#pragma unroll
+			for (int it = 0; it < G::STAGE_PX / PXI; ++it) {
+				const int pi = it * PXI + lane / NCH;
+				const unsigned slot = static_cast<unsigned>(lane % NCH);
+				const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & (NCH - 1));
+				const uint4 val = *reinterpret_cast<const uint4 *>(stage + pi * G::RBW + (slot << 4));
+				if constexpr (POOL) {
+					const int oy = (y0 >> 1) + pair, ox = (x0 >> 1) + pi;
+					if (pi < kFbOutW / 2 && oy < (p.H >> 1) && ox < (p.W >> 1)) {
+						*reinterpret_cast<uint4 *>(outp + (((size_t)oy * (p.W >> 1) + ox) * CMID + cb * 32) * G::ESZ + chunk * 16) = val;
+					}
+				} else {
+					const int gy = y0 + 2 * pair + (pi >> 5), gx = x0 + (pi & 31);
+					if ((pi & 31) < kFbOutW && gy < p.H && gx < p.W) {
+						*reinterpret_cast<uint4 *>(outp + (((size_t)gy * p.W + gx) * CMID + cb * 32) * G::ESZ + chunk * 16) = val;
+					}
+				}
+			}
+		}
+		// the slice is reused by this wave's next pair
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+}
+
+template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTF32>
+void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
+	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTF32>;
+	static_assert(G::FITS, "tile does not fit LDS");
+	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTF32>;
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "flow block");
+	dim3 grid((p.W + kFbOutW - 1) / kFbOutW, (p.H + TH - 1) / TH);
+	hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS, stream, p);
+	hipCheckLaunch("flow_block");
+}
+
+// Tile height: the tall tile (18 rows: 11 % recompute ring) when the launch then still
+// fills the chip, the short one (6 rows) for small tensors.
+constexpr int kFbTall = 18, kFbShort = 6;
+
+template <typename T, int CIN, int CMID, bool UPS, bool POOL, bool OUTF32>
+void launchFlowBlockT(const FlowBlockParams &p, int numCUs, hipStream_t stream) {
+	const long tilesX = (p.W + kFbOutW - 1) / kFbOutW;
+	if constexpr (FbGeom<CIN, CMID, kFbTall, UPS, POOL, OUTF32>::FITS) {
+		if (tilesX * ((p.H + kFbTall - 1) / kFbTall) * 10 >= 7L * numCUs) {
+			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTF32>(p, stream);
+		}
+	}
+	launchFlowBlockInst<T, CIN, CMID, kFbShort, UPS, POOL, OUTF32>(p, stream);
+}
+
+template <typename T>
+void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
+	FlowBlockParams p{};
+	p.in = q.in;
+	p.w1 = q.w1;
+	p.b1 = q.b1;
+	p.w2 = q.w2;
+	p.b2 = q.b2;
+	p.out = q.out;
+	p.H = q.H;
+	p.W = q.W;
+	p.act1 = q.act1;
+	p.act2 = q.act2;
+	p.slope = q.slope;
+	static const int cus = [] {
+		int dev = 0, n = 256;
+		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+		return n;
+	}();
+	if (q.upsample && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused upsampling needs even H and W");
+	if (q.pool && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused max-pool needs even H and W");
+	// the shapes of the flow auto-encoder's fusable blocks (flowBlockSupported)
+#define JU_FB_CASE(CIN_, CMID_, UPS_, POOL_, F32_)                                                       \
+	if (q.cin == CIN_ && q.cmid == CMID_ && q.upsample == UPS_ && q.pool == POOL_ && q.outF32 == F32_) { \
+		return launchFlowBlockT<T, CIN_, CMID_, UPS_, POOL_, F32_>(p, cus, stream);                        \
+	}
+	JU_FB_CASE(16, 32, false, true, false)   // encoder block 1: 12(16) -> 32 -> 32, pool
+	JU_FB_CASE(32, 64, false, true, false)   // encoder block 2: 32 -> 64 -> 64, pool
+	JU_FB_CASE(128, 64, true, false, false)  // last decoder block: up(128) -> 64 -> 64
+	JU_FB_CASE(128, 64, false, false, false)
+	JU_FB_CASE(64, 32, true, false, true)    // head: up(64) -> 32 -> 32 (f32 flow)
+	JU_FB_CASE(64, 32, false, false, true)
+#undef JU_FB_CASE
+	throw std::invalid_argument("flow block: unsupported shape");
+}
+
+}  // namespace
+
+bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outF32) {
+	if (cin == 16 && cmid == 32) return !upsample && pool && !outF32;
+	if (cin == 32 && cmid == 64) return !upsample && pool && !outF32;
+	if (cin == 128 && cmid == 64) return !pool && !outF32;
+	if (cin == 64 && cmid == 32) return !pool && outF32;
+	return false;
+}
+
+void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream) {
+	if (dt == kF16) launchFlowBlockDT<f16>(q, stream);
+	else launchFlowBlockDT<bf16>(q, stream);
+}
+
+}  // namespace ju

@@ -106,6 +106,26 @@ inline void convTiling(int H, int W, int cout, int *nb, int *rw) {
 
 void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
 
+// ---- a flow auto-encoder block as one launch (flow_kernels.hip) ---------------------
+// conv A 3x3 cin -> cmid, activation, conv B 3x3 cmid -> cmid, [activation], [2x2
+// max-pool]; `upsample`: `in` is the half-resolution tensor [H/2][W/2][cin] and the TF1
+// bilinear x2 is part of the tile staging.  Weights: packConvWeights with nb = 1.
+struct FlowBlockLaunch {
+	const void *in;
+	const void *w1;
+	const float *b1;
+	const void *w2;
+	const float *b2;
+	void *out;      // [H][W][cmid], pooled [H/2][W/2][cmid], f32 when outF32
+	int H, W;       // the block's resolution (after the upsampling)
+	int cin, cmid;  // cin padded to 16
+	bool upsample, pool, outF32;
+	int act1, act2;  // ConvParams::relu codes
+	float slope;
+};
+bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outF32);
+void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream);
+
 // Persistent 3x3 64->64 kernel of the generator tower.  in/res/out must be
 // tower-layout tensors addressed at their interior origin with
 // pitch == towerPitch(W); other shapes fall back to launchConv.

@@ -460,6 +460,40 @@ def test_keras_import_runs_through_the_engine():
     direct.close()
 
 
+@pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
+def test_flow_blocks_fused_and_per_layer_paths_agree(monkeypatch, dtype):
+    """The flow auto-encoder's blocks run as one launch each (flow_block_kernel: both
+    convolutions, the pool / the preceding bilinear x2, intermediate tensor in LDS);
+    JU_FLOW_CONV=generic keeps one conv_mfma_kernel launch per layer.  Same arithmetic up
+    to the fp32 summation order: the flow head must agree to a fraction of the tolerance
+    against the oracle, the frames to 1 LSB -- at a ragged small size (partial tiles in
+    both directions) and at the full benchmark size."""
+    for cfg, n in [(small_config(frame_height=34, frame_width=70, gen_blocks=1), 3),
+                   (small_config(frame_height=64, frame_width=96, gen_blocks=1, flow_activation="lrelu"), 2),
+                   (M.PRESETS["psp-fast"], 2)]:
+        blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+        frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=61, kind="smooth")
+        runs = {}
+        for mode in ("fused", "generic"):
+            if mode == "generic":
+                monkeypatch.setenv("JU_FLOW_CONV", "generic")
+            else:
+                monkeypatch.delenv("JU_FLOW_CONV", raising=False)
+            rt = R.Runtime(blob, 0, dtype)
+            outs, flows = [], []
+            for f in frames:
+                outs.append(rt.process_image(f).copy())
+                flows.append(rt.read_tensor("flow").copy())
+            runs[mode] = (outs, flows, rt.stat("launches_per_frame"))
+            rt.close()
+        monkeypatch.delenv("JU_FLOW_CONV", raising=False)
+        assert runs["fused"][2] < runs["generic"][2]          # fewer launches per frame
+        for a, b in zip(runs["fused"][0], runs["generic"][0]):
+            assert u8_stats(a, b)["max"] <= 1
+        for a, b in zip(runs["fused"][1], runs["generic"][1]):
+            assert err(a, b)["max_abs"] <= 0.5 * TOL[dtype]["flow"], err(a, b)
+
+
 def test_long_sequence_does_not_drift():
     """The engine is recurrent: 16-bit rounding of the state could accumulate.  48
     frames of a moving scene against the float64 oracle: the error of the last
