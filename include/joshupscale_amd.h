@@ -155,7 +155,7 @@ JU_API int ju_get_dtype(const ju_runtime *runtime);
 
 /* Copies a named internal tensor to host memory as float32.  *count receives the
  * element count; dst may be NULL to query it.  Names: "state" (last output_raw,
- * f16 [4H][4W][4]), "flow" (f32 [PH][PW][32]), "flow_in", "gen_in", "trunk",
+ * f16 [4H][4W][4]), "flow" (f16 [PH][PW][32], the flow head before depth-to-space), "flow_in", "gen_in", "trunk",
  * "tail_y", and the per-layer flow activations. */
 JU_API int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, size_t capacity,
     size_t *count);

@@ -493,9 +493,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
 					for (int i = 0; i < 4; ++i) v[i] = leaky(v[i], p.slope);
 				}
-				if (p.outF32) {
-					f32x4 o = {v[0], v[1], v[2], v[3]};
-					*reinterpret_cast<f32x4 *>(static_cast<float *>(p.out) + off) = o;
+				if (p.outHead) {  // the flow head is f16 whatever the compute type
+					*reinterpret_cast<Vec4<f16> *>(static_cast<f16 *>(p.out) + off) = pack4<f16>(v[0], v[1], v[2], v[3]);
 				} else {
 					Vec4<T> o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]),
 					    static_cast<T>(v[3])};
@@ -534,7 +533,7 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 	    (p.rw != 1 && p.rw != 2) || p.cout % (32 * p.nb) != 0) {
 		throw std::invalid_argument("conv: cin must be a multiple of 16, cout of 32*nb");
 	}
-	if (p.pool && (p.rw != 2 || p.H % 2 || p.W % 2 || p.res != nullptr || p.outF32)) {
+	if (p.pool && (p.rw != 2 || p.H % 2 || p.W % 2 || p.res != nullptr || p.outHead)) {
 		throw std::invalid_argument("conv: fused max-pool needs rw = 2, even H and W, 16-bit output");
 	}
 	// Several 64-channel chunks and a launch that leaves at most one workgroup per CU

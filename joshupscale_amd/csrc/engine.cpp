@@ -81,7 +81,7 @@ void Engine::planFlowUnits() {
 		prevUps = !pool;
 		cin = f;
 	}
-	if (hasHeadConv) {  // flow/conv_1 (BN, act) + flow/conv_2 (bias, 32 channels, f32 flow head)
+	if (hasHeadConv) {  // flow/conv_1 (BN, act) + flow/conv_2 (bias, 32 channels, f16 flow head)
 		if (prevUps) {
 			h *= 2;
 			w *= 2;
@@ -184,7 +184,7 @@ void Engine::buildWeights(const ModelFile &model) {
 
 void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
     const std::string &wname, Operand in, Operand res, Operand out, int H, int W,
-    bool relu, bool outF32, bool tower, bool pool, bool upsample) {
+    bool relu, bool outHead, bool tower, bool pool, bool upsample) {
 	auto it = m_Convs.find(wname);
 	if (it == m_Convs.end()) throw std::logic_error("missing conv weights " + wname);
 	const ConvWeights &cw = it->second;
@@ -208,7 +208,7 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 		p.relu = relu ? (act == 1 ? 2 : 1) : 0;
 		p.slope = flowLayer ? m_Config.flowNegativeSlope : m_Config.genNegativeSlope;
 	}
-	p.outF32 = outF32 ? 1 : 0;
+	p.outHead = outHead ? 1 : 0;
 	p.nb = cw.nb;
 	p.rw = cw.rw;
 	if (pool) {  // the pooled epilogue pairs the two rows of a wave
@@ -282,7 +282,7 @@ void Engine::buildProgram(int set) {
 		// one launch for a whole block (both convs, pool, preceding upsample) where planned
 		const int flowAct = c.flowActivation == 1 ? 2 : 1;
 		auto addBlockStep = [&](const std::string &convA, const std::string &convB, const void *in, void *out,
-		                        int bh, int bw, bool ups, bool pool, bool outF32, int act2) {
+		                        int bh, int bw, bool ups, bool pool, bool outHead, int act2) {
 			const ConvWeights &wa = m_Convs.at(convA), &wb = m_Convs.at(convB);
 			FlowBlockLaunch fb{};
 			fb.in = in;
@@ -297,7 +297,7 @@ void Engine::buildProgram(int set) {
 			fb.cmid = wa.cout;
 			fb.upsample = ups;
 			fb.pool = pool;
-			fb.outF32 = outF32;
+			fb.outHead = outHead;
 			fb.act1 = flowAct;
 			fb.act2 = act2;
 			fb.slope = c.flowNegativeSlope;
@@ -375,7 +375,7 @@ void Engine::buildProgram(int set) {
 			}
 		}
 		if (c.flowFilters.size() % 2) {
-			if (m_FlowUnits[2 * nb].fused) {  // flow/conv_1 + flow/conv_2 -> the f32 flow head, one launch
+			if (m_FlowUnits[2 * nb].fused) {  // flow/conv_1 + flow/conv_2 -> the f16 flow head, one launch
 				if (upsampleNext != m_FlowUnits[2 * nb].upsIn) throw std::logic_error("flow plan out of step");
 				addBlockStep("flow/conv_1", "flow/conv_2", cur.ptr, T("flow"), h, w, upsampleNext, false, true, 0);
 				upsampleNext = false;
@@ -432,7 +432,7 @@ void Engine::buildProgram(int set) {
 	if (!flowHeadDone) addConvStep(&prog, "flow", "flow/conv_2", cur, none, Op("flow"), h, w, false, true);
 	// ---- warp + space-to-depth + concat ----
 	{
-		const float *flow = static_cast<const float *>(T("flow"));
+		const void *flow = T("flow");
 		void *genIn = T("gen_in");
 		void *preWarp = c.temporalStrength > 0.0f ? T("pre_warp") : nullptr;
 		prog.push_back({"warp", 0.0, [=](hipStream_t s) {
@@ -705,7 +705,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		addTensor("flow/x1", plr * c.flowResFilters);
 		addTensor("flow/t", plr * c.flowResFilters);
 	}
-	addTensor("flow", plr * 32, true);
+	addTensor("flow", plr * 32, false, true);  // the flow head: f16 whatever the compute type
 	addTensor("gen_in", lr * 64);
 	if (c.temporalStrength > 0.0f) {
 		addTensor("pre_warp", lr * 16 * 4);  // f16 [4H][4W][4]
@@ -1075,6 +1075,7 @@ std::size_t Engine::readTensor(const std::string &name, float *dst, std::size_t 
 		src = it->second.buf.get();
 		count = it->second.count;
 		f32 = it->second.isF32;
+		if (it->second.isState) dt = kF16;
 		if (it->second.towerC) tw = &it->second;
 	}
 	const std::size_t outCount =

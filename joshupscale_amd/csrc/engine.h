@@ -116,7 +116,7 @@ private:
 	ConvWeights &addConv(const std::string &name, const FoldedConv &f,
 	    const std::vector<int> &cinMap, int H, int W);
 	void addConvStep(std::vector<Step> *prog, const std::string &tag, const std::string &wname,
-	    Operand in, Operand res, Operand out, int H, int W, bool relu, bool outF32,
+	    Operand in, Operand res, Operand out, int H, int W, bool relu, bool outHead,
 	    bool tower = false, bool pool = false, bool upsample = false);
 	Operand operand(const std::string &name);
 	Tensor &addTowerTensor(const std::string &name, int H, int W, int C);

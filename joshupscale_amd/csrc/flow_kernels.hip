@@ -129,17 +129,29 @@ struct FlowBlockParams {
 	const float *b1;  // [CMID]
 	const void *w2;   // [CMID/32][1][9][CMID/16][2][32][8]
 	const float *b2;  // [CMID]
-	void *out;        // [H][W][CMID] (POOL: [H/2][W/2][CMID]); f32 when OUTF32
+	void *out;        // [H][W][CMID] (POOL: [H/2][W/2][CMID]); f16 when OUTHEAD
 	int H, W;         // the block's resolution (the upsampled one with UPS)
 	int act1, act2;   // 0 none, 1 ReLU, 2 LeakyReLU(slope)
 	float slope;
+	int skip;         // timing ablation (JU_FB_SKIP, developer only): 1 staging/expansion, 2 conv A, 4 conv B, 8 stores
 };
 
-__device__ __forceinline__ float fbAct(float v, int act, float slope) {
-	return act == 1 ? fmaxf(v, 0.0f) : (act == 2 ? leaky(v, slope) : v);
+// Activation as ONE multiplier: x < 0 ? x * s : x with s = 0 (ReLU), the negative slope
+// (LeakyReLU) or 1 (none).  (ReLU of a negative value gives -0.0, which every consumer
+// treats as zero.)
+__device__ __forceinline__ float fbActS(int act, float slope) {
+	return act == 1 ? 0.0f : (act == 2 ? slope : 1.0f);
+}
+__device__ __forceinline__ float fbAct(float v, float s) {
+	return v < 0.0f ? v * s : v;
 }
 
-template <int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTF32>
+// value of the neighbouring lane (lane ^ 1) without an LDS round trip: DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float fbSwapPair(float v) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+template <int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTHEAD, int NW = 4>
 struct FbGeom {
 	static constexpr int CK1 = CIN >= 64 ? 64 : CIN;   // channels per staged plane
 	static constexpr int NPL = CIN / CK1;               // planes (64-channel chunks) of the input
@@ -160,22 +172,26 @@ struct FbGeom {
 	static constexpr int OFF_T = NPL * XPLANE;
 	static constexpr int TREGION = TBYTES > LBYTES ? TBYTES : LBYTES;  // the patch is dead before T is written
 	// output staging per wave: 32 couts of a row pair (or of its pooled row)
-	static constexpr int ESZ = OUTF32 ? 4 : 2;
+	static constexpr int ESZ = 2;                       // (OUTHEAD: f16 instead of T, same size)
 	static constexpr int RBW = 32 * ESZ;                // bytes per pixel per cout block
 	static constexpr int STAGE_PX = POOL ? 16 : 64;
 	static constexpr int STAGE_WAVE = STAGE_PX * RBW;
-	static constexpr bool STAGE_IN_X = NPL * XPLANE >= 4 * STAGE_WAVE;  // X is dead once conv A is done
+	static constexpr bool STAGE_IN_X = NPL * XPLANE >= NW * STAGE_WAVE;  // X is dead once conv A is done
 	static constexpr int OFF_STAGE = STAGE_IN_X ? OFF_X : OFF_T + TREGION;
-	static constexpr int LDS = OFF_T + TREGION + (STAGE_IN_X ? 0 : 4 * STAGE_WAVE);
+	static constexpr int LDS = OFF_T + TREGION + (STAGE_IN_X ? 0 : NW * STAGE_WAVE);
 	static_assert(CIN == 16 || CIN == 32 || CIN == 64 || CIN == 128, "input channels");
 	static_assert(CMID == 32 || CMID == 64, "block filters");
 	static_assert(TH % 2 == 0 && TH >= 2, "row pairs");
 	static constexpr bool FITS = LDS <= 160 * 1024;
 };
 
-template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTF32>
-__global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
-	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTF32>;
+// NW waves per workgroup: 8 (two per SIMD) wherever the kernel fits 256 registers -- the
+// staging, expansion and epilogue phases are VALU work that one wave per SIMD issues at
+// half rate, and a partner wave's epilogue runs beside the other's MFMAs.
+template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTHEAD, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockParams p) {
+	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTHEAD, NW>;
+	constexpr int NT = NW * 64;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6;
@@ -192,7 +208,8 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 	constexpr int NCB = G::NCB;
 	const int cb = NCB == 2 ? (wave & 1) : 0;
 	const int pstart = NCB == 2 ? (wave >> 1) : wave;
-	constexpr int PSTEP = NCB == 2 ? 2 : 4;
+	constexpr int PSTEP = NCB == 2 ? NW / 2 : NW;
+	const float s1 = fbActS(p.act1, p.slope), s2 = fbActS(p.act2, p.slope);
 
 	// ---- conv A weights: A fragments of this wave's cout block, straight to registers ----
 	Vec8<T> wa[G::NPL][9 * G::KS1];
@@ -213,9 +230,10 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 	// convolution's zero padding.
 	const bool border = y0 - 2 < 0 || y0 + TH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
 	constexpr int LPP = G::PBX / 16;  // lanes (16-byte chunks) per pixel
-	if constexpr (!UPS) {
+	if (p.skip & 1) {
+	} else if constexpr (!UPS) {
 		if (border) {  // interior tiles are overwritten completely
-			for (int i = tid; i < G::NPL * G::XPLANE / 16; i += 256) {
+			for (int i = tid; i < G::NPL * G::XPLANE / 16; i += NT) {
 				reinterpret_cast<uint4 *>(smem + G::OFF_X)[i] = make_uint4(0, 0, 0, 0);
 			}
 			__syncthreads();
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 		constexpr int NINSTR = (NPIX + NPXI - 1) / NPXI;
 #pragma unroll
 		for (int pl = 0; pl < G::NPL; ++pl) {
-			for (int i = wave; i < NINSTR; i += 4) {
+			for (int i = wave; i < NINSTR; i += NW) {
 				const int q = i * NPXI + lane / LPP;
 				const int r = q / kFbW, k = q - r * kFbW;
 				const int gy = y0 - 2 + r, gx = x0 - 2 + k;
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 		constexpr int NINSTR = (NPIX + NPXI - 1) / NPXI;
 #pragma unroll
 		for (int pl = 0; pl < G::NPL; ++pl) {
-			for (int i = wave; i < NINSTR; i += 4) {
+			for (int i = wave; i < NINSTR; i += NW) {
 				const int q = min(i * NPXI + lane / LPP, NPIX - 1);
 				const int r = q / G::LC, k = q - r * G::LC;
 				const int cy = min(max(ly0 + r, 0), lh - 1), cx = min(max(lx0 + k, 0), lw - 1);
@@ -262,56 +280,48 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__syncthreads();
-		constexpr int NEL = G::NPL * G::XR * kFbW * LPP;
-		for (int e = tid; e < NEL; e += 256) {
+		// One thread per (low-resolution pixel, 16-byte chunk): its 2x2 block of the tile is
+		// a copy, two 2-tap means and one 4-tap mean of (self, right, below, diagonal) --
+		// upsample2_kernel's expressions with the zero-weight terms dropped (a + (b - a) * 0
+		// == a exactly), so the result is bit-identical to the separate kernel.  The patch was
+		// loaded with clamped coordinates, so "right" / "below" at the tensor's edge are the
+		// edge pixel itself, which is what min(lo + 1, n - 1) selects.
+		constexpr int BR = G::XR / 2, BC = kFbW / 2;  // 2x2 blocks of the tile
+		constexpr int NEL = G::NPL * BR * BC * LPP;
+		for (int e = tid; e < NEL; e += NT) {
 			const int c = e % LPP;
-			const int q = (e / LPP) % (G::XR * kFbW);
-			const int pl = e / (LPP * G::XR * kFbW);
-			const int r = q / kFbW, k = q - r * kFbW;
-			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
-			Vec8<T> o;
-			if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-				const int yy0 = gy >> 1, xx0 = gx >> 1;
-				const int yy1 = min(yy0 + 1, lh - 1), xx1 = min(xx0 + 1, lw - 1);
-				const unsigned char *base = smL + pl * (NPIX * G::PBX) + c * 16;
-				auto at = [&](int yy, int xx) {
-					return *reinterpret_cast<const Vec8<T> *>(base + ((yy - ly0) * G::LC + (xx - lx0)) * G::PBX);
-				};
-				const Vec8<T> tl = at(yy0, xx0);
-				const bool oddY = gy & 1, oddX = gx & 1;
-				if (!oddY && !oddX) {
-					o = tl;
-				} else if (!oddY) {
-					const Vec8<T> tr = at(yy0, xx1);
+			const int bq = (e / LPP) % (BR * BC);
+			const int pl = e / (LPP * BR * BC);
+			const int br = bq / BC, bc = bq - br * BC;
+			const unsigned char *base = smL + pl * (NPIX * G::PBX) + (br * G::LC + bc) * G::PBX + c * 16;
+			const Vec8<T> tl = *reinterpret_cast<const Vec8<T> *>(base);
+			const Vec8<T> tr = *reinterpret_cast<const Vec8<T> *>(base + G::PBX);
+			const Vec8<T> bl = *reinterpret_cast<const Vec8<T> *>(base + G::LC * G::PBX);
+			const Vec8<T> brr = *reinterpret_cast<const Vec8<T> *>(base + (G::LC + 1) * G::PBX);
+			Vec8<T> o01, o10, o11;
 #pragma unroll
-					for (int j = 0; j < 8; ++j) {
-						const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
-						o[j] = static_cast<T>(a + (b2 - a) * 0.5f);
-					}
-				} else if (!oddX) {
-					const Vec8<T> bl = at(yy1, xx0);
-#pragma unroll
-					for (int j = 0; j < 8; ++j) {
-						const float a = static_cast<float>(tl[j]), d = static_cast<float>(bl[j]);
-						o[j] = static_cast<T>(a + (d - a) * 0.5f);
-					}
-				} else {
-					const Vec8<T> tr = at(yy0, xx1), bl = at(yy1, xx0), br = at(yy1, xx1);
-#pragma unroll
-					for (int j = 0; j < 8; ++j) {
-						const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
-						const float d = static_cast<float>(bl[j]), e2 = static_cast<float>(br[j]);
-						const float top = a + (b2 - a) * 0.5f;
-						const float bot = d + (e2 - d) * 0.5f;
-						o[j] = static_cast<T>(top + (bot - top) * 0.5f);
-					}
-				}
-			} else {
-#pragma unroll
-				for (int j = 0; j < 8; ++j) o[j] = static_cast<T>(0.f);
+			for (int j = 0; j < 8; ++j) {
+				const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
+				const float d = static_cast<float>(bl[j]), e2 = static_cast<float>(brr[j]);
+				const float top = a + (b2 - a) * 0.5f;
+				const float bot = d + (e2 - d) * 0.5f;
+				o01[j] = static_cast<T>(top);
+				o10[j] = static_cast<T>(a + (d - a) * 0.5f);
+				o11[j] = static_cast<T>(top + (bot - top) * 0.5f);
 			}
-			*reinterpret_cast<Vec8<T> *>(smem + G::OFF_X + pl * G::XPLANE + q * G::PBX +
-			                             ((static_cast<unsigned>(c) ^ fbSwz<G::PBX>(k)) << 4)) = o;
+			const int r = 2 * br, k = 2 * bc;
+			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
+			const Vec8<T> zero = {static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f),
+			    static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f)};
+			// (H, W even: a 2x2 block is inside or outside the image as a whole)
+			const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+			unsigned char *xb = smem + G::OFF_X + pl * G::XPLANE + (r * kFbW + k) * G::PBX;
+			const unsigned s0 = (static_cast<unsigned>(c) ^ fbSwz<G::PBX>(k)) << 4;
+			const unsigned s1x = (static_cast<unsigned>(c) ^ fbSwz<G::PBX>(k + 1)) << 4;
+			*reinterpret_cast<Vec8<T> *>(xb + s0) = inside ? tl : zero;
+			*reinterpret_cast<Vec8<T> *>(xb + G::PBX + s1x) = inside ? o01 : zero;
+			*reinterpret_cast<Vec8<T> *>(xb + kFbW * G::PBX + s0) = inside ? o10 : zero;
+			*reinterpret_cast<Vec8<T> *>(xb + (kFbW + 1) * G::PBX + s1x) = inside ? o11 : zero;
 		}
 		__syncthreads();  // X complete; the patch (aliasing T) is dead
 	}
@@ -330,6 +340,11 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 		// one pair at a time
 		constexpr int HOLD = G::NPL > 1 ? MAXP : 1;
 		f32x16 acc[HOLD][2];
+		unsigned tOff[4];  // byte offset of this lane's 4 channels of group g inside a T row
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			tOff[g] = px * G::PBT + ((static_cast<unsigned>(cb * 4 + g) ^ fbSwz<G::PBT>(px)) << 4) + hh * 8;
+		}
 		auto initAcc = [&](f32x16(&a)[2]) {
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
@@ -343,22 +358,24 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 		};
 		auto epilogueA = [&](const f32x16(&a)[2], int pair) {
 			// T pixel (tr, px) = image (y0 - 1 + tr, x0 - 1 + px); chunk = cb * 4 + g
+			const int gx = x0 - 1 + px;
+			const bool colIn = gx >= 0 && gx < p.W;
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
 				const int tr = 2 * pair + r;
-				const int gy = y0 - 1 + tr, gx = x0 - 1 + px;
-				const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+				const int gy = y0 - 1 + tr;
+				const float keep = (colIn && gy >= 0 && gy < p.H) ? 1.0f : 0.0f;  // zero padding of conv B
+				unsigned char *row = smem + G::OFF_T + tr * (kFbW * G::PBT);
 #pragma unroll
 				for (int g = 0; g < 4; ++g) {
-					Vec4<T> o = pack4<T>(fbAct(a[r][4 * g + 0], p.act1, p.slope), fbAct(a[r][4 * g + 1], p.act1, p.slope),
-					    fbAct(a[r][4 * g + 2], p.act1, p.slope), fbAct(a[r][4 * g + 3], p.act1, p.slope));
-					if (!inside) o = Vec4<T>{static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f)};
-					const unsigned c = static_cast<unsigned>(cb * 4 + g) ^ fbSwz<G::PBT>(px);
-					*reinterpret_cast<Vec4<T> *>(smem + G::OFF_T + (tr * kFbW + px) * G::PBT + (c << 4) + hh * 8) = o;
+					*reinterpret_cast<Vec4<T> *>(row + tOff[g]) =
+					    pack4<T>(fbAct(a[r][4 * g + 0], s1) * keep, fbAct(a[r][4 * g + 1], s1) * keep,
+					        fbAct(a[r][4 * g + 2], s1) * keep, fbAct(a[r][4 * g + 3], s1) * keep);
 				}
 			}
 		};
-		if constexpr (G::NPL == 1) {
+		if (p.skip & 2) {
+		} else if constexpr (G::NPL == 1) {
 			for (int pair = pstart; pair < NPAIR; pair += PSTEP) {
 				initAcc(acc[0]);
 				FbPair<T, G::KS1, G::PBX>::run(ldsBase + G::OFF_X + (2 * pair) * (kFbW * G::PBX), colOffA, colSwzA,
@@ -406,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 	}
 	unsigned char *stage = smem + G::OFF_STAGE + wave * G::STAGE_WAVE;
 	constexpr int NCH = G::RBW / 16;  // 16-byte chunks per staged pixel
-	for (int pair = pstart; pair < TH / 2; pair += PSTEP) {
+	for (int pair = pstart; pair < ((p.skip & 4) ? 0 : TH / 2); pair += PSTEP) {
 		f32x16 acc[2];
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
@@ -430,8 +447,8 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
 					float m = fmaxf(acc[0][4 * g + i], acc[1][4 * g + i]);
-					m = fmaxf(m, __shfl_xor(m, 1));
-					v[i] = fbAct(m, p.act2, p.slope);
+					m = fmaxf(m, fbSwapPair(m));
+					v[i] = fbAct(m, s2);
 				}
 				if ((g >> 1) == (px & 1)) {
 					const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(pp) & (NCH - 1));
@@ -446,12 +463,11 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 				for (int g = 0; g < 4; ++g) {
 					float v[4];
 #pragma unroll
-					for (int i = 0; i < 4; ++i) v[i] = fbAct(acc[r][4 * g + i], p.act2, p.slope);
-					if constexpr (OUTF32) {
-						const unsigned c = static_cast<unsigned>(2 * g + hh) ^ (static_cast<unsigned>(pi) & (NCH - 1));
-						*reinterpret_cast<f32x4 *>(stage + pi * G::RBW + (c << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+					for (int i = 0; i < 4; ++i) v[i] = fbAct(acc[r][4 * g + i], s2);
+					const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(pi) & (NCH - 1));
+					if constexpr (OUTHEAD) {  // the flow head is f16 whatever the compute type
+						*reinterpret_cast<Vec4<f16> *>(stage + pi * G::RBW + (c << 4) + hh * 8) = pack4<f16>(v[0], v[1], v[2], v[3]);
 					} else {
-						const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(pi) & (NCH - 1));
 						*reinterpret_cast<Vec4<T> *>(stage + pi * G::RBW + (c << 4) + hh * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
 					}
 				}
@@ -470,7 +486,8 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 				const unsigned slot = static_cast<unsigned>(lane % NCH);
 				const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & (NCH - 1));
 				const uint4 val = *reinterpret_cast<const uint4 *>(stage + pi * G::RBW + (slot << 4));
-				if constexpr (POOL) {
+				if (p.skip & 8) {
+				} else if constexpr (POOL) {
 					const int oy = (y0 >> 1) + pair, ox = (x0 >> 1) + pi;
 					if (pi < kFbOutW / 2 && oy < (p.H >> 1) && ox < (p.W >> 1)) {
 						*reinterpret_cast<uint4 *>(outp + (((size_t)oy * (p.W >> 1) + ox) * CMID + cb * 32) * G::ESZ + chunk * 16) = val;
@@ -489,15 +506,23 @@ __global__ __launch_bounds__(256, 1) void flow_block_kernel(FlowBlockParams p) {
 	}
 }
 
-template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTF32>
+// 8 waves where the widest instantiation stays within 256 registers (two 64-channel
+// planes of conv A weights do not)
+template <int CIN>
+constexpr int fbWaves() {
+	return CIN > 64 ? 4 : 8;
+}
+
+template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTHEAD>
 void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
-	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTF32>;
+	constexpr int NW = fbWaves<CIN>();
+	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTHEAD, NW>;
 	static_assert(G::FITS, "tile does not fit LDS");
-	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTF32>;
+	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTHEAD, NW>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "flow block");
 	dim3 grid((p.W + kFbOutW - 1) / kFbOutW, (p.H + TH - 1) / TH);
-	hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS, stream, p);
+	hipLaunchKernelGGL(kern, grid, dim3(NW * 64), G::LDS, stream, p);
 	hipCheckLaunch("flow_block");
 }
 
@@ -505,15 +530,15 @@ void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
 // fills the chip, the short one (6 rows) for small tensors.
 constexpr int kFbTall = 18, kFbShort = 6;
 
-template <typename T, int CIN, int CMID, bool UPS, bool POOL, bool OUTF32>
+template <typename T, int CIN, int CMID, bool UPS, bool POOL, bool OUTHEAD>
 void launchFlowBlockT(const FlowBlockParams &p, int numCUs, hipStream_t stream) {
 	const long tilesX = (p.W + kFbOutW - 1) / kFbOutW;
-	if constexpr (FbGeom<CIN, CMID, kFbTall, UPS, POOL, OUTF32>::FITS) {
+	if constexpr (FbGeom<CIN, CMID, kFbTall, UPS, POOL, OUTHEAD, fbWaves<CIN>()>::FITS) {
 		if (tilesX * ((p.H + kFbTall - 1) / kFbTall) * 10 >= 7L * numCUs) {
-			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTF32>(p, stream);
+			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTHEAD>(p, stream);
 		}
 	}
-	launchFlowBlockInst<T, CIN, CMID, kFbShort, UPS, POOL, OUTF32>(p, stream);
+	launchFlowBlockInst<T, CIN, CMID, kFbShort, UPS, POOL, OUTHEAD>(p, stream);
 }
 
 template <typename T>
@@ -530,6 +555,11 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.act1 = q.act1;
 	p.act2 = q.act2;
 	p.slope = q.slope;
+	static const int skipEnv = [] {
+		const char *e = std::getenv("JU_FB_SKIP");
+		return e ? std::atoi(e) : 0;
+	}();
+	p.skip = skipEnv;
 	static const int cus = [] {
 		int dev = 0, n = 256;
 		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -539,14 +569,14 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	if (q.pool && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused max-pool needs even H and W");
 	// the shapes of the flow auto-encoder's fusable blocks (flowBlockSupported)
 #define JU_FB_CASE(CIN_, CMID_, UPS_, POOL_, F32_)                                                       \
-	if (q.cin == CIN_ && q.cmid == CMID_ && q.upsample == UPS_ && q.pool == POOL_ && q.outF32 == F32_) { \
+	if (q.cin == CIN_ && q.cmid == CMID_ && q.upsample == UPS_ && q.pool == POOL_ && q.outHead == F32_) { \
 		return launchFlowBlockT<T, CIN_, CMID_, UPS_, POOL_, F32_>(p, cus, stream);                        \
 	}
 	JU_FB_CASE(16, 32, false, true, false)   // encoder block 1: 12(16) -> 32 -> 32, pool
 	JU_FB_CASE(32, 64, false, true, false)   // encoder block 2: 32 -> 64 -> 64, pool
 	JU_FB_CASE(128, 64, true, false, false)  // last decoder block: up(128) -> 64 -> 64
 	JU_FB_CASE(128, 64, false, false, false)
-	JU_FB_CASE(64, 32, true, false, true)    // head: up(64) -> 32 -> 32 (f32 flow)
+	JU_FB_CASE(64, 32, true, false, true)    // head: up(64) -> 32 -> 32 (f16 flow head)
 	JU_FB_CASE(64, 32, false, false, true)
 #undef JU_FB_CASE
 	throw std::invalid_argument("flow block: unsupported shape");
@@ -554,11 +584,11 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 
 }  // namespace
 
-bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outF32) {
-	if (cin == 16 && cmid == 32) return !upsample && pool && !outF32;
-	if (cin == 32 && cmid == 64) return !upsample && pool && !outF32;
-	if (cin == 128 && cmid == 64) return !pool && !outF32;
-	if (cin == 64 && cmid == 32) return !pool && outF32;
+bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHead) {
+	if (cin == 16 && cmid == 32) return !upsample && pool && !outHead;
+	if (cin == 32 && cmid == 64) return !upsample && pool && !outHead;
+	if (cin == 128 && cmid == 64) return !pool && !outHead;
+	if (cin == 64 && cmid == 32) return !pool && outHead;
 	return false;
 }
 

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void upsample2_kernel(
 // writes 2 KiB contiguously.
 template <typename T>
 __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ state,
-    const float *__restrict__ flow, const std::uint8_t *__restrict__ frame,
+    const f16 *__restrict__ flow, const std::uint8_t *__restrict__ frame,
     std::ptrdiff_t frameStride, T *__restrict__ out, int H, int W, int PW, int padTop,
     int padLeft, const unsigned *__restrict__ sums, f16 *__restrict__ preWarpOut) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -192,10 +192,11 @@ __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ 
 	const int HH = H * 4, WW = W * 4;
 	// depth-to-space(4) of the flow head is just this channel addressing:
 	// flow[4h+i, 4w+j, k] = head[h, w, (i*4+j)*2 + k]  (keras_layers.py:175)
-	const float *fp = flow + ((size_t)(h + padTop) * PW + (w + padLeft)) * 32 + i * 8;
-	const f32x4 f0 = *reinterpret_cast<const f32x4 *>(fp);
-	const f32x4 f1 = *reinterpret_cast<const f32x4 *>(fp + 4);
-	const float fl[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+	const Vec8<f16> f8 = *reinterpret_cast<const Vec8<f16> *>(
+	    flow + ((size_t)(h + padTop) * PW + (w + padLeft)) * 32 + i * 8);
+	float fl[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) fl[k] = static_cast<float>(f8[k]);
 	T o[16];
 	Vec4<f16> pw[4];  // the same 4 HR pixels in [4H][4W][4] f16 for the temporal filter
 	const int Y = 4 * h + i;
@@ -675,17 +676,17 @@ void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, h
 	hipCheckLaunch("upsample2");
 }
 
-void launchWarpPack(DType dt, const void *state, const float *flow, const std::uint8_t *frame,
+void launchWarpPack(DType dt, const void *state, const void *flow, const std::uint8_t *frame,
     std::ptrdiff_t frameStride, void *out, int H, int W, int PW, int padTop, int padLeft,
     const unsigned *sums, void *preWarpOut, hipStream_t stream) {
 	const unsigned nb = blocksFor((size_t)H * W * 4);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(warp_pack_kernel<f16>, dim3(nb), dim3(256), 0, stream,
-		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<f16 *>(out), H,
+		    static_cast<const f16 *>(state), static_cast<const f16 *>(flow), frame, frameStride, static_cast<f16 *>(out), H,
 		    W, PW, padTop, padLeft, sums, static_cast<f16 *>(preWarpOut));
 	} else {
 		hipLaunchKernelGGL(warp_pack_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
-		    static_cast<const f16 *>(state), flow, frame, frameStride, static_cast<bf16 *>(out), H,
+		    static_cast<const f16 *>(state), static_cast<const f16 *>(flow), frame, frameStride, static_cast<bf16 *>(out), H,
 		    W, PW, padTop, padLeft, sums, static_cast<f16 *>(preWarpOut));
 	}
 	hipCheckLaunch("warp_pack");

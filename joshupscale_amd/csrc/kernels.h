@@ -23,7 +23,7 @@ inline std::size_t dtypeSize(DType) { return 2; }
 // wgt  : kernel-ready weights from packConvWeights() (model.cpp)
 // bias : f32 [cout] (BN-folded bias or the layer's own bias)
 // res  : optional NHWC [H][W][cout] 16-bit tensor added before the activation
-// out  : NHWC [H][W][cout], 16-bit or f32 (outF32)
+// out  : NHWC [H][W][cout] in the compute type, or f16 (outHead: the flow head)
 struct ConvParams {
 	const void *in;
 	const void *wgt;
@@ -35,7 +35,8 @@ struct ConvParams {
 	int taps;    // 9 (3x3 "same") or 1 (1x1)
 	int relu;    // activation: 0 none, 1 max(x, 0), 2 LeakyReLU (x < 0 ? slope * x : x)
 	float slope; // negative slope for relu == 2
-	int outF32;  // store f32 instead of the 16-bit type
+	int outHead; // store f16 whatever the compute type: the flow head (HR pixel offsets up to a few
+	             // pixels: f16 resolves 2^-9 .. 2^-8 px there, bf16 would not)
 	// 2x2 max-pool fused into the epilogue: out is [H/2][W/2][cout] (dense or pitched
 	// in POOLED pixels).  Needs rw == 2, even H and W, no residual, 16-bit output.
 	int pool;
@@ -116,14 +117,14 @@ struct FlowBlockLaunch {
 	const float *b1;
 	const void *w2;
 	const float *b2;
-	void *out;      // [H][W][cmid], pooled [H/2][W/2][cmid], f32 when outF32
+	void *out;      // [H][W][cmid], pooled [H/2][W/2][cmid]; f16 when outHead
 	int H, W;       // the block's resolution (after the upsampling)
 	int cin, cmid;  // cin padded to 16
-	bool upsample, pool, outF32;
+	bool upsample, pool, outHead;
 	int act1, act2;  // ConvParams::relu codes
 	float slope;
 };
-bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outF32);
+bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHead);
 void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream);
 
 // Persistent 3x3 64->64 kernel of the generator tower.  in/res/out must be
@@ -225,14 +226,14 @@ void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C,
 
 // ---- warp + space-to-depth + concat ----------------------------------------
 // state : previous HR output, f16 [4H][4W][4] (B,G,R,0)
-// flow  : f32 [PH][PW][32], channel (i*4+j)*2 + {dy,dx} (depth-to-space is free)
+// flow  : f16 [PH][PW][32], channel (i*4+j)*2 + {dy,dx} (depth-to-space is free)
 // frame : current LR frame, u8 BGRX
 // out   : generator input NHWC [H][W][64] in the packed channel order
 //         ch = i*16 + j*3 + c for the warped HR pixel (4h+i, 4w+j, c),
 //         ch 12,13,14 = current LR frame B,G,R, other spare slots zero.
 // preWarpOut (may be null): the warped previous output itself, f16 [4H][4W][4], for
 // the temporal filter below.
-void launchWarpPack(DType dt, const void *state, const float *flow,
+void launchWarpPack(DType dt, const void *state, const void *flow,
     const std::uint8_t *frame, std::ptrdiff_t frameStride, void *out, int H, int W, int PW,
     int padTop, int padLeft, const unsigned *sums, void *preWarpOut, hipStream_t stream);
 

@@ -1031,7 +1031,7 @@ void launchResidentT(const ResidentParams &p, hipStream_t stream) {
 
 void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 	const int pitch = towerPitch(p.W);
-	const bool fits = p.taps == 9 && p.cin == 64 && p.cout == 64 && !p.outF32 && p.nb == 2 &&
+	const bool fits = p.taps == 9 && p.cin == 64 && p.cout == 64 && !p.outHead && p.nb == 2 &&
 	                  p.inPitch == pitch && p.outPitch == pitch &&
 	                  (p.res == nullptr || p.resPitch == pitch);
 	if (!fits) {
