@@ -132,6 +132,12 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 	cw.w.upload(packed.data(), packed.size() * 2);
 	cw.bias = DeviceBuffer(f.bias.size() * 4);
 	cw.bias.upload(f.bias.data(), f.bias.size() * 4);
+	if (f.cin == 64 && f.cout == 64 && f.taps == 9 &&
+	    (name.rfind("generator/block_", 0) == 0 || flowBlock)) {
+		const auto blk = packConvWeights(f, cinMap, 1, m_DType);
+		cw.wBlock = DeviceBuffer(blk.size() * 2);
+		cw.wBlock.upload(blk.data(), blk.size() * 2);
+	}
 	cw.cinP = static_cast<int>(cinMap.size());
 	cw.cout = f.cout;
 	cw.taps = f.taps;
@@ -264,6 +270,28 @@ void Engine::buildProgram(int set) {
 		                launchPackFrames(dt, io->in, io->inStride, packedIn, packedOut, H, W, PH, PW,
 		                    padTop, padLeft, nIn, sums, generation, s);
 	                }});
+	// one launch for a 64-filter residual block outside the resident tower
+	auto addResBlockStep = [&](const std::string &tag, const std::string &block, Operand in, Operand out,
+	                           int bh, int bw, int act, float slope) {
+		const ConvWeights &wa = m_Convs.at(block + "/conv_1"), &wb = m_Convs.at(block + "/conv_2");
+		FlowBlockLaunch fb{};
+		fb.in = in.ptr;
+		fb.inPitch = in.pitch;
+		fb.w1 = wa.wBlock.get();
+		fb.b1 = wa.bias.as<float>();
+		fb.w2 = wb.wBlock.get();
+		fb.b2 = wb.bias.as<float>();
+		fb.out = out.ptr;
+		fb.outPitch = out.pitch;
+		fb.H = bh;
+		fb.W = bw;
+		fb.cin = fb.cmid = 64;
+		fb.residual = true;
+		fb.act1 = fb.act2 = act;
+		fb.slope = slope;
+		prog.push_back({tag, 2.0 * bh * bw * 9.0 * 64 * 64 * 2,
+		    [dt, fb](hipStream_t s) { launchFlowBlock(dt, fb, s); }});
+	};
 	// ---- flow net ----
 	Operand cur{packedOut, 0};
 	int h = PH, w = PW;
@@ -422,6 +450,12 @@ void Engine::buildProgram(int set) {
 		int a = 0;
 		for (int i = 0; i < c.flowResBlocks; ++i) {
 			const std::string n = "flow/block_" + std::to_string(i + 1);
+			if (m_BlockFused && c.flowResFilters == 64) {
+				addResBlockStep("flow", n, Op(xs[a]), Op(xs[a ^ 1]), h, w, c.flowActivation == 1 ? 2 : 1,
+				    c.flowNegativeSlope);
+				a ^= 1;
+				continue;
+			}
 			addConvStep(&prog, "flow", n + "/conv_1", Op(xs[a]), none, Op("flow/t"), h, w, true, false);
 			addConvStep(&prog, "flow", n + "/conv_2", Op("flow/t"), Op(xs[a]), Op(xs[a ^ 1]), h, w,
 			    true, false);
@@ -522,6 +556,12 @@ void Engine::buildProgram(int set) {
 	} else {
 		for (int i = 0; i < c.genBlocks; ++i) {
 			const std::string n = "generator/block_" + std::to_string(i + 1);
+			if (m_BlockFused && c.genFilters == 64) {
+				addResBlockStep("tower", n, Op(xs[a]), Op(xs[a ^ 1]), H, W, c.genActivation == 1 ? 2 : 1,
+				    c.genNegativeSlope);
+				a ^= 1;
+				continue;
+			}
 			addConvStep(&prog, "tower", n + "/conv_1", Op(xs[a]), none, Op("trunk_t"), H, W, true,
 			    false, true);
 			addConvStep(&prog, "tower", n + "/conv_2", Op("trunk_t"), Op(xs[a]), Op(xs[a ^ 1]), H, W,
@@ -633,7 +673,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		int cus = 0;
 		JU_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
 		// (the 8-bit tower has a per-layer kernel only)
-		bool wanted = !(mode && std::string(mode) == "layers") && !m_Fp8Tower;
+		bool wanted = !(mode && (std::string(mode) == "layers" || std::string(mode) == "convs")) && !m_Fp8Tower;
+		m_BlockFused = !(mode && std::string(mode) == "convs");
 		if (wanted && c.genActivation != 0) {
 			// the resident kernel's halo slots carry their epoch tag in the sign bits of
 			// post-ReLU values; a LeakyReLU model has no free bits there
@@ -658,7 +699,9 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		m_TowerHostW.clear();
 		m_TowerHostW.shrink_to_fit();
 		const char *flowMode = std::getenv("JU_FLOW");
-		if (m_Resident && !(flowMode && std::string(flowMode) == "layers") && c.flowArch == 1 &&
+		if (flowMode && std::string(flowMode) == "convs") m_BlockFused = false;
+		if (m_Resident && !(flowMode && (std::string(flowMode) == "layers" || std::string(flowMode) == "convs")) &&
+		    c.flowArch == 1 &&
 		    c.flowActivation == 0 &&
 		    c.flowResFilters == 64 && c.flowResBlocks >= 1 && 3 * c.numFlowInputs <= 64 &&
 		    residentTowerGeometry(PH, PW, cus, &m_FlowGX, &m_FlowGY, &m_FlowRH)) {

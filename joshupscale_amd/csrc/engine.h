@@ -105,6 +105,7 @@ private:
 	};
 	struct ConvWeights {
 		DeviceBuffer w;
+		DeviceBuffer wBlock;  // 64 -> 64 block convolutions: a second copy packed with nb = 1 for flow_block_kernel
 		DeviceBuffer bias;
 		int cinP = 0, cout = 0, taps = 9, cinReal = 0;
 		int nb = 2, rw = 2;  // tile shape the weights were packed for
@@ -172,6 +173,10 @@ private:
 	};
 	std::vector<FlowUnit> m_FlowUnits;
 	bool m_FlowFused = true;
+	// residual blocks outside the resident tower (more regions than CUs, LeakyReLU models,
+	// after a fallback): one launch per BLOCK (flow_block_kernel, intermediate tensor in LDS);
+	// JU_TOWER=convs keeps one launch per convolution
+	bool m_BlockFused = true;
 	void planFlowUnits();
 	bool flowConvIsFused(const std::string &name) const;
 	bool m_FusedUpsample = true;  // flow decoder: bilinear x2 folded into the next conv's staging

@@ -129,8 +129,10 @@ struct FlowBlockParams {
 	const float *b1;  // [CMID]
 	const void *w2;   // [CMID/32][1][9][CMID/16][2][32][8]
 	const float *b2;  // [CMID]
-	void *out;        // [H][W][CMID] (POOL: [H/2][W/2][CMID]); f16 when OUTHEAD
+	void *out;        // [H][W][CMID] (POOL: [H/2][W/2][CMID]); f16 when OUTK == 1
 	int H, W;         // the block's resolution (the upsampled one with UPS)
+	int inPitch, outPitch;  // row pitches in pixels (of the tensor as stored: half resolution for a
+	                        // UPS input / a pooled output)
 	int act1, act2;   // 0 none, 1 ReLU, 2 LeakyReLU(slope)
 	float slope;
 	int skip;         // timing ablation (JU_FB_SKIP, developer only): 1 staging/expansion, 2 conv A, 4 conv B, 8 stores
@@ -151,7 +153,7 @@ __device__ __forceinline__ float fbSwapPair(float v) {
 	return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-template <int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTHEAD, int NW = 4>
+template <int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK, int NW = 4>
 struct FbGeom {
 	static constexpr int CK1 = CIN >= 64 ? 64 : CIN;   // channels per staged plane
 	static constexpr int NPL = CIN / CK1;               // planes (64-channel chunks) of the input
@@ -172,7 +174,7 @@ struct FbGeom {
 	static constexpr int OFF_T = NPL * XPLANE;
 	static constexpr int TREGION = TBYTES > LBYTES ? TBYTES : LBYTES;  // the patch is dead before T is written
 	// output staging per wave: 32 couts of a row pair (or of its pooled row)
-	static constexpr int ESZ = 2;                       // (OUTHEAD: f16 instead of T, same size)
+	static constexpr int ESZ = 2;                       // (OUTK 1: f16 instead of T, same size)
 	static constexpr int RBW = 32 * ESZ;                // bytes per pixel per cout block
 	static constexpr int STAGE_PX = POOL ? 16 : 64;
 	static constexpr int STAGE_WAVE = STAGE_PX * RBW;
@@ -188,9 +190,9 @@ struct FbGeom {
 // NW waves per workgroup: 8 (two per SIMD) wherever the kernel fits 256 registers -- the
 // staging, expansion and epilogue phases are VALU work that one wave per SIMD issues at
 // half rate, and a partner wave's epilogue runs beside the other's MFMAs.
-template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTHEAD, int NW>
+template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockParams p) {
-	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTHEAD, NW>;
+	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, NW>;
 	constexpr int NT = NW * 64;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 				const int gy = y0 - 2 + r, gx = x0 - 2 + k;
 				const unsigned c = static_cast<unsigned>(lane % LPP) ^ fbSwz<G::PBX>(k);
 				if (q < NPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-					fbGlds16(in + ((size_t)gy * p.W + gx) * CIN + pl * 64 + c * 8,
+					fbGlds16(in + ((size_t)gy * p.inPitch + gx) * CIN + pl * 64 + c * 8,
 					    smem + G::OFF_X + pl * G::XPLANE + i * 1024);
 				}
 			}
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 				const int r = q / G::LC, k = q - r * G::LC;
 				const int cy = min(max(ly0 + r, 0), lh - 1), cx = min(max(lx0 + k, 0), lw - 1);
 				if (i * NPXI + lane / LPP < NPIX) {
-					fbGlds16(in + ((size_t)cy * lw + cx) * CIN + pl * 64 + (lane % LPP) * 8,
+					fbGlds16(in + ((size_t)cy * p.inPitch + cx) * CIN + pl * 64 + (lane % LPP) * 8,
 					    smL + pl * (NPIX * G::PBX) + i * 1024);
 				}
 			}
@@ -435,6 +437,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 			}
 		}
 		FbPair<T, G::KS2, G::PBT>::run(ldsBase + G::OFF_T + (2 * pair) * (kFbW * G::PBT), colOffB, colSwzB, hh, wb, acc);
+		// residual block (OUTK 2, models.py:248-253): the skip connection is the block's own
+		// input at the output pixel; its 8-byte pieces are fetched behind the K loop
+		// (the tile was just staged from the same lines: L2 hits; the SIMD's other wave computes
+		// meanwhile -- fetched in front of the loop they cost 16 registers the loop has not got)
+		Vec4<T> resv[2][4];
+		if constexpr (OUTK == 2) {
+			static_assert(CIN == CMID && !UPS && !POOL, "residual block: same width in and out");
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int gy = min(y0 + 2 * pair + r, p.H - 1), gx = min(x0 + px, p.W - 1);
+				const T *rp = in + ((size_t)gy * p.inPitch + gx) * CIN + cb * 32 + 4 * hh;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) resv[r][g] = *reinterpret_cast<const Vec4<T> *>(rp + 8 * g);
+			}
+		}
 		if constexpr (POOL) {
 			// rows y0 + 2 pair, + 1 (y0 even) and columns px, px ^ 1 (x0 even): vertical max in
 			// the lane, horizontal with the neighbouring lane; the activation is monotonic
@@ -463,9 +480,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 				for (int g = 0; g < 4; ++g) {
 					float v[4];
 #pragma unroll
-					for (int i = 0; i < 4; ++i) v[i] = fbAct(acc[r][4 * g + i], s2);
+					for (int i = 0; i < 4; ++i) {
+						float x = acc[r][4 * g + i];
+						if constexpr (OUTK == 2) x += static_cast<float>(resv[r][g][i]);
+						v[i] = fbAct(x, s2);
+					}
 					const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(pi) & (NCH - 1));
-					if constexpr (OUTHEAD) {  // the flow head is f16 whatever the compute type
+					if constexpr (OUTK == 1) {  // the flow head is f16 whatever the compute type
 						*reinterpret_cast<Vec4<f16> *>(stage + pi * G::RBW + (c << 4) + hh * 8) = pack4<f16>(v[0], v[1], v[2], v[3]);
 					} else {
 						*reinterpret_cast<Vec4<T> *>(stage + pi * G::RBW + (c << 4) + hh * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
@@ -490,12 +511,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 				} else if constexpr (POOL) {
 					const int oy = (y0 >> 1) + pair, ox = (x0 >> 1) + pi;
 					if (pi < kFbOutW / 2 && oy < (p.H >> 1) && ox < (p.W >> 1)) {
-						*reinterpret_cast<uint4 *>(outp + (((size_t)oy * (p.W >> 1) + ox) * CMID + cb * 32) * G::ESZ + chunk * 16) = val;
+						*reinterpret_cast<uint4 *>(outp + (((size_t)oy * p.outPitch + ox) * CMID + cb * 32) * G::ESZ + chunk * 16) = val;
 					}
 				} else {
 					const int gy = y0 + 2 * pair + (pi >> 5), gx = x0 + (pi & 31);
 					if ((pi & 31) < kFbOutW && gy < p.H && gx < p.W) {
-						*reinterpret_cast<uint4 *>(outp + (((size_t)gy * p.W + gx) * CMID + cb * 32) * G::ESZ + chunk * 16) = val;
+						*reinterpret_cast<uint4 *>(outp + (((size_t)gy * p.outPitch + gx) * CMID + cb * 32) * G::ESZ + chunk * 16) = val;
 					}
 				}
 			}
@@ -506,6 +527,231 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	}
 }
 
+// ---------------------------------------------------------------------------
+// res_block_kernel: one 64-filter residual block (models.py:193-254) per launch, PERSISTENT
+// ---------------------------------------------------------------------------
+// For towers that cannot use tower_resident_kernel (more 32 x 16 regions than CUs, e.g.
+// 640 x 448; LeakyReLU models; after a fallback).  One workgroup per CU loops over
+// 14 x 30-pixel tiles:
+//   * both convolutions' A fragments stay in registers for the whole launch (2 x 36
+//     fragments = 288 VGPRs per wave, one wave per SIMD): no weight traffic per tile;
+//   * conv A: X tile (18 x 34 px, LDS) -> activation -> T tile (16 x 34 px, LDS);
+//   * while conv B (T -> + skip -> activation -> global) is on the matrix cores, the NEXT
+//     tile's X is already in flight into the X buffer by LDS-DMA (X is dead once conv A
+//     is done), so tile staging costs no time of its own;
+//   * the skip connection is re-read from global (the lines were just staged: L2 hits).
+// in / out are addressed at image pixel (0, 0) with a row pitch, so dense and tower-layout
+// tensors both work; only image pixels are written (a tower tensor's zero border stays).
+constexpr int kRbTH = 14;
+constexpr int kRbXR = kRbTH + 4, kRbTR = kRbTH + 2;
+constexpr int kRbX = kRbXR * kFbW * 128;           // 78336
+constexpr int kRbT = kRbTR * kFbW * 128;           // 69632
+constexpr int kRbStageWave = 32 * 64;              // one row of 32 px x 32 couts, 16-bit
+constexpr int kRbLds = kRbX + kRbT + 4 * kRbStageWave;
+static_assert(kRbLds <= 160 * 1024, "res block tile");
+
+struct ResBlockParams {
+	const void *in;
+	void *out;
+	const void *w1, *w2;   // packConvWeights(nb = 1)
+	const float *b1, *b2;
+	int H, W, inPitch, outPitch;
+	int tilesX, numTiles;
+	float s1, s2;          // activation multipliers (fbActS)
+	int skip;              // timing ablation (JU_FB_SKIP, developer only)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
+	const int cb = wave & 1, pl = wave >> 1;  // cout block, pair lane (pairs pl, pl + 2, ...)
+	const T *__restrict__ in = static_cast<const T *>(p.in);
+	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (__attribute__((address_space(3))) unsigned char *)smem));
+	unsigned char *smX = smem, *smT = smem + kRbX;
+	unsigned char *stage = smem + kRbX + kRbT + wave * kRbStageWave;
+
+	// both convolutions' fragments of this wave's cout block, for the whole launch
+	Vec8<T> wa[36], wb[36];
+	{
+		const unsigned char *a = static_cast<const unsigned char *>(p.w1) + (size_t)cb * (36 * 1024) + lane * 16;
+		const unsigned char *b = static_cast<const unsigned char *>(p.w2) + (size_t)cb * (36 * 1024) + lane * 16;
+#pragma unroll
+		for (int f = 0; f < 36; ++f) {
+			wa[f] = *reinterpret_cast<const Vec8<T> *>(a + (size_t)f * 1024);
+			wb[f] = *reinterpret_cast<const Vec8<T> *>(b + (size_t)f * 1024);
+		}
+	}
+	f32x4 biasA[4], biasB[4];
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		biasA[g] = *reinterpret_cast<const f32x4 *>(p.b1 + cb * 32 + 8 * g + 4 * hh);
+		biasB[g] = *reinterpret_cast<const f32x4 *>(p.b2 + cb * 32 + 8 * g + 4 * hh);
+	}
+	unsigned colOff[3], colSwz[3], tOff[4];
+#pragma unroll
+	for (int dx = 0; dx < 3; ++dx) {
+		colOff[dx] = (px + dx) * 128;
+		colSwz[dx] = fbSwz<128>(px + dx);
+	}
+#pragma unroll
+	for (int g = 0; g < 4; ++g) tOff[g] = px * 128 + ((static_cast<unsigned>(cb * 4 + g) ^ fbSwz<128>(px)) << 4) + hh * 8;
+
+	// X tile of `tile`: image pixels by LDS-DMA, pixels outside the image zeroed by hand
+	// (disjoint LDS locations, so the two need no ordering between them)
+	auto stageX = [&](int tile) {
+		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
+		constexpr int NPIX = kRbXR * kFbW;
+		constexpr int NINSTR = (NPIX + 7) / 8;  // 8 pixels (1 KiB) per wave-instruction
+		const bool border = y0 - 2 < 0 || y0 + kRbTH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
+		for (int i = wave; i < NINSTR; i += 4) {
+			const int q = i * 8 + (lane >> 3);
+			const int r = q / kFbW, k = q - r * kFbW;
+			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
+			const unsigned c = static_cast<unsigned>(lane & 7) ^ fbSwz<128>(k);
+			const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+			if (q < NPIX && inside) {
+				fbGlds16(in + ((size_t)gy * p.inPitch + gx) * 64 + c * 8, smX + i * 1024);
+			} else if (border && q < NPIX) {
+				*reinterpret_cast<uint4 *>(smX + i * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+			}
+		}
+	};
+
+	int tile = blockIdx.x;
+	if (tile < p.numTiles && !(p.skip & 1)) stageX(tile);
+	for (; tile < p.numTiles; tile += gridDim.x) {
+		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's X has landed (and the last tile's stores left)
+		__syncthreads();                                  // ... for every wave; all are done with T too
+		// ---- conv A: 16 rows x 32 columns -> T, zero outside the image ----
+		for (int pair = pl; pair < kRbTR / 2; pair += 2) {
+			f32x16 acc[2];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = biasA[g][i];
+				}
+			}
+			if (!(p.skip & 2)) FbPair<T, 4, 128>::run(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, acc);
+			if (p.skip & 32) continue;
+			const int gx = x0 - 1 + px;
+			const bool colIn = gx >= 0 && gx < p.W;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int tr = 2 * pair + r;
+				const int gy = y0 - 1 + tr;
+				const float keep = (colIn && gy >= 0 && gy < p.H) ? 1.0f : 0.0f;
+				unsigned char *row = smT + tr * (kFbW * 128);
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					*reinterpret_cast<Vec4<T> *>(row + tOff[g]) =
+					    pack4<T>(fbAct(acc[r][4 * g + 0], p.s1) * keep, fbAct(acc[r][4 * g + 1], p.s1) * keep,
+					        fbAct(acc[r][4 * g + 2], p.s1) * keep, fbAct(acc[r][4 * g + 3], p.s1) * keep);
+				}
+			}
+		}
+		__syncthreads();  // T complete, X dead
+		// ---- the next tile's X travels while conv B computes ----
+		if (tile + static_cast<int>(gridDim.x) < p.numTiles && !(p.skip & 1)) stageX(tile + gridDim.x);
+		// ---- conv B: 14 rows x 32 columns (30 valid) + skip -> activation -> global ----
+		for (int pair = pl; pair < kRbTH / 2; pair += 2) {
+			f32x16 acc[2];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = biasB[g][i];
+				}
+			}
+			Vec4<T> resv[2][4];
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int gy = min(y0 + 2 * pair + r, p.H - 1), gx = min(x0 + px, p.W - 1);
+				const T *rp = in + ((size_t)gy * p.inPitch + gx) * 64 + cb * 32 + 4 * hh;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					if (p.skip & 8) resv[r][g] = Vec4<T>{};
+					else resv[r][g] = *reinterpret_cast<const Vec4<T> *>(rp + 8 * g);
+				}
+			}
+			if (!(p.skip & 4)) FbPair<T, 4, 128>::run(ldsBase + kRbX + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wb, acc);
+			if (p.skip & 64) continue;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					float v[4];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[i] = fbAct(acc[r][4 * g + i] + static_cast<float>(resv[r][g][i]), p.s2);
+					const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(px) & 3u);
+					*reinterpret_cast<Vec4<T> *>(stage + px * 64 + (c << 4) + hh * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				// one row: 32 px x 64 B = 2 KiB = 2 wave-instructions of 16 B per lane
+				unsigned char *outp = static_cast<unsigned char *>(p.out);
+				const int gy = y0 + 2 * pair + r;
+#pragma unroll
+				for (int it = 0; it < 2; ++it) {
+					const int pi = it * 16 + (lane >> 2);
+					const unsigned slot = static_cast<unsigned>(lane & 3);
+					const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & 3u);
+					const uint4 val = *reinterpret_cast<const uint4 *>(stage + pi * 64 + (slot << 4));
+					const int gx = x0 + pi;
+					if (pi < kFbOutW && gy < p.H && gx < p.W && !(p.skip & 16)) {
+						*reinterpret_cast<uint4 *>(outp + (((size_t)gy * p.outPitch + gx) * 64 + cb * 32) * 2 + chunk * 16) = val;
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	}
+}
+
+template <typename T>
+void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
+	auto kern = res_block_kernel<T>;
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kRbLds, &ldsDone, "res block");
+	static const int cus = [] {
+		int dev = 0, n = 256;
+		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+		return n;
+	}();
+	ResBlockParams p{};
+	p.in = q.in;
+	p.out = q.out;
+	p.w1 = q.w1;
+	p.w2 = q.w2;
+	p.b1 = q.b1;
+	p.b2 = q.b2;
+	p.H = q.H;
+	p.W = q.W;
+	p.inPitch = q.inPitch ? q.inPitch : q.W;
+	p.outPitch = q.outPitch ? q.outPitch : q.W;
+	p.tilesX = (q.W + kFbOutW - 1) / kFbOutW;
+	p.numTiles = p.tilesX * ((q.H + kRbTH - 1) / kRbTH);
+	p.s1 = q.act1 == 1 ? 0.0f : (q.act1 == 2 ? q.slope : 1.0f);
+	p.s2 = q.act2 == 1 ? 0.0f : (q.act2 == 2 ? q.slope : 1.0f);
+	static const int skipEnv = [] {
+		const char *e = std::getenv("JU_FB_SKIP");
+		return e ? std::atoi(e) : 0;
+	}();
+	p.skip = skipEnv;
+	const int grid = p.numTiles < cus ? p.numTiles : cus;
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kRbLds, stream, p);
+	hipCheckLaunch("res_block");
+}
+
 // 8 waves where the widest instantiation stays within 256 registers (two 64-channel
 // planes of conv A weights do not)
 template <int CIN>
@@ -513,12 +759,12 @@ constexpr int fbWaves() {
 	return CIN > 64 ? 4 : 8;
 }
 
-template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, bool OUTHEAD>
+template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK>
 void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
 	constexpr int NW = fbWaves<CIN>();
-	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTHEAD, NW>;
+	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, NW>;
 	static_assert(G::FITS, "tile does not fit LDS");
-	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTHEAD, NW>;
+	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTK, NW>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "flow block");
 	dim3 grid((p.W + kFbOutW - 1) / kFbOutW, (p.H + TH - 1) / TH);
@@ -528,17 +774,22 @@ void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
 
 // Tile height: the tall tile (18 rows: 11 % recompute ring) when the launch then still
 // fills the chip, the short one (6 rows) for small tensors.
-constexpr int kFbTall = 18, kFbShort = 6;
+constexpr int kFbTall = 18, kFbMid = 14, kFbShort = 6;
 
-template <typename T, int CIN, int CMID, bool UPS, bool POOL, bool OUTHEAD>
+template <typename T, int CIN, int CMID, bool UPS, bool POOL, int OUTK>
 void launchFlowBlockT(const FlowBlockParams &p, int numCUs, hipStream_t stream) {
 	const long tilesX = (p.W + kFbOutW - 1) / kFbOutW;
-	if constexpr (FbGeom<CIN, CMID, kFbTall, UPS, POOL, OUTHEAD, fbWaves<CIN>()>::FITS) {
+	if constexpr (FbGeom<CIN, CMID, kFbTall, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS) {
 		if (tilesX * ((p.H + kFbTall - 1) / kFbTall) * 10 >= 7L * numCUs) {
-			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTHEAD>(p, stream);
+			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTK>(p, stream);
+		}
+	} else if constexpr (FbGeom<CIN, CMID, kFbMid, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS && OUTK == 2) {
+		// (64 -> 64 -> 64: two 128-byte tiles; 14 rows is what fits)
+		if (tilesX * ((p.H + kFbMid - 1) / kFbMid) * 10 >= 7L * numCUs) {
+			return launchFlowBlockInst<T, CIN, CMID, kFbMid, UPS, POOL, OUTK>(p, stream);
 		}
 	}
-	launchFlowBlockInst<T, CIN, CMID, kFbShort, UPS, POOL, OUTHEAD>(p, stream);
+	launchFlowBlockInst<T, CIN, CMID, kFbShort, UPS, POOL, OUTK>(p, stream);
 }
 
 template <typename T>
@@ -552,6 +803,8 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.out = q.out;
 	p.H = q.H;
 	p.W = q.W;
+	p.inPitch = q.inPitch ? q.inPitch : (q.upsample ? q.W / 2 : q.W);
+	p.outPitch = q.outPitch ? q.outPitch : (q.pool ? q.W / 2 : q.W);
 	p.act1 = q.act1;
 	p.act2 = q.act2;
 	p.slope = q.slope;
@@ -568,16 +821,18 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	if (q.upsample && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused upsampling needs even H and W");
 	if (q.pool && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused max-pool needs even H and W");
 	// the shapes of the flow auto-encoder's fusable blocks (flowBlockSupported)
-#define JU_FB_CASE(CIN_, CMID_, UPS_, POOL_, F32_)                                                       \
-	if (q.cin == CIN_ && q.cmid == CMID_ && q.upsample == UPS_ && q.pool == POOL_ && q.outHead == F32_) { \
-		return launchFlowBlockT<T, CIN_, CMID_, UPS_, POOL_, F32_>(p, cus, stream);                        \
+	const int outk = q.residual ? 2 : (q.outHead ? 1 : 0);
+#define JU_FB_CASE(CIN_, CMID_, UPS_, POOL_, OUTK_)                                              \
+	if (q.cin == CIN_ && q.cmid == CMID_ && q.upsample == UPS_ && q.pool == POOL_ && outk == OUTK_) { \
+		return launchFlowBlockT<T, CIN_, CMID_, UPS_, POOL_, OUTK_>(p, cus, stream);                \
 	}
-	JU_FB_CASE(16, 32, false, true, false)   // encoder block 1: 12(16) -> 32 -> 32, pool
-	JU_FB_CASE(32, 64, false, true, false)   // encoder block 2: 32 -> 64 -> 64, pool
-	JU_FB_CASE(128, 64, true, false, false)  // last decoder block: up(128) -> 64 -> 64
-	JU_FB_CASE(128, 64, false, false, false)
-	JU_FB_CASE(64, 32, true, false, true)    // head: up(64) -> 32 -> 32 (f16 flow head)
-	JU_FB_CASE(64, 32, false, false, true)
+	JU_FB_CASE(16, 32, false, true, 0)   // encoder block 1: 12(16) -> 32 -> 32, pool
+	JU_FB_CASE(32, 64, false, true, 0)   // encoder block 2: 32 -> 64 -> 64, pool
+	JU_FB_CASE(128, 64, true, false, 0)  // last decoder block: up(128) -> 64 -> 64
+	JU_FB_CASE(128, 64, false, false, 0)
+	JU_FB_CASE(64, 32, true, false, 1)   // head: up(64) -> 32 -> 32 (f16 flow head)
+	JU_FB_CASE(64, 32, false, false, 1)
+	JU_FB_CASE(64, 64, false, false, 2)  // res_block of a 64-filter tower (generator, flow-resnet)
 #undef JU_FB_CASE
 	throw std::invalid_argument("flow block: unsupported shape");
 }
@@ -585,6 +840,7 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 }  // namespace
 
 bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHead) {
+	if (cin == 64 && cmid == 64) return false;  // (only as a residual block: FlowBlockLaunch::residual)
 	if (cin == 16 && cmid == 32) return !upsample && pool && !outHead;
 	if (cin == 32 && cmid == 64) return !upsample && pool && !outHead;
 	if (cin == 128 && cmid == 64) return !pool && !outHead;
@@ -593,6 +849,14 @@ bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHea
 }
 
 void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream) {
+	if (q.residual && q.cin == 64 && q.cmid == 64 && !q.upsample && !q.pool) {
+		static const char *mode = std::getenv("JU_RES_BLOCK");  // "tile": the non-persistent flow_block_kernel form (A/B)
+		if (!(mode && std::string(mode) == "tile")) {
+			if (dt == kF16) launchResBlockT<f16>(q, stream);
+			else launchResBlockT<bf16>(q, stream);
+			return;
+		}
+	}
 	if (dt == kF16) launchFlowBlockDT<f16>(q, stream);
 	else launchFlowBlockDT<bf16>(q, stream);
 }

@@ -119,8 +119,12 @@ struct FlowBlockLaunch {
 	const float *b2;
 	void *out;      // [H][W][cmid], pooled [H/2][W/2][cmid]; f16 when outHead
 	int H, W;       // the block's resolution (after the upsampling)
+	int inPitch, outPitch;  // row pitches in pixels of the tensors as stored (0 = dense)
 	int cin, cmid;  // cin padded to 16
 	bool upsample, pool, outHead;
+	// res_block (models.py:193-254): out = act(conv B(act(conv A(x))) + x), cin == cmid;
+	// in / out may be tower-layout tensors (interior origin + pitch)
+	bool residual;
 	int act1, act2;  // ConvParams::relu codes
 	float slope;
 };

@@ -159,11 +159,16 @@ def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
         rt.process_image(frames[0])
     assert all(np.array_equal(a, b) for a, b in zip(first, inter))
     rt2.close()
-    monkeypatch.setenv("JU_TOWER", "layers")            # per-layer tower kernels: same arithmetic
-    rt4 = R.Runtime(blob, 0, R.DTYPE_BF16)
-    layered = [rt4.process_image(f).copy() for f in frames]
-    assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(first, layered))
-    rt4.close()
+    # outside the resident tower: one launch per residual block ("layers": flow_block_kernel,
+    # intermediate tensor in LDS) or one per convolution ("convs"): same arithmetic
+    for mode, launches in (("layers", 3), ("convs", 6)):
+        monkeypatch.setenv("JU_TOWER", mode)
+        rt4 = R.Runtime(blob, 0, R.DTYPE_BF16)
+        assert rt4.stat("resident_tower") == 0
+        assert rt4.time_steps("tower", 0)[1] == launches
+        layered = [rt4.process_image(f).copy() for f in frames]
+        assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(first, layered))
+        rt4.close()
     monkeypatch.delenv("JU_TOWER")
     monkeypatch.setenv("JU_TAIL", "split")              # two-kernel tail: same arithmetic up to fp32 order
     rt5 = R.Runtime(blob, 0, R.DTYPE_BF16)
@@ -588,13 +593,16 @@ def test_flow_resnet_resident_and_per_layer_paths_agree(monkeypatch):
     fused = [rt.process_image(f).copy() for f in frames]
     flow_fused = rt.read_tensor("flow").copy()
     rt.close()
-    monkeypatch.setenv("JU_FLOW", "layers")
-    rt2 = R.Runtime(blob, 0, R.DTYPE_BF16)
-    layered = [rt2.process_image(f).copy() for f in frames]
-    flow_layered = rt2.read_tensor("flow").copy()
-    rt2.close()
-    assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(fused, layered))
-    assert err(flow_fused, flow_layered)["rel_to_max"] < 2e-2
+    for mode in ("layers", "convs"):      # one launch per residual block / per convolution
+        monkeypatch.setenv("JU_FLOW", mode)
+        rt2 = R.Runtime(blob, 0, R.DTYPE_BF16)
+        assert rt2.stat("resident_flow") == 0
+        layered = [rt2.process_image(f).copy() for f in frames]
+        flow_layered = rt2.read_tensor("flow").copy()
+        rt2.close()
+        assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(fused, layered))
+        assert err(flow_fused, flow_layered)["rel_to_max"] < 2e-2
+    monkeypatch.delenv("JU_FLOW")
     sess = O.Session(wts, oracle_config(cfg))
     for f, out in zip(frames, fused):
         check_u8(out, sess.run(f), R.DTYPE_BF16, "flowres-resident")
