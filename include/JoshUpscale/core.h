@@ -17,8 +17,8 @@
 //
 // Differences from the reference, all inside the implementation:
 //   * DataLocation::CUDA means "pointer valid on the HIP device" here;
-//   * GRAPHICS_RESOURCE images and the GL helpers throw std::runtime_error
-//     (interop is not implemented yet); there are no D3D11 entry points
+//   * GRAPHICS_RESOURCE images are OpenGL textures registered through HIP-GL
+//     interop (getGLImage / getGLDeviceIndex); there are no D3D11 entry points
 //     (Linux only);
 //   * processImage throws std::invalid_argument on a size mismatch instead of
 //     asserting (reference core/src/core.cc:179-182).
@@ -61,7 +61,7 @@ JOSHUPSCALE_EXPORT void setLogSink(LogSink *sink);
 enum class DataLocation : std::uint8_t {
 	CPU,               // host pointer
 	CUDA,              // device pointer: a HIP device pointer in this runtime
-	GRAPHICS_RESOURCE  // not supported here
+	GRAPHICS_RESOURCE  // an image from getGLImage (a registered OpenGL texture)
 };
 
 // 4 bytes per pixel, byte order B,G,R,X.  `stride` is in bytes and may be
@@ -86,10 +86,14 @@ protected:
 	Image m_Image = {};
 };
 
-// Both throw std::runtime_error in this runtime (see header comment).
+// The HIP device that drives the calling thread's current OpenGL context
+// (reference core/src/core.cc:140-149).
 JOSHUPSCALE_EXPORT int getGLDeviceIndex();
-JOSHUPSCALE_EXPORT GraphicsResourceImage *getGLImage(std::uint32_t glTexture,
-    GraphicsResourceImageType role);
+// Registers a 2-D BGRX / RGBA8 texture of the current OpenGL context (core.cc:92-138); the
+// caller owns the result (delete unregisters it).  processImage maps it for the duration
+// of its staging copy only.
+JOSHUPSCALE_EXPORT GraphicsResourceImage *getGLImage(std::uint32_t image,
+    GraphicsResourceImageType type);
 
 // ---------------------------------------------------------------- runtime --
 // One recurrent super-resolution stream.  Not thread-safe; processImage is

@@ -125,10 +125,26 @@ JU_API const char *ju_last_error(void);
 typedef void (*ju_log_callback)(const char *tag, int level, const char *message, void *user);
 JU_API void ju_set_log_callback(ju_log_callback callback, void *user);
 
-/* Replaces getGLDeviceIndex() / getGLImage() (core.h:60-62): graphics interop is
- * not available in this runtime yet; both report JU_ERR_UNSUPPORTED. */
+/* Replaces getGLDeviceIndex() (core.h:60, core/src/core.cc:140-149): the HIP device that
+ * drives the calling thread's current OpenGL context (hipGLGetDevices). */
 JU_API int ju_get_gl_device_index(int *out_device);
+
+/* Replaces getGLImage(image, type) (core.h:61-62, core.cc:92-138): registers an OpenGL
+ * 2-D texture (RGBA8 / BGRX, the caller's GL context current) with the HIP runtime
+ * (hipGraphicsGLRegisterImage; type 0 = input, read only; 1 = output, write discard) and
+ * describes it as a JU_LOC_GRAPHICS_RESOURCE image whose width / height are the
+ * texture's.  ju_process maps it, copies texture array <-> staging buffer and unmaps it
+ * (core/include/JoshUpscale/core/cuda.h:310-349, core/src/cuda_convert.cc.cu:380-397,
+ * 419-436).  Release with ju_release_gl_image (the reference's ~GLResourceImage). */
 JU_API int ju_get_gl_image(uint32_t gl_texture, int type, ju_image *out_image);
+JU_API void ju_release_gl_image(ju_image *image);
+
+/* Test double for the graphics path (no GL context exists on a headless GPU box): texture
+ * ids defined here resolve to pitched device buffers; device_ptr NULL removes the double
+ * again.  Counters: resources registered / currently mapped / map and unmap calls. */
+JU_API int ju_debug_fake_gl_texture(uint32_t gl_texture, void *device_ptr, size_t pitch, size_t width,
+    size_t height, int bytes_per_pixel);
+JU_API void ju_debug_fake_gl_counters(int *registered, int *mapped, int *maps, int *unmaps);
 
 /* ---- multi-GPU start-up (BASELINE.json config 4; no reference counterpart: the reference
  * has no distributed code).  N GPUs = N independent streams, one process per GPU; the ONLY

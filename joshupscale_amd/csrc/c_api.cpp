@@ -14,6 +14,7 @@
 
 #include "engine.h"
 #include "fp8.h"
+#include "graphics.h"
 #include "log.h"
 #include "model.h"
 
@@ -44,6 +45,8 @@ int guarded(F &&f) {
 		return fail(JU_ERR_IO, std::string("std::ios_base::failure: ") + e.what());
 	} catch (const std::bad_alloc &e) {
 		return fail(JU_ERR_INTERNAL, std::string("std::bad_alloc: ") + e.what());
+	} catch (const std::runtime_error &e) {
+		return fail(JU_ERR_INTERNAL, std::string("std::runtime_error: ") + e.what());
 	} catch (const std::exception &e) {
 		return fail(JU_ERR_INTERNAL, std::string("std::exception: ") + e.what());
 	} catch (...) {
@@ -171,12 +174,52 @@ void ju_set_log_callback(ju_log_callback callback, void *user) {
 
 int ju_get_gl_device_index(int *out_device) {
 	if (out_device) *out_device = -1;
-	return fail(JU_ERR_UNSUPPORTED, "std::runtime_error: OpenGL interop is not supported by the MI355X runtime");
+	return guarded([&] {
+		if (out_device == nullptr) throw std::invalid_argument("out_device is NULL");
+		*out_device = ju::graphicsBackend().deviceIndex();
+	});
 }
 
-int ju_get_gl_image(uint32_t, int, ju_image *out_image) {
+int ju_get_gl_image(uint32_t gl_texture, int type, ju_image *out_image) {
 	if (out_image) *out_image = ju_image{};
-	return fail(JU_ERR_UNSUPPORTED, "std::runtime_error: OpenGL interop is not supported by the MI355X runtime");
+	return guarded([&] {
+		if (out_image == nullptr) throw std::invalid_argument("out_image is NULL");
+		if (type != 0 && type != 1) throw std::invalid_argument("image type must be 0 (input) or 1 (output)");
+		ju::GraphicsBackend &backend = ju::graphicsBackend();
+		std::size_t w = 0, h = 0;
+		void *res = backend.registerImage(gl_texture, type, &w, &h);
+		out_image->ptr = new ju::GraphicsHandle{&backend, res};
+		out_image->location = JU_LOC_GRAPHICS_RESOURCE;
+		out_image->stride = 0;
+		out_image->width = w;
+		out_image->height = h;
+	});
+}
+
+void ju_release_gl_image(ju_image *image) {
+	if (image == nullptr || image->location != JU_LOC_GRAPHICS_RESOURCE || image->ptr == nullptr) return;
+	auto *h = static_cast<ju::GraphicsHandle *>(image->ptr);
+	try {
+		h->backend->unregisterImage(h->resource);
+	} catch (...) {
+	}
+	delete h;
+	image->ptr = nullptr;
+}
+
+int ju_debug_fake_gl_texture(uint32_t gl_texture, void *device_ptr, size_t pitch, size_t width, size_t height,
+    int bytes_per_pixel) {
+	return guarded([&] {
+		if (device_ptr == nullptr) {
+			ju::fakeGraphicsReset();
+			return;
+		}
+		ju::fakeGraphicsDefineTexture(gl_texture, device_ptr, pitch, width, height, bytes_per_pixel);
+	});
+}
+
+void ju_debug_fake_gl_counters(int *registered, int *mapped, int *maps, int *unmaps) {
+	ju::fakeGraphicsCounters(registered, mapped, maps, unmaps);
 }
 
 int ju_get_dtype(const ju_runtime *runtime) {

@@ -111,12 +111,32 @@ void setLogSink(LogSink *sink) {
 
 int getGLDeviceIndex() {
 	int dev = -1;
-	raise(ju_get_gl_device_index(&dev));
+	const int rc = ju_get_gl_device_index(&dev);
+	if (rc != JU_OK) raise(rc);
+	return dev;
 }
 
+namespace {
+// reference core/src/core.cc:92-131 (GLResourceImage)
+struct GLResourceImage final : GraphicsResourceImage {
+	GLResourceImage(std::uint32_t image, GraphicsResourceImageType type) {
+		const int rc = ju_get_gl_image(image, static_cast<int>(type), &m_C);
+		if (rc != JU_OK) raise(rc);
+		m_Image.ptr = m_C.ptr;
+		m_Image.location = DataLocation::GRAPHICS_RESOURCE;
+		m_Image.stride = 0;
+		m_Image.width = m_C.width;
+		m_Image.height = m_C.height;
+	}
+	~GLResourceImage() override { ju_release_gl_image(&m_C); }
+
+private:
+	ju_image m_C{};
+};
+}  // namespace
+
 GraphicsResourceImage *getGLImage(std::uint32_t image, GraphicsResourceImageType type) {
-	ju_image img{};
-	raise(ju_get_gl_image(image, static_cast<int>(type), &img));
+	return new GLResourceImage(image, type);
 }
 
 Runtime *createRuntime(int deviceId, const std::filesystem::path &modelPath) {

@@ -7,6 +7,7 @@
 #include <stdexcept>
 
 #include "fp8.h"
+#include "graphics.h"
 #include "log.h"
 
 namespace ju {
@@ -892,11 +893,37 @@ FrameSize Engine::frameSize() const {
 	return {w, h, w * 4, h * 4};
 }
 
+namespace {
+// Scoped map of a graphics resource on the engine's stream (cuda.h:310-349 GraphicsResource):
+// unmapped again when the copy has been enqueued, also when that throws.
+struct MappedResource {
+	GraphicsHandle *h;
+	hipStream_t stream;
+	GraphicsArray array;
+	MappedResource(void *handle, hipStream_t s) : h(static_cast<GraphicsHandle *>(handle)), stream(s) {
+		if (h == nullptr || h->backend == nullptr) throw std::invalid_argument("processImage: NULL graphics resource");
+		array = h->backend->map(h->resource, stream);
+	}
+	~MappedResource() { h->backend->unmap(h->resource, stream); }
+	MappedResource(const MappedResource &) = delete;
+	MappedResource &operator=(const MappedResource &) = delete;
+};
+}  // namespace
+
 void Engine::stageIn(const Frame &in) {
 	const FrameSize fs = frameSize();
 	if (in.location == Location::GraphicsResource) {
-		throw std::invalid_argument(
-		    "processImage: GRAPHICS_RESOURCE images are not supported by this runtime");
+		// map -> texture array -> staging buffer -> unmap (cuda_convert.h:57-77,
+		// cuda_convert.cc.cu:380-397); the array's own extent is what counts
+		MappedResource m(in.ptr, m_Stream);
+		if (!m.array.fourBytes || m.array.width != fs.inputWidth || m.array.height != fs.inputHeight ||
+		    in.width != fs.inputWidth || in.height != fs.inputHeight) {
+			throw std::invalid_argument("processImage: input texture must be " + std::to_string(fs.inputWidth) + "x" +
+			                            std::to_string(fs.inputHeight) + " with four 8-bit channels");
+		}
+		m.h->backend->copyFromArray(m_InStage.get(), fs.inputWidth * 4, m.array, fs.inputWidth * 4, fs.inputHeight,
+		    m_Stream);
+		return;
 	}
 	if (in.ptr == nullptr || in.width != fs.inputWidth || in.height != fs.inputHeight) {
 		throw std::invalid_argument("processImage: input image must be exactly " +
@@ -943,9 +970,16 @@ void Engine::stageIn(const Frame &in) {
 
 void Engine::stageOut(const Frame &out) {
 	const FrameSize fs = frameSize();
-	if (out.location == Location::GraphicsResource) {
-		throw std::invalid_argument(
-		    "processImage: GRAPHICS_RESOURCE images are not supported by this runtime");
+	if (out.location == Location::GraphicsResource) {  // cuda_convert.cc.cu:419-436
+		MappedResource m(out.ptr, m_Stream);
+		if (!m.array.fourBytes || m.array.width != fs.outputWidth || m.array.height != fs.outputHeight ||
+		    out.width != fs.outputWidth || out.height != fs.outputHeight) {
+			throw std::invalid_argument("processImage: output texture must be " + std::to_string(fs.outputWidth) + "x" +
+			                            std::to_string(fs.outputHeight) + " with four 8-bit channels");
+		}
+		m.h->backend->copyToArray(m.array, m_OutStage.get(), fs.outputWidth * 4, fs.outputWidth * 4, fs.outputHeight,
+		    m_Stream);
+		return;
 	}
 	if (out.ptr == nullptr || out.width != fs.outputWidth || out.height != fs.outputHeight) {
 		throw std::invalid_argument("processImage: output image must be exactly " +

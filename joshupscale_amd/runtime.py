@@ -87,6 +87,10 @@ def load_library() -> C.CDLL:
         "ju_set_log_callback": (None, [LOG_CALLBACK, C.c_void_p]),
         "ju_get_gl_device_index": (C.c_int, [P(C.c_int)]),
         "ju_get_gl_image": (C.c_int, [C.c_uint32, C.c_int, P(JuImage)]),
+        "ju_release_gl_image": (None, [P(JuImage)]),
+        "ju_debug_fake_gl_texture": (C.c_int, [C.c_uint32, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                               C.c_int]),
+        "ju_debug_fake_gl_counters": (None, [P(C.c_int)] * 4),
         "ju_get_dtype": (C.c_int, [C.c_void_p]),
         "ju_debug_e4m3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "ju_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
@@ -280,6 +284,19 @@ class Comm:
             self.close()
         except Exception:  # pragma: no cover
             pass
+
+
+def gl_image(texture: int, output: bool) -> JuImage:
+    """``ju_get_gl_image`` (``getGLImage``, reference core.h:61-62): a registered OpenGL
+    texture as a GRAPHICS_RESOURCE image.  Release with :func:`release_gl_image`."""
+    lib = load_library()
+    img = JuImage()
+    _check(lib, lib.ju_get_gl_image(texture, 1 if output else 0, C.byref(img)))
+    return img
+
+
+def release_gl_image(img: JuImage) -> None:
+    load_library().ju_release_gl_image(C.byref(img))
 
 
 def host_image(arr: np.ndarray) -> JuImage:

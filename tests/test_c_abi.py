@@ -50,7 +50,13 @@ def test_version_and_error_paths_without_gpu(hip_library, tmp_path):
     assert rc == 2 and not h.value                      # JU_ERR_IO
     assert b"cannot open model file" in hip_library.ju_last_error()
     assert hip_library.ju_process(None, None, None) == 1  # JU_ERR_INVALID_ARGUMENT
-    assert hip_library.ju_get_gl_device_index(None) == 4  # JU_ERR_UNSUPPORTED
+    assert hip_library.ju_get_gl_device_index(None) == 1  # JU_ERR_INVALID_ARGUMENT
+    dev = C.c_int(7)
+    assert hip_library.ju_get_gl_device_index(C.byref(dev)) in (3, 5) and dev.value == -1   # no GPU / no GL context here
+    img = R.JuImage()
+    assert hip_library.ju_get_gl_image(1, 0, C.byref(img)) != 0 and not img.ptr          # no current GL context
+    assert hip_library.ju_get_gl_image(1, 9, C.byref(img)) == 1                           # bad image type
+    hip_library.ju_release_gl_image(C.byref(img))                                          # no-op on an empty image
     hip_library.ju_destroy(None)                          # no-op
 
 

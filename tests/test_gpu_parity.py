@@ -226,7 +226,7 @@ def test_error_reporting():
     with pytest.raises(R.JoshUpscaleError) as e:
         rt.process(R.JuImage(None, R.LOC_GRAPHICS_RESOURCE, 192, 48, 30),
                    R.host_image(np.zeros((120, 192, 4), np.uint8)))
-    assert "GRAPHICS_RESOURCE" in e.value.message
+    assert "NULL graphics resource" in e.value.message
     assert rt.process_image(np.zeros((30, 48, 4), np.uint8)).shape == (120, 192, 4)  # still usable
     rt.close()
 
@@ -509,6 +509,84 @@ def test_flow_blocks_fused_and_per_layer_paths_agree(monkeypatch, dtype):
             # summation orders propagates through the 14 layers, so their distance is of that order)
             e = err(a, b)
             assert e["max_abs"] <= TOL[dtype]["flow"] and e["rms"] <= 0.2 * TOL[dtype]["flow"], e
+
+
+def test_graphics_resource_frames_through_the_test_double():
+    """DataLocation::GRAPHICS_RESOURCE (what the OBS plugin passes on Linux: registered
+    OpenGL textures; reference core.cc:92-149, cuda.h:310-349, cuda_convert.cc.cu:380-397,
+    419-436, obs_plugin/src/filter.cc:242-279).  No GL context can exist on a headless GPU
+    box, so the textures are a test double (pitched device buffers behind texture ids): the
+    engine's plumbing -- register, map, array <-> staging copy, unmap, size / format checks,
+    unregister -- runs for real; the HIP-GL calls themselves do not (untested on hardware)."""
+    import torch
+    lib = R.load_library()
+    cfg = small_config()
+    _, blob, rt = make(cfg, R.DTYPE_F16)
+    h, w = 30, 48
+    frames = M.synthetic_frames(3, h, w, seed=71, kind="smooth")
+    want = [rt.process_image(f).copy() for f in frames]
+    rt.reset()
+    dev = torch.device("cuda", 0)
+    in_pitch, out_pitch = w * 4 + 64, 4 * w * 4 + 128
+    tex_in = torch.zeros((h, in_pitch), dtype=torch.uint8, device=dev)
+    tex_out = torch.full((4 * h, out_pitch), 0xAB, dtype=torch.uint8, device=dev)
+    tex_small = torch.zeros((h, w * 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    counters = lambda: tuple(c.value for c in _gl_counters(lib))
+    try:
+        assert lib.ju_debug_fake_gl_texture(11, tex_in.data_ptr(), in_pitch, w, h, 4) == 0
+        assert lib.ju_debug_fake_gl_texture(12, tex_out.data_ptr(), out_pitch, 4 * w, 4 * h, 4) == 0
+        assert lib.ju_debug_fake_gl_texture(13, tex_small.data_ptr(), w * 4, w - 1, h, 4) == 0      # wrong size
+        assert lib.ju_debug_fake_gl_texture(14, tex_small.data_ptr(), w * 2, w, h, 2) == 0          # RG8, not RGBA8
+        img_in, img_out = R.gl_image(11, output=False), R.gl_image(12, output=True)
+        assert (img_in.location, img_in.width, img_in.height) == (R.LOC_GRAPHICS_RESOURCE, w, h)
+        assert (img_out.width, img_out.height) == (4 * w, 4 * h)
+        assert counters()[:2] == (2, 0)
+        for t, f in enumerate(frames):
+            tex_in[:, :w * 4] = torch.from_numpy(f.reshape(h, w * 4)).to(dev)
+            torch.cuda.synchronize()
+            rt.process(img_in, img_out)                  # texture -> staging -> engine -> staging -> texture
+            got = tex_out.cpu().numpy()
+            assert np.array_equal(got[:, :4 * w * 4].reshape(4 * h, 4 * w, 4), want[t])
+            assert (got[:, 4 * w * 4:] == 0xAB).all()    # the row padding of the "texture" is untouched
+        reg, mapped, maps, unmaps = counters()
+        assert (reg, mapped) == (2, 0) and maps == unmaps == 2 * len(frames)
+        # a texture and a host frame can be mixed (OBS falls back to either)
+        rt.reset()
+        tex_in[:, :w * 4] = torch.from_numpy(frames[0].reshape(h, w * 4)).to(dev)
+        torch.cuda.synchronize()
+        out_host = np.empty((4 * h, 4 * w, 4), np.uint8)
+        rt.process(img_in, R.host_image(out_host))
+        assert np.array_equal(out_host, want[0])
+        # errors: unknown texture, wrong size, wrong format, output into an input resource
+        with pytest.raises(R.JoshUpscaleError, match="Failed to bind texture"):
+            R.gl_image(99, output=False)
+        bad = R.gl_image(13, output=False)
+        with pytest.raises(R.JoshUpscaleError, match="input texture must be 48x30"):
+            rt.process(bad, img_out)
+        R.release_gl_image(bad)
+        bad = R.gl_image(14, output=False)
+        with pytest.raises(R.JoshUpscaleError, match="four 8-bit channels"):
+            rt.process(bad, img_out)
+        R.release_gl_image(bad)
+        ro = R.gl_image(12, output=False)
+        with pytest.raises(R.JoshUpscaleError, match="read-only"):
+            rt.process(img_in, ro)
+        R.release_gl_image(ro)
+        assert counters()[1] == 0                        # every failed call unmapped what it mapped
+        assert np.array_equal(rt.process_image(frames[0]).shape, (4 * h, 4 * w, 4))   # still usable
+        R.release_gl_image(img_in)
+        R.release_gl_image(img_out)
+        assert counters()[0] == 0 and not img_in.ptr
+    finally:
+        lib.ju_debug_fake_gl_texture(0, None, 0, 0, 0, 0)    # remove the double
+    rt.close()
+
+
+def _gl_counters(lib):
+    vals = [C.c_int() for _ in range(4)]
+    lib.ju_debug_fake_gl_counters(*[C.byref(v) for v in vals])
+    return vals
 
 
 def test_long_sequence_does_not_drift():
