@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 
@@ -45,7 +46,35 @@ Engine::Operand Engine::operand(const std::string &name) {
 
 namespace {
 int padTo16(int c) { return (c + 15) / 16 * 16; }
+
+// Runtimes of this process per device, and the completion event of the frame submitted
+// last by one that uses the resident tower (Engine::chainBefore / chainAfter).
+struct DeviceChain {
+	int engines = 0;
+	const void *lastOwner = nullptr;
+	hipEvent_t last = nullptr;
+};
+std::mutex g_ChainMutex;
+std::map<int, DeviceChain> g_Chains;
 }  // namespace
+
+void Engine::chainBefore() {
+	std::lock_guard<std::mutex> lock(g_ChainMutex);
+	DeviceChain &c = g_Chains[m_Device];
+	if (c.engines > 1 && m_Resident && c.last != nullptr && c.lastOwner != this) {
+		JU_HIP(hipStreamWaitEvent(m_Stream, c.last, 0));
+	}
+}
+
+void Engine::chainAfter() {
+	std::lock_guard<std::mutex> lock(g_ChainMutex);
+	DeviceChain &c = g_Chains[m_Device];
+	if (c.engines > 1 && m_Resident) {
+		m_FrameDone.record(m_Stream);
+		c.last = m_FrameDone.get();
+		c.lastOwner = this;
+	}
+}
 
 // Which units of the flow auto-encoder (models.py:334-481) run as one launch each.
 void Engine::planFlowUnits() {
@@ -266,10 +295,9 @@ void Engine::buildProgram(int set) {
 		prog.push_back({"pack", 0.0,
 		    [=](hipStream_t s) { launchFrameSums(io->in, io->inStride, H, W, sumsOut, s); }});
 	}
-	unsigned *generation = m_Resident ? m_ResFlags.as<unsigned>() : nullptr;
 	prog.push_back({"pack", 0.0, [=](hipStream_t s) {
 		                launchPackFrames(dt, io->in, io->inStride, packedIn, packedOut, H, W, PH, PW,
-		                    padTop, padLeft, nIn, sums, generation, s);
+		                    padTop, padLeft, nIn, sums, s);
 	                }});
 	// one launch for a 64-filter residual block outside the resident tower
 	auto addResBlockStep = [&](const std::string &tag, const std::string &block, Operand in, Operand out,
@@ -419,7 +447,7 @@ void Engine::buildProgram(int set) {
 		if (upsampleNext) throw std::logic_error("flow head cannot take a half-resolution input");
 	} else if (m_ResidentFlow) {
 		// flow-resnet body = conv_1 + residual blocks, 64 filters: ONE launch of the
-		// resident tower kernel (own mailbox and generation word)
+		// resident tower kernel (own mailbox and publish counters)
 		void *in64 = T("flow/in64");
 		prog.push_back({"flow", 0.0,
 		    [=](hipStream_t s) { launchExpandChannels(dt, packedOut, in64, PH * PW, s); }});
@@ -431,7 +459,7 @@ void Engine::buildProgram(int set) {
 		rp.weights = m_FlowTowerW.get();
 		rp.bias = m_FlowTowerB.as<float>();
 		rp.mailbox = m_FlowMail.get();
-		rp.generation = m_FlowFlags.as<unsigned>();
+		rp.counters = m_FlowFlags.as<unsigned>();
 		rp.error = m_ResErrorDev;
 		rp.debug = m_Tensors.at("tower_profile").buf.get();
 		rp.H = PH;
@@ -440,7 +468,6 @@ void Engine::buildProgram(int set) {
 		rp.GY = m_FlowGY;
 		rp.RH = m_FlowRH;
 		rp.nLayers = 1 + 2 * c.flowResBlocks;
-		rp.bumpGeneration = 1;  // (pack_frames bumps the generator tower's word only)
 		prog.push_back({"flow",
 		    2.0 * PH * PW * 9.0 * (3.0 * c.numFlowInputs * 64 + 64.0 * 64 * 2 * c.flowResBlocks),
 		    [=](hipStream_t s) { launchResidentTower(dt, rp, s); }});
@@ -484,7 +511,7 @@ void Engine::buildProgram(int set) {
 	int a = 0;
 	bool tailInTower = false;
 	if (m_Resident) {
-		// one launch for the whole tower (plus the 1-thread generation bump)
+		// one launch for the whole tower
 		ResidentTowerParams rp{};
 		rp.in = Op("gen_in").ptr;  // dense [H][W][64]; conv_1 is layer 0 of the launch
 		rp.inPitch = W;
@@ -493,7 +520,7 @@ void Engine::buildProgram(int set) {
 		rp.weights = m_TowerW.get();
 		rp.bias = m_TowerB.as<float>();
 		rp.mailbox = m_ResMail.get();
-		rp.generation = m_ResFlags.as<unsigned>();
+		rp.counters = m_ResFlags.as<unsigned>();
 		rp.error = m_ResErrorDev;
 		rp.debug = m_Tensors.at("tower_profile").buf.get();
 		rp.H = H;
@@ -502,7 +529,6 @@ void Engine::buildProgram(int set) {
 		rp.GY = m_ResGY;
 		rp.RH = m_ResRH;
 		rp.nLayers = 1 + 2 * c.genBlocks;
-		rp.bumpGeneration = 0;  // pack_frames, the first kernel of the frame, bumps it
 		tailInTower = m_FusedTail && m_TailInTower && c.genFilters == 64;
 		if (tailInTower) {  // the tail runs on the tower's LDS-resident last layer
 			rp.tailW1 = m_Convs.at("generator/conv_trans_1").w.get();
@@ -686,14 +712,13 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		}
 		if (wanted && c.genFilters == 64 && c.genBlocks >= 1 &&
 		    residentTowerGeometry(c.frameHeight, c.frameWidth, cus, &m_ResGX, &m_ResGY, &m_ResRH)) {
-			m_Resident = true;
+			m_Resident = m_ResidentCapable = true;
 			m_TowerW = DeviceBuffer(m_TowerHostW.size() * 2);
 			m_TowerW.upload(m_TowerHostW.data(), m_TowerHostW.size() * 2);
 			m_TowerB = DeviceBuffer(m_TowerHostB.size() * 4);
 			m_TowerB.upload(m_TowerHostB.data(), m_TowerHostB.size() * 4);
 			m_ResMail = DeviceBuffer(residentMailboxBytes(m_ResGX, m_ResGY));
-			// word 0: launch generation; from byte 64: one flag word per region
-			m_ResFlags = DeviceBuffer(64 + (static_cast<std::size_t>(m_ResGX) * m_ResGY * 4 + 15) / 16 * 16);
+			m_ResFlags = DeviceBuffer(residentCounterBytes(m_ResGX, m_ResGY));  // publish counts per region
 			m_ResError = PinnedWords(64);
 			m_ResErrorDev = m_ResError.device();
 		}
@@ -706,13 +731,13 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		    c.flowActivation == 0 &&
 		    c.flowResFilters == 64 && c.flowResBlocks >= 1 && 3 * c.numFlowInputs <= 64 &&
 		    residentTowerGeometry(PH, PW, cus, &m_FlowGX, &m_FlowGY, &m_FlowRH)) {
-			m_ResidentFlow = true;
+			m_ResidentFlow = m_ResidentFlowCapable = true;
 			m_FlowTowerW = DeviceBuffer(m_FlowTowerHostW.size() * 2);
 			m_FlowTowerW.upload(m_FlowTowerHostW.data(), m_FlowTowerHostW.size() * 2);
 			m_FlowTowerB = DeviceBuffer(m_FlowTowerHostB.size() * 4);
 			m_FlowTowerB.upload(m_FlowTowerHostB.data(), m_FlowTowerHostB.size() * 4);
 			m_FlowMail = DeviceBuffer(residentMailboxBytes(m_FlowGX, m_FlowGY));
-			m_FlowFlags = DeviceBuffer(64 + (static_cast<std::size_t>(m_FlowGX) * m_FlowGY * 4 + 15) / 16 * 16);
+			m_FlowFlags = DeviceBuffer(residentCounterBytes(m_FlowGX, m_FlowGY));
 		}
 		m_FlowTowerHostW.clear();
 		m_FlowTowerHostW.shrink_to_fit();
@@ -800,6 +825,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_PreferDirect = !(direct && direct[0] == '0');
 	const char *noGraph = std::getenv("JU_NO_GRAPH");
 	m_UseGraph = !(noGraph && noGraph[0] == '1');
+	if (const char *retry = std::getenv("JU_RESIDENT_RETRY")) m_RetryBase = static_cast<unsigned>(std::atoi(retry));
 	const char *directGraph = std::getenv("JU_DIRECT_GRAPH");
 	m_DirectGraph = !(directGraph && directGraph[0] == '0');
 	if (const char *spin = std::getenv("JU_SYNC_SPIN_US")) m_SpinUs = static_cast<unsigned>(std::atoi(spin));
@@ -810,6 +836,10 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 			});
 		}
 		m_Stream.synchronize();
+	}
+	{
+		std::lock_guard<std::mutex> lock(g_ChainMutex);
+		++g_Chains[m_Device].engines;
 	}
 	std::ostringstream ss;
 	ss << "engine ready: " << W << "x" << H << " -> " << 4 * W << "x" << 4 * H << ", "
@@ -823,6 +853,15 @@ Engine::~Engine() {
 	try {
 		DeviceGuard g(m_Device);
 		(void)hipStreamSynchronize(m_Stream);
+		std::lock_guard<std::mutex> lock(g_ChainMutex);
+		auto it = g_Chains.find(m_Device);
+		if (it != g_Chains.end()) {
+			if (it->second.lastOwner == this) {  // (its event dies with this engine; the work behind it is done)
+				it->second.last = nullptr;
+				it->second.lastOwner = nullptr;
+			}
+			if (it->second.engines > 0) --it->second.engines;
+		}
 	} catch (...) {
 	}
 }
@@ -843,11 +882,22 @@ void Engine::fallbackToLayers(unsigned code) {
 	ss << "resident tower kernel: a bounded wait on a neighbouring workgroup expired (code 0x"
 	   << std::hex << code << std::dec << "); " << m_ResGX * m_ResGY
 	   << " workgroups are not all co-resident on this device. Switching to the per-layer tower "
-	      "kernels (slower) for the rest of this runtime's life";
+	      "kernels (slower)";
+	++m_Fallbacks;
+	m_CleanFrames = 0;
+	// retry after 512, 2048, 8192, ... clean frames
+	m_RetryAfter = m_RetryBase ? std::min<std::uint64_t>(std::uint64_t(m_RetryBase) << (2 * std::min(m_Fallbacks - 1, 8u)), 1u << 30) : 0;
+	if (m_RetryAfter) ss << "; the resident kernel will be tried again after " << m_RetryAfter << " frames";
 	logMessage(LogLevel::Warning, "Engine", ss.str());
 	m_Resident = false;
 	m_ResidentFlow = false;
 	m_DirectGraphs.clear();  // they replay the resident program
+	// the aborted launch left the slot epochs of the regions out of step: start them over
+	m_ResMail.zeroAsync(m_Stream);
+	m_ResFlags.zeroAsync(m_Stream);
+	m_FlowMail.zeroAsync(m_Stream);
+	m_FlowFlags.zeroAsync(m_Stream);
+	m_Stream.synchronize();
 	for (int s = 0; s < 2; ++s) {
 		m_Graph[s] = GraphExec();
 		buildProgram(s);
@@ -874,6 +924,44 @@ void Engine::fallbackToLayers(unsigned code) {
 		}
 		m_Stream.synchronize();
 		m_IO = keep;
+	}
+}
+
+// Back to the one-launch tower after enough clean frames on the fallback path.
+void Engine::restoreResident() {
+	m_Stream.synchronize();
+	m_Resident = true;
+	m_ResidentFlow = m_ResidentFlowCapable;
+	m_CleanFrames = 0;
+	m_DirectGraphs.clear();
+	m_ResMail.zeroAsync(m_Stream);
+	m_ResFlags.zeroAsync(m_Stream);
+	m_FlowMail.zeroAsync(m_Stream);
+	m_FlowFlags.zeroAsync(m_Stream);
+	for (int s = 0; s < 2; ++s) {
+		m_Graph[s] = GraphExec();
+		buildProgram(s);
+	}
+	if (m_UseGraph) {  // (the resident kernels ran before: nothing sets an attribute inside the capture)
+		const FrameIO keep = m_IO;
+		m_IO.in = m_InStage.as<std::uint8_t>();
+		m_IO.inStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 4;
+		m_IO.out = m_OutStage.as<std::uint8_t>();
+		m_IO.outStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 16;
+		for (int s = 0; s < 2; ++s) {
+			m_Graph[s] = GraphExec::capture(m_Stream, [&] {
+				for (const Step &st : m_Program[s]) st.run(m_Stream);
+			});
+		}
+		m_IO = keep;
+	}
+	m_Stream.synchronize();
+	logMessage(LogLevel::Info, "Engine", "trying the resident tower kernel again");
+}
+
+void Engine::maybeRestoreResident() {
+	if (!m_Resident && m_ResidentCapable && m_RetryAfter != 0 && ++m_CleanFrames >= m_RetryAfter) {
+		restoreResident();
 	}
 }
 
@@ -1073,6 +1161,7 @@ void Engine::submit(const Frame &in, const Frame &out) {
 	                 -out.stride >= static_cast<std::ptrdiff_t>(fs.outputWidth * 4)) &&
 	             (reinterpret_cast<std::uintptr_t>(in.ptr) % 4 == 0) && in.stride % 4 == 0 &&
 	             (reinterpret_cast<std::uintptr_t>(out.ptr) % 8 == 0) && out.stride % 8 == 0;
+	chainBefore();
 	if (m_DirectIO) {
 		m_IO.in = static_cast<const std::uint8_t *>(in.ptr);
 		m_IO.inStride = in.stride;
@@ -1088,6 +1177,7 @@ void Engine::submit(const Frame &in, const Frame &out) {
 		runProgram();
 		stageOut(out);
 	}
+	chainAfter();
 	m_Idx ^= 1;  // state ping-pong (tensorrt_backend.cc:277)
 }
 
@@ -1109,6 +1199,8 @@ void Engine::process(const Frame &in, const Frame &out) {
 		fallbackToLayers(code);
 		submit(in, out);
 		m_Stream.synchronize();
+	} else {
+		maybeRestoreResident();
 	}
 }
 
@@ -1218,19 +1310,14 @@ double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
 	}
 	if (launches) *launches = static_cast<int>(steps.size());
 	if (steps.empty() || iters <= 0) return 0.0;
-	// Run in isolation the tower never sees pack_frames, which bumps the launch
-	// generation of its halo tags: do it here, or stale slots would match at once.
-	const bool bump = m_Resident && tag == "tower";
 	m_IO.in = m_InStage.as<std::uint8_t>();
 	m_IO.inStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 4;
 	m_IO.out = m_OutStage.as<std::uint8_t>();
 	m_IO.outStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 16;
-	if (bump) launchBumpGeneration(m_ResFlags.as<unsigned>(), m_Stream);
 	for (const Step *s : steps) s->run(m_Stream);  // warm
 	Event t0, t1;
 	t0.record(m_Stream);
 	for (int i = 0; i < iters; ++i) {
-		if (bump) launchBumpGeneration(m_ResFlags.as<unsigned>(), m_Stream);
 		for (const Step *s : steps) s->run(m_Stream);
 	}
 	t1.record(m_Stream);
@@ -1256,6 +1343,7 @@ double Engine::stat(const std::string &key) const {
 	if (key == "eager_runs") return static_cast<double>(m_EagerRuns);
 	if (key == "resident_tower") return m_Resident ? 1.0 : 0.0;
 	if (key == "resident_flow") return m_ResidentFlow ? 1.0 : 0.0;
+	if (key == "fallbacks") return static_cast<double>(m_Fallbacks);
 	if (key == "launches_per_frame") return static_cast<double>(m_Program[0].size());
 	if (key == "direct_graphs") {
 		double n = 0;

@@ -198,6 +198,22 @@ private:
 	std::vector<std::uint16_t> m_FlowTowerHostW;
 	std::vector<float> m_FlowTowerHostB;
 	DeviceBuffer m_FlowTowerW, m_FlowTowerB, m_FlowMail, m_FlowFlags;
+	// The resident tower needs every workgroup co-resident.  When a bounded wait expires the
+	// engine drops to the per-block kernels (fallbackToLayers) -- not for good: after
+	// m_RetryAfter clean frames it tries the resident kernel again (the CUs may have been
+	// taken only temporarily, e.g. by another process), backing off x4 after every failure.
+	// JU_RESIDENT_RETRY=<frames> sets the first interval (default 512, 0 = never retry).
+	bool m_ResidentCapable = false, m_ResidentFlowCapable = false;
+	unsigned m_RetryBase = 512, m_RetryAfter = 0, m_CleanFrames = 0, m_Fallbacks = 0;
+	void restoreResident();
+	void maybeRestoreResident();
+	// Two resident towers cannot share the GPU (each wants a workgroup on every CU and both
+	// would wait for workgroups that cannot be scheduled).  Runtimes of one process on one
+	// device therefore chain their frames through events when more than one of them uses the
+	// resident kernel; a single runtime pays nothing.
+	Event m_FrameDone;
+	void chainBefore();
+	void chainAfter();
 	PinnedWords m_ResError;              // pinned, device-visible: word 0 = the tower's error report
 	unsigned *m_ResErrorDev = nullptr;
 	unsigned takeResidentError();        // 0 = none; clears it
@@ -234,6 +250,7 @@ private:
 	std::uint64_t m_GraphReplays = 0, m_EagerRuns = 0;  // introspection ("graph_replays" / "eager_runs")
 
 public:
+	std::uint64_t fallbacks() const { return m_Fallbacks; }
 	// counters of how the per-frame program ran so far (tests, bench)
 	std::uint64_t graphReplays() const { return m_GraphReplays; }
 	std::uint64_t eagerRuns() const { return m_EagerRuns; }

@@ -65,12 +65,8 @@ __global__ __launch_bounds__(256) void expand_channels_kernel(const uint4 *__res
 template <typename T>
 __global__ __launch_bounds__(256) void pack_frames_kernel(const std::uint8_t *__restrict__ frame,
     std::ptrdiff_t frameStride, const T *__restrict__ prev, T *__restrict__ cur, int H, int W,
-    int PH, int PW, int padTop, int padLeft, int numInputs, const unsigned *__restrict__ sums,
-    unsigned *generation) {
+    int PH, int PW, int padTop, int padLeft, int numInputs, const unsigned *__restrict__ sums) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
-	// first kernel of every frame: bump the launch generation the resident tower tags
-	// its halo slots with (saves a 1-thread launch)
-	if (idx == 0 && generation != nullptr) *generation = *generation + 1;
 	if (idx >= PH * PW) return;
 	const float bright = brightnessOf(sums, 1.0f / static_cast<float>(H * W));
 	const int py = idx / PW;
@@ -631,17 +627,17 @@ __global__ __launch_bounds__(256) void to_float_kernel(
 
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
-    int padLeft, int numInputs, const unsigned *sums, unsigned *generation,
+    int padLeft, int numInputs, const unsigned *sums,
     hipStream_t stream) {
 	const unsigned nb = blocksFor((size_t)PH * PW);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(pack_frames_kernel<f16>, dim3(nb), dim3(256), 0, stream, frame,
 		    frameStride, static_cast<const f16 *>(prevPacked), static_cast<f16 *>(curPacked), H, W,
-		    PH, PW, padTop, padLeft, numInputs, sums, generation);
+		    PH, PW, padTop, padLeft, numInputs, sums);
 	} else {
 		hipLaunchKernelGGL(pack_frames_kernel<bf16>, dim3(nb), dim3(256), 0, stream, frame,
 		    frameStride, static_cast<const bf16 *>(prevPacked), static_cast<bf16 *>(curPacked), H,
-		    W, PH, PW, padTop, padLeft, numInputs, sums, generation);
+		    W, PH, PW, padTop, padLeft, numInputs, sums);
 	}
 	hipCheckLaunch("pack_frames");
 }

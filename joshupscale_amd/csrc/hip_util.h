@@ -242,6 +242,7 @@ private:
 class Event {
 public:
 	Event() { JU_HIP(hipEventCreate(&m_Event)); }
+	hipEvent_t get() const { return m_Event; }
 	~Event() {
 		if (m_Event) (void)hipEventDestroy(m_Event);
 	}

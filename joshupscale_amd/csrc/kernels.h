@@ -161,10 +161,11 @@ void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int
 // weights: nLayers consecutive 64->64 3x3 kernels in packConvWeights (nb = 2)
 // order, bias nLayers x 64.  hasHead: layer 0 is a plain conv+ReLU (generator
 // conv_1), residual blocks (conv, conv + skip) follow.
-// mailbox (residentMailboxBytes, zeroed once) carries the halo exchange between
-// neighbouring workgroups as tagged granules; *generation (one zero-initialised
-// device word) is bumped by every launch so tags never repeat; *error is written
-// (non-zero) if a bounded wait expires.  Needs GX*GY co-resident workgroups.
+// mailbox (residentMailboxBytes) carries the halo exchange between neighbouring
+// workgroups as self-validating 16-byte slots; counters (residentCounterBytes) holds
+// each region's publish counts, from which the slot epochs follow -- both zeroed
+// together, once, and again after a failed launch; *error is written (non-zero) if a
+// bounded wait expires.  Needs GX*GY co-resident workgroups.
 struct ResidentTowerParams {
 	const void *in;
 	int inPitch;
@@ -173,13 +174,12 @@ struct ResidentTowerParams {
 	const void *weights;
 	const float *bias;
 	void *mailbox;
-	unsigned *generation;
+	unsigned *counters;
 	unsigned *error;
 	void *debug;  // optional: GX*GY*4*8 u64 cycle sums (diagnostic variant 4 only)
 	int H, W;
 	int GX, GY, RH;
 	int nLayers;
-	int bumpGeneration;  // 1: bump *generation in a 1-thread launch first (0: someone else did)
 	// Optional fused generator tail (tailW1 != nullptr): instead of writing the last
 	// layer to `out`, every workgroup runs the tail (launchTailFused's arithmetic) on
 	// its LDS-resident region and writes the HR state and the BGRX frame directly.
@@ -194,9 +194,11 @@ struct ResidentTowerParams {
 	std::ptrdiff_t outStride;
 	const unsigned *sums;     // normalize_brightness channel sums or nullptr
 };
-void launchBumpGeneration(unsigned *generation, hipStream_t stream);
 bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH);
 std::size_t residentMailboxBytes(int GX, int GY);
+inline std::size_t residentCounterBytes(int GX, int GY) {
+	return (static_cast<std::size_t>(GX) * GY * 2 * sizeof(unsigned) + 63) / 64 * 64;
+}
 void launchResidentTower(DType dt, const ResidentTowerParams &p, hipStream_t stream);
 
 // Timing-only ablation switch of the tower kernel (0 = product kernel).
@@ -208,11 +210,10 @@ void setResidentFault(int n);
 // ---- flow-net helpers -------------------------------------------------------
 // cur frame (u8 BGRX, signed row stride) + previous packed history ->
 // packed [PH][PW][16]: ch 0-2 current frame (x/255-0.5, zero in the pad border),
-// ch 3-11 = previous ch 0-8, ch 12-15 zero.  generation (optional): device word
-// incremented once per launch (the resident tower's launch generation).
+// ch 3-11 = previous ch 0-8, ch 12-15 zero.
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,
-    int padLeft, int numInputs, const unsigned *sums, unsigned *generation, hipStream_t stream);
+    int padLeft, int numInputs, const unsigned *sums, hipStream_t stream);
 
 // normalize_brightness (reference models.py:772-779): exact integer sums of the B, G, R
 // bytes of the frame -> sums[0..2]; the kernels taking `sums` derive the scalar

@@ -394,14 +394,12 @@ struct ResidentParams {
 	const void *weights;      // nLayers x 73728 B, kernel-ready (packConvWeights)
 	const float *bias;        // nLayers x 64
 	uint4 *mail;              // [regions][2][kResMailSlots] 16-byte slots
-	unsigned *flag;           // [regions] {generation<<8 | layers published}
-	const unsigned *gen;      // launch generation (bumped by bump_generation_kernel)
+	unsigned *count;          // [regions][2] publishes so far into the region's two slot parities (persistent)
 	unsigned *error;          // host-visible word, 0 = ok
 	unsigned long long *debug;  // VARIANT 4 only: [regions][4 waves][8] cycle sums
 	int H, W, pitch;
 	int GX, GY, RH;
 	int nLayers;
-	int bumpGeneration;  // host-side only: launch bump_generation_kernel first
 	// fused generator tail (tailW1 != nullptr), see ResidentTowerParams
 	const void *tailW1;
 	const float *tailB1;
@@ -418,10 +416,6 @@ struct ResidentParams {
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
-
-__global__ void bump_generation_kernel(unsigned *gen) {
-	*gen = *gen + 1;
-}
 
 // VARIANT: timing ablation only (0 = product; bit 0 = no halo exchange, bit 1 = no MFMA loop)
 // HEAD: layer 0 is the generator's conv_1 (plain conv + ReLU), residual blocks follow
@@ -459,7 +453,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int rhv = min(p.RH, p.H - y0);
 	volatile int *failFlag = reinterpret_cast<volatile int *>(smem + kResOffMisc);
 	float *ldsBias = reinterpret_cast<float *>(smem + kResOffMisc + 64);
-	const unsigned genTag = (*p.gen) << 8;  // uniform; never matches a previous launch
+	// Publishes into this region's two slot parities so far, over ALL launches (zeroed with
+	// the mailbox).  Every region publishes the same layers, so a consumer knows its
+	// neighbours' counts from its own.
+	unsigned pubCount[2] = {p.count[region * 2], p.count[region * 2 + 1]};
 
 	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
 	    (__attribute__((address_space(3))) unsigned char *)smem));
@@ -720,26 +717,27 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		return smem + off + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4);
 	};
 	// Self-validating slots: every tower output is post-ReLU (>= 0), so the sign bit
-	// of each of the 8 values in a 16-byte slot is free; it carries one bit of an
-	// 8-bit epoch tag {generation & 3, layer + 1}.  Consecutive writes to the same
-	// slot (layers l-2, l, l+2, ... and the previous launch) always differ in tag,
-	// so a consumer can tell "new" from "old" from the payload itself and the
-	// producer needs neither a drain nor a release: ONE hop instead of
-	// store-ack -> flag -> load.  The flag below is only a hint that keeps 65k
-	// threads from polling the fabric before the data can possibly be there.
-	auto tagMasks = [&](int layer, u32x4 *m) {
-		const unsigned t = ((genTag >> 8) & 3u) << 6 | (unsigned)((layer + 1) & 63);
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			(*m)[k] = ((t >> (2 * k)) & 1u) << 15 | ((t >> (2 * k + 1)) & 1u) << 31;
-		}
+	// of each of the 8 values in a 16-byte slot is free.  EVERY dword carries the same
+	// 2-bit epoch e = (number of writes to this slot so far) & 3 in its two sign bits:
+	// consecutive writes to a slot differ in e, so in every dword -- a slot is accepted only
+	// when all four dwords show the expected epoch, which a store or load torn at dword
+	// granularity between two consecutive writes cannot produce (the previous 8-bit tag
+	// spread over the dwords left 12 of 16 bytes unprotected against that).  The slot always
+	// holds the previous write or the expected one (the producer cannot run further ahead:
+	// it needs this region's next layer first), and the mailbox starts zeroed with the
+	// counts (e = 0 never matches a first write, e = 1).  The producer needs neither a drain
+	// nor a release: ONE hop instead of store-ack -> flag -> load.
+	auto epochMask = [&](int par) -> unsigned {
+		const unsigned e = pubCount[par] & 3u;
+		return (e & 1u) << 15 | (e >> 1) << 31;
 	};
 	// `layer`: the layer whose output (in buffer `off`) is published
 	auto publish = [&](int off, int layer) {
 		// (the caller has just passed the workgroup barrier: the region's output is in LDS)
-		u32x4 tm;
-		tagMasks(layer, &tm);
-		const unsigned base = (unsigned)((region * 2 + ((layer + 1) & 1)) * kResMailSlots) * 16u;
+		const int ppar = (layer + 1) & 1;
+		pubCount[ppar] += 1u;
+		const unsigned tm = epochMask(ppar);
+		const unsigned base = (unsigned)((region * 2 + ppar) * kResMailSlots) * 16u;
 #pragma unroll
 		for (int it = 0; it < kResMailSlots / 256; ++it) {
 			const int idx = it * 256 + tid;
@@ -756,42 +754,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				__builtin_amdgcn_raw_buffer_store_b128(v, mailRsrc, base + idx * 16, 0, kSc1);
 			}
 		}
-		if (tid == 0) {  // hint only: no drain, no barrier
-			__hip_atomic_store((gu32 *)(p.flag + region), genTag | (unsigned)(layer + 1),
-			    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
 	};
 	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
 	// returns false on timeout (uniform across the workgroup)
-	constexpr bool kUseHint = false;  // measured: polling a hint flag first is not faster than sweeping
 	auto fillHalo = [&](int off, int layer) -> bool {
-		const unsigned want = genTag | (unsigned)(layer + 1);
-		(void)want;
 		const u64 t0 = __builtin_amdgcn_s_memrealtime();
-		if (wave == 0 && kUseHint) {
-			bool ready = true;
-			const gu32 *f = nullptr;
-			if (lane < 8) {
-				const int k = lane < 4 ? lane : lane + 1;  // skip the centre of the 3x3
-				const int nx = gxr + (k % 3) - 1, ny = gyr + (k / 3) - 1;
-				if (nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY) {
-					f = (const gu32 *)(p.flag + ny * p.GX + nx);
-					ready = false;
-				}
-			}
-			while (!__all(ready)) {
-				if (!ready) {
-					const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					ready = (v - want) <= 1u;  // a neighbour is at most one layer ahead
-				}
-				if (__builtin_amdgcn_s_memrealtime() - t0 > kResTimeoutTicks) break;  // the sweep reports it
-				__builtin_amdgcn_s_sleep(1);
-			}
-		}
-		if (kUseHint) __syncthreads();
 		const int par = (layer + 1) & 1;
-		u32x4 tm;
-		tagMasks(layer, &tm);
+		// (this region published the same layer a moment ago: its count is the neighbours')
+		const unsigned tm = epochMask(par);
 		constexpr int NS = kResMailSlots / 256 + 1;  // 4 sides x 32 entries x 8 chunks, + the 4 corners
 		unsigned hsrc[NS];
 		unsigned char *hd[NS];
@@ -852,7 +822,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
 				const u32x4 tg = hv[it] & 0x80008000u;
-				const bool ok = tg[0] == tm[0] && tg[1] == tm[1] && tg[2] == tm[2] && tg[3] == tm[3];
+				const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
 				if ((pending >> it & 1u) && ok) {
 					*reinterpret_cast<u32x4 *>(hd[it]) = hv[it] & 0x7fff7fffu;
 					pending &= ~(1u << it);
@@ -948,6 +918,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 	}
 	const int finalOff = (L & 1) ? kResOffB : kResOffA;
+	if (tid == 0 && xchg) {  // the next launch continues the slot epochs (plain stores: kernel boundary)
+		p.count[region * 2] = pubCount[0];
+		p.count[region * 2 + 1] = pubCount[1];
+	}
 	if constexpr (VARIANT == 4) {
 		if (lane == 0 && p.debug != nullptr) {
 			for (int k = 0; k < 7; ++k) p.debug[(region * 4 + wave) * 8 + k] = prof[k];
@@ -1016,10 +990,6 @@ void launchResidentT(const ResidentParams &p, hipStream_t stream) {
 	auto kern = tower_resident_kernel<T, VARIANT, HEAD, TAIL>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), kResLds, &ldsDone, "resident tower");
-	if (p.bumpGeneration) {
-		hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream,
-		    const_cast<unsigned *>(p.gen));
-	}
 	// (g_ResidentFault > 0, tests only: some regions are never computed, their neighbours'
 	// bounded waits expire and the error path runs)
 	const int grid = p.GX * p.GY - (g_ResidentFault < p.GX * p.GY ? g_ResidentFault : 0);
@@ -1054,11 +1024,6 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 void setTowerVariant(int v) { g_TowerVariant = v; }
 void setResidentFault(int n) { g_ResidentFault = n; }
 
-void launchBumpGeneration(unsigned *generation, hipStream_t stream) {
-	hipLaunchKernelGGL(bump_generation_kernel, dim3(1), dim3(1), 0, stream, generation);
-	hipCheckLaunch("bump_generation");
-}
-
 bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH) {
 	const int gx = (W + kResRW - 1) / kResRW;
 	const int gy = (H + kResMaxRH - 1) / kResMaxRH;
@@ -1083,8 +1048,7 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.weights = q.weights;
 	p.bias = q.bias;
 	p.mail = static_cast<uint4 *>(q.mailbox);
-	p.gen = q.generation;
-	p.flag = q.generation + 16;  // same small buffer: word 0 = generation, flags from byte 64
+	p.count = q.counters;
 	p.debug = static_cast<unsigned long long *>(q.debug);
 	p.error = q.error;
 	p.H = q.H;
@@ -1094,7 +1058,6 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.GY = q.GY;
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
-	p.bumpGeneration = q.bumpGeneration;
 	p.tailW1 = q.tailW1;
 	p.tailB1 = q.tailB1;
 	p.tailW2 = q.tailW2;

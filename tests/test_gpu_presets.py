@@ -169,3 +169,94 @@ def test_resident_failure_recovers_with_graphs_enabled():
     assert any(lvl == 1 and b"per-layer" in msg for lvl, msg in seen), seen
     assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(want, got))
     rt.close()
+
+
+def test_resident_failure_is_recoverable(monkeypatch):
+    """After a bounded-wait failure the engine uses the per-block kernels, but not for good:
+    after JU_RESIDENT_RETRY clean frames it goes back to the one-launch tower (with the
+    mailbox and the slot epochs reset), and backs off x4 when that fails again."""
+    from helpers import small_config
+    monkeypatch.setenv("JU_RESIDENT_RETRY", "3")
+    monkeypatch.setenv("JU_NO_GRAPH", "1")       # the fault hook acts on new launches
+    cfg = small_config()
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames = M.synthetic_frames(12, 30, 48, seed=43, kind="smooth")
+    ref_rt = R.Runtime(blob, 0, R.DTYPE_BF16)
+    want = [ref_rt.process_image(f).copy() for f in frames]
+    ref_rt.close()
+    rt = R.Runtime(blob, 0, R.DTYPE_BF16)
+    lib = R.load_library()
+    got = [rt.process_image(frames[0]).copy()]
+    assert rt.stat("resident_tower") == 1 and rt.stat("fallbacks") == 0
+    lib.ju_debug_set(b"resident_fault", 1)
+    try:
+        got.append(rt.process_image(frames[1]).copy())          # times out, falls back, re-runs
+    finally:
+        lib.ju_debug_set(b"resident_fault", 0)
+    assert rt.stat("resident_tower") == 0 and rt.stat("fallbacks") == 1
+    got.append(rt.process_image(frames[2]).copy())
+    got.append(rt.process_image(frames[3]).copy())
+    assert rt.stat("resident_tower") == 0
+    got.append(rt.process_image(frames[4]).copy())               # third clean frame: resident again
+    assert rt.stat("resident_tower") == 1
+    got += [rt.process_image(f).copy() for f in frames[5:8]]     # ... and it works (epochs start over)
+    assert rt.stat("resident_tower") == 1 and rt.stat("fallbacks") == 1
+    lib.ju_debug_set(b"resident_fault", 1)
+    try:
+        got.append(rt.process_image(frames[8]).copy())
+    finally:
+        lib.ju_debug_set(b"resident_fault", 0)
+    assert rt.stat("resident_tower") == 0 and rt.stat("fallbacks") == 2
+    got += [rt.process_image(f).copy() for f in frames[9:]]      # 3 clean frames < the backed-off 12
+    assert rt.stat("resident_tower") == 0
+    assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(want, got))
+    rt.close()
+
+
+def test_two_resident_runtimes_enqueue_concurrently():
+    """Two runtimes on one GPU, each on its own thread and stream (two OBS filters): two
+    resident towers cannot be co-resident, so the runtimes chain their frames through
+    events.  Both streams must produce exactly their solo frames, without a fallback."""
+    import threading
+    import torch
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    n = 24
+    clips = [M.synthetic_frames(n, h, w, seed=81 + k, kind="smooth") for k in range(2)]
+    dev = torch.device("cuda", 0)
+    d_in = [torch.from_numpy(c).to(dev) for c in clips]
+    solo = []
+    for k in range(2):
+        rt = R.Runtime(blob, 0, R.DTYPE_F16)
+        d_out = torch.empty((n, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for t in range(n):
+            rt.enqueue(rt.device_image(d_in[k][t].data_ptr(), w, h), rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h))
+        rt.synchronize()
+        solo.append(d_out.cpu())
+        rt.close()
+    rts = [R.Runtime(blob, 0, R.DTYPE_F16) for _ in range(2)]
+    outs = [torch.empty((n, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            for t in range(n):
+                rts[k].enqueue(rts[k].device_image(d_in[k][t].data_ptr(), w, h),
+                               rts[k].device_image(outs[k][t].data_ptr(), 4 * w, 4 * h))
+            rts[k].synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not errors, errors
+    for k in range(2):
+        assert rts[k].stat("resident_tower") == 1 and rts[k].stat("fallbacks") == 0
+        assert torch.equal(outs[k].cpu(), solo[k]), k
+        rts[k].close()
