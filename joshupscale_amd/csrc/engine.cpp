@@ -559,7 +559,29 @@ void Engine::buildProgram(int set) {
 		const int e0 = m_Fp8Exp[0];
 		prog.push_back({"tower", 0.0,
 		    [=](hipStream_t s) { launchQuantizeTower(dt, streamBuf, x8, H, W, e0, s); }});
-		for (int i = 0; i < c.genBlocks; ++i) {
+		for (int i = 0; i < c.genBlocks && m_BlockFused; ++i) {
+			// one launch per block: the e4m3 stream copy ping-pongs between the two tensors
+			const std::string n = "generator/block_" + std::to_string(i + 1);
+			const Fp8Conv &q1 = m_Fp8Convs.at(n + "/conv_1"), &q2 = m_Fp8Convs.at(n + "/conv_2");
+			Fp8BlockLaunch fb{};
+			fb.in8 = (i & 1) ? t8 : x8;
+			fb.out8 = (i & 1) ? x8 : t8;
+			fb.stream = streamBuf;
+			fb.w1 = q1.w.get();
+			fb.w2 = q2.w.get();
+			fb.scaleA1 = q1.scaleA.as<int>();
+			fb.scaleA2 = q2.scaleA.as<int>();
+			fb.b1 = m_Convs.at(n + "/conv_1").bias.as<float>();
+			fb.b2 = m_Convs.at(n + "/conv_2").bias.as<float>();
+			fb.inExp = m_Fp8Exp[2 * i];
+			fb.midExp = m_Fp8Exp[2 * i + 1];
+			fb.outExp = (i + 1 < c.genBlocks) ? m_Fp8Exp[2 * i + 2] : 0;  // (the last copy has no reader)
+			fb.H = H;
+			fb.W = W;
+			prog.push_back({"tower", 2.0 * H * W * 9.0 * 64 * 64 * 2,
+			    [=](hipStream_t s) { launchResBlockFp8(dt, fb, s); }});
+		}
+		for (int i = 0; i < c.genBlocks && !m_BlockFused; ++i) {
 			const std::string n = "generator/block_" + std::to_string(i + 1);
 			for (int j = 0; j < 2; ++j) {
 				const std::string name = n + (j ? "/conv_2" : "/conv_1");

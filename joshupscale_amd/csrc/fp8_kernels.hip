@@ -311,6 +311,318 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 	}
 }
 
+// ---------------------------------------------------------------------------
+// res_block_fp8_kernel: one residual block of the 8-bit tower per launch
+// ---------------------------------------------------------------------------
+// The per-layer form above moves every e4m3 tensor through HBM twice and its second
+// convolution runs at the memory rate.  Here a block is ONE persistent
+// launch (one workgroup of 8 waves per CU, two per SIMD) over TH x 30-pixel tiles:
+//   * a convolution's A fragments (9 taps x 8 VGPRs) are in registers while it runs; they
+//     are re-fetched per tile and convolution (18 KB per wave from L2) -- holding both sets
+//     for the whole launch does not fit two waves per SIMD (256 registers) without spills;
+//   * conv A: X8 tile ((TH + 4) x 34 records of 64 B, LDS) -> ReLU -> e4m3 with the
+//     intermediate tensor's scale -> T8 tile ((TH + 2) x 34, LDS), zero outside the image;
+//     the intermediate tensor never reaches memory;
+//   * conv B: T8 -> + skip (16-bit stream, read back from memory at the output pixel) ->
+//     ReLU -> the stream in place, and its e4m3 copy with the NEXT block's scale into the
+//     other e4m3 tensor (a neighbouring tile still reads this block's input as its halo);
+//   * the next tile's X8 travels by LDS-DMA while conv B computes (X8 is dead then).
+// The arithmetic per element is exactly the per-layer kernels' (same instruction sequence
+// per output), so both paths produce the same bytes.
+struct Fp8BlockParams {
+	const unsigned char *in8;   // e4m3 tower-layout tensor, allocation start
+	unsigned char *out8;        // the other e4m3 tower-layout tensor
+	void *stream;               // 16-bit residual stream, tower layout, updated in place
+	const unsigned char *w1, *w2;
+	const int *scaleA1, *scaleA2;
+	const float *b1, *b2;
+	int scaleB1, scaleB2;       // E8M0 codes of the input / intermediate tensor scales
+	float mulT, mulOut;         // 2^e of the intermediate / output e4m3 tensors
+	int H, W, pitch;
+	int tilesX, numTiles;
+	int skip;                   // timing ablation (JU_FB_SKIP, developer only)
+};
+
+template <int TH>
+struct Fp8BlockGeom {
+	static constexpr int XR = TH + 4, TR = TH + 2;
+	static constexpr int XBYTES = (XR * 34 * 64 + 1023) / 1024 * 1024;  // whole 1 KiB DMA writes
+	static constexpr int TBYTES = TR * 34 * 64;
+	static constexpr int WBYTES = 9 * 2 * 64 * 32;  // conv B's fragments (both cout blocks): 36 KiB
+	// per wave: the skip records of a row pair (2 x 32 px x 64 B; the results overwrite them
+	// in place; a row's e4m3 copy is then staged in the same 2 KiB once its stream row has
+	// been read out)
+	static constexpr int STAGE_WAVE = 4096;
+	static constexpr int OFF_T = XBYTES;
+	static constexpr int OFF_W = OFF_T + TBYTES;
+	static constexpr int OFF_STAGE = OFF_W + WBYTES;
+	static constexpr int OFF_BIAS = OFF_STAGE + 8 * STAGE_WAVE;  // 2 x 64 floats
+	static constexpr int LDS = OFF_BIAS + 512;
+	static_assert(LDS <= 160 * 1024, "fp8 block tile");
+};
+
+template <typename T, int TH>
+__global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p) {
+	using G = Fp8BlockGeom<TH>;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	unsigned char *smX = smem, *smT = smem + G::OFF_T, *smW = smem + G::OFF_W;
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
+	const int cb = wave & 1, pl = wave >> 1;  // cout block; pairs pl, pl + 4, ...
+	unsigned char *stage = smem + G::OFF_STAGE + wave * G::STAGE_WAVE;
+
+	// conv A's fragments of this wave's cout block: registers, for the whole launch (buffer
+	// loads: ONE lane offset register, the tap offset scalar -- flat loads keep 18 64-bit
+	// addresses alive: spills).  conv B's fragments: LDS, shared by the workgroup (both sets
+	// in registers do not fit two waves per SIMD).
+	typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+	i32x8 wa[9];
+	{
+		const __amdgpu_buffer_rsrc_t rsrc =
+		    __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(p.w1), 0, G::WBYTES, 0x00020000);
+		const unsigned wLane = static_cast<unsigned>((cb * 64 + lane) * 32);
+#pragma unroll
+		for (int t = 0; t < 9; ++t) {
+			const u32x4w lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wLane, t * 4096, 0);
+			const u32x4w hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wLane, t * 4096 + 16, 0);
+			wa[t] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+		}
+	}
+	for (int i = wave; i < G::WBYTES / 1024; i += 8) dmaToLds16(p.w2, 0u, static_cast<unsigned>(i * 1024 + lane * 16), smW + i * 1024);
+	const int scA1 = p.scaleA1[cb * 32 + px], scA2 = p.scaleA2[cb * 32 + px];
+	float *smBias = reinterpret_cast<float *>(smem + G::OFF_BIAS);
+	if (tid < 64) smBias[tid] = p.b1[tid];
+	else if (tid < 128) smBias[tid] = p.b2[tid - 64];
+	const float *biasA = smBias + cb * 32 + 4 * hh, *biasB = smBias + 64 + cb * 32 + 4 * hh;
+	const unsigned char *wbLane = smW + (cb * 64 + lane) * 32;  // + tap * 4096
+
+	// X8 tile: record q = r * 34 + k = image pixel (y0 - 2 + r, x0 - 2 + k) at q * 64, chunk c of
+	// column k at position c ^ ((k >> 2) & 3).  Image pixels by LDS-DMA (16 records per
+	// wave-instruction), the rest zeroed by hand (disjoint locations).
+	auto stageX = [&](int tile) {
+		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		const int y0 = ty * TH, x0 = tx * 30;
+		constexpr int NREC = G::XR * 34;
+		constexpr int NINSTR = (NREC + 15) / 16;
+		const bool border = y0 - 2 < 0 || y0 + TH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
+		for (int i = wave; i < NINSTR; i += 8) {
+			const int q = i * 16 + (lane >> 2);
+			const int r = q / 34, k = q - r * 34;
+			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
+			const int c = (lane & 3) ^ ((k >> 2) & 3);
+			const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+			if (q < NREC && inside) {
+				dmaToLds16(p.in8, 0u, static_cast<unsigned>(((gy + 1) * p.pitch + gx + 1) * 64 + c * 16), smX + i * 1024);
+			} else if (border && q < NREC) {
+				*reinterpret_cast<i32x4 *>(smX + i * 1024 + lane * 16) = i32x4{0, 0, 0, 0};
+			}
+		}
+	};
+	// B fragments of one horizontal tap of a row pair: 4 input rows x 32 bytes per lane
+	auto loadFrags = [&](const unsigned char *tile, int pair, int dx, i32x8(&fb)[4]) {
+		const int x = px + dx;
+		const int sw = (x >> 2) & 3;
+		const unsigned char *col = tile + ((2 * pair) * 34 + x) * 64;
+		const unsigned char *colLo = col + (((2 * hh) ^ sw) << 4);
+		const unsigned char *colHi = col + (((2 * hh + 1) ^ sw) << 4);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const i32x4 lo = *reinterpret_cast<const i32x4 *>(colLo + r * (34 * 64));
+			const i32x4 hi = *reinterpret_cast<const i32x4 *>(colHi + r * (34 * 64));
+			fb[r] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+		}
+	};
+
+	int tile = blockIdx.x;
+	if (tile < p.numTiles && !(p.skip & 1)) stageX(tile);
+	for (; tile < p.numTiles; tile += gridDim.x) {
+		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		const int y0 = ty * TH, x0 = tx * 30;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's X8 (first tile: and conv B's weights) landed
+		__syncthreads();                                  // ... for every wave; all are done with T8
+		// ---- conv A: (TH + 2) rows x 32 columns -> ReLU -> e4m3 -> T8, zero outside the image ----
+		for (int pair = pl; pair < G::TR / 2; pair += 4) {
+			f32x16 acc[2];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = biasA[8 * g + i];
+				}
+			}
+			// the next tap's fragments travel behind the current tap's 6 instructions
+			i32x8 f0[4], f1[4];
+			if (p.skip & 2) goto epiA;
+			loadFrags(smX, pair, 0, f0);
+			loadFrags(smX, pair, 1, f1);
+#pragma unroll
+			for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 0], f0[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
+			}
+			loadFrags(smX, pair, 2, f0);
+#pragma unroll
+			for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 1], f1[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
+			}
+#pragma unroll
+			for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 2], f0[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
+			}
+		epiA:
+			if (p.skip & 32) continue;
+			const int gx = x0 - 1 + px;
+			const bool colIn = gx >= 0 && gx < p.W;
+			const int sw = (px >> 2) & 3;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int tr = 2 * pair + r;
+				const int gy = y0 - 1 + tr;
+				const bool inside = colIn && gy >= 0 && gy < p.H;
+				unsigned char *rec = smT + (tr * 34 + px) * 64;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					int q = quantize4(fmaxf(acc[r][4 * g], 0.0f), fmaxf(acc[r][4 * g + 1], 0.0f),
+					    fmaxf(acc[r][4 * g + 2], 0.0f), fmaxf(acc[r][4 * g + 3], 0.0f), p.mulT);
+					if (!inside) q = 0;
+					// bytes 32 cb + 8 g + 4 hh .. + 3 of the record: chunk 2 cb + (g >> 1)
+					*reinterpret_cast<int *>(rec + (((2 * cb + (g >> 1)) ^ sw) << 4) + (g & 1) * 8 + hh * 4) = q;
+				}
+			}
+		}
+		__syncthreads();  // T8 complete, X8 dead
+		if (tile + static_cast<int>(gridDim.x) < p.numTiles && !(p.skip & 1)) stageX(tile + gridDim.x);
+		// ---- conv B: TH rows x 32 columns (30 valid) + skip -> ReLU -> stream, e4m3 copy ----
+		for (int pair = pl; pair < TH / 2; pair += 4) {
+			// the pair's skip records (this wave's half: channels 32 cb ..) by LDS-DMA into the
+			// staging slice, pixel pi = r * 32 + px at pi * 64, chunk c at c ^ (pi & 3); they land
+			// during the K loop, and the results go back into the same places
+			if (!(p.skip & 8)) {
+				const unsigned char *src = static_cast<const unsigned char *>(p.stream);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int pi = i * 16 + (lane >> 2);
+					const int gy = min(y0 + 2 * pair + (pi >> 5), p.H - 1), gx = min(x0 + (pi & 31), p.W - 1);
+					const unsigned c = static_cast<unsigned>(lane & 3) ^ (static_cast<unsigned>(pi) & 3u);
+					dmaToLds16(src, 0u, static_cast<unsigned>((((gy + 1) * p.pitch + gx + 1) * 64 + cb * 32) * 2 + c * 16),
+					    stage + i * 1024);
+				}
+			}
+			f32x16 acc[2];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = biasB[8 * g + i];
+				}
+			}
+			i32x8 f0[4], f1[4];
+			if (!(p.skip & 4)) {
+			loadFrags(smT, pair, 0, f0);
+			loadFrags(smT, pair, 1, f1);
+			}
+#pragma unroll
+			for (int dx = 0; dx < ((p.skip & 4) ? 0 : 3); ++dx) {
+				if (dx == 1) loadFrags(smT, pair, 2, f0);
+#pragma unroll
+				for (int dy = 0; dy < 3; ++dy) {
+					const i32x4 lo = *reinterpret_cast<const i32x4 *>(wbLane + (dy * 3 + dx) * 4096);
+					const i32x4 hi = *reinterpret_cast<const i32x4 *>(wbLane + (dy * 3 + dx) * 4096 + 16);
+					const i32x8 w = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+					for (int r = 0; r < 2; ++r) {
+						acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, (dx == 1 ? f1 : f0)[r + dy], acc[r], 0, 0, 0, scA2, 0, p.scaleB2);
+					}
+				}
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the skip records have landed (this wave's own DMA)
+			if (p.skip & 64) continue;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int pi = r * 32 + px;
+				unsigned char *rec = stage + pi * 64 + hh * 8;
+				const unsigned sw = static_cast<unsigned>(pi) & 3u;
+				Vec4<T> rv[4];
+#pragma unroll
+				for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const Vec4<T> *>(rec + ((static_cast<unsigned>(g) ^ sw) << 4));
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					float v[4];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[r][4 * g + i] + static_cast<float>(rv[g][i]), 0.0f);
+					*reinterpret_cast<Vec4<T> *>(rec + ((static_cast<unsigned>(g) ^ sw) << 4)) = pack4<T>(v[0], v[1], v[2], v[3]);
+					acc[r][4 * g] = v[0];
+					acc[r][4 * g + 1] = v[1];
+					acc[r][4 * g + 2] = v[2];
+					acc[r][4 * g + 3] = v[3];
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			// stream rows: 2 x 32 px x 64 B = 4 wave-instructions of 16 B per lane
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int pi = i * 16 + (lane >> 2);
+				const unsigned slot = static_cast<unsigned>(lane & 3);
+				const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & 3u);
+				const i32x4 val = *reinterpret_cast<const i32x4 *>(stage + pi * 64 + (slot << 4));
+				const int gy = y0 + 2 * pair + (pi >> 5), gx = x0 + (pi & 31);
+				if ((pi & 31) < 30 && gy < p.H && gx < p.W && !(p.skip & 16)) {
+					*reinterpret_cast<i32x4 *>(static_cast<unsigned char *>(p.stream) +
+					    (((size_t)(gy + 1) * p.pitch + gx + 1) * 64 + cb * 32) * 2 + chunk * 16) = val;
+				}
+			}
+			// e4m3 copy, one row at a time through [g][px][hh] dwords (every write instruction
+			// covers all 64 banks once) in the row's own, now free, 2 KiB; lane = (pixel, 16-byte
+			// half of the 32-byte half record)
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				unsigned char *stage8 = stage + r * 2048;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					*reinterpret_cast<int *>(stage8 + (g * 64 + px * 2 + hh) * 4) =
+					    quantize4(acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3], p.mulOut);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const int pxo = lane >> 1, c = lane & 1;
+				typedef int i32x2 __attribute__((ext_vector_type(2)));
+				const i32x2 a = *reinterpret_cast<const i32x2 *>(stage8 + ((2 * c) * 64 + pxo * 2) * 4);
+				const i32x2 b = *reinterpret_cast<const i32x2 *>(stage8 + ((2 * c + 1) * 64 + pxo * 2) * 4);
+				const int gy = y0 + 2 * pair + r, gx = x0 + pxo;
+				if (pxo < 30 && gy < p.H && gx < p.W && !(p.skip & 16)) {
+					*reinterpret_cast<i32x4 *>(p.out8 + ((size_t)(gy + 1) * p.pitch + gx + 1) * 64 + cb * 32 + c * 16) =
+					    i32x4{a[0], a[1], b[0], b[1]};
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+			// the slice is read out before the next pair's skip DMA refills it: LDS reads of one
+			// wave complete in order, but the DMA is a memory operation -- wait for them
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		}
+	}
+}
+
+template <typename T, int TH>
+void launchFp8BlockT(Fp8BlockParams k, int cus, hipStream_t stream) {
+	using G = Fp8BlockGeom<TH>;
+	auto kern = res_block_fp8_kernel<T, TH>;
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "fp8 block");
+	k.tilesX = (k.W + 29) / 30;
+	k.numTiles = k.tilesX * ((k.H + TH - 1) / TH);
+	const int grid = k.numTiles < cus ? k.numTiles : cus;
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS, stream, k);
+	hipCheckLaunch("res_block_fp8");
+}
+
 // 16-bit tower tensor -> e4m3 copy (interior pixels only: the border stays zero)
 template <typename T>
 __global__ __launch_bounds__(256) void quantize_tower_kernel(const T *__restrict__ in,
@@ -386,6 +698,62 @@ void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
 		if (dt == kF16) launchFp8T<f16, false>(k, grid, stream);
 		else launchFp8T<bf16, false>(k, grid, stream);
 	}
+}
+
+void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
+	Fp8BlockParams k{};
+	k.in8 = static_cast<const unsigned char *>(q.in8);
+	k.out8 = static_cast<unsigned char *>(q.out8);
+	k.stream = q.stream;
+	k.w1 = static_cast<const unsigned char *>(q.w1);
+	k.w2 = static_cast<const unsigned char *>(q.w2);
+	k.scaleA1 = q.scaleA1;
+	k.scaleA2 = q.scaleA2;
+	k.b1 = q.b1;
+	k.b2 = q.b2;
+	k.scaleB1 = 127 - q.inExp;
+	k.scaleB2 = 127 - q.midExp;
+	k.mulT = std::ldexp(1.0f, q.midExp);
+	k.mulOut = std::ldexp(1.0f, q.outExp);
+	k.H = q.H;
+	k.W = q.W;
+	k.pitch = towerPitch(q.W);
+	static const int skipEnv = [] {
+		const char *e = std::getenv("JU_FB_SKIP");
+		return e ? std::atoi(e) : 0;
+	}();
+	k.skip = skipEnv;
+	static const int cus = [] {
+		int dev = 0, n = 256;
+		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+		return n;
+	}();
+	// Tile height: a CU works through ceil(tiles / CUs) tiles one after the other, each
+	// costing about (rows + 5) row-times (recompute ring + per-tile fixed work): take the
+	// height with the shortest makespan (480x270: 18 rows, 240 tiles, one each; 640x448: 14
+	// rows, 704 tiles, three rounds -- 18 rows would be three rounds of taller tiles).
+	const long tilesX = (q.W + 29) / 30;
+	int best = 6;
+	long bestCost = -1;
+	for (int th : {18, 14, 10, 6}) {
+		const long tiles = tilesX * ((q.H + th - 1) / th);
+		const long cost = ((tiles + cus - 1) / cus) * (th + 5);
+		if (bestCost < 0 || cost < bestCost) {
+			bestCost = cost;
+			best = th;
+		}
+	}
+#define JU_F8B(TH_)                                        \
+	if (best == TH_) {                                     \
+		if (dt == kF16) launchFp8BlockT<f16, TH_>(k, cus, stream); \
+		else launchFp8BlockT<bf16, TH_>(k, cus, stream);   \
+		return;                                            \
+	}
+	JU_F8B(18)
+	JU_F8B(14)
+	JU_F8B(10)
+	JU_F8B(6)
+#undef JU_F8B
 }
 
 void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int exponent,

@@ -151,6 +151,20 @@ struct Fp8TowerParams {
 	int H, W;
 };
 void launchConvTowerFp8(DType dt, const Fp8TowerParams &p, hipStream_t stream);
+// One residual block of the 8-bit tower per launch (the intermediate e4m3 tensor stays in
+// LDS): in8 -> conv A -> ReLU -> e4m3(2^midExp) -> conv B -> + stream -> ReLU -> stream
+// (in place) and out8 = e4m3(stream * 2^outExp).  in8 / out8 must be different tensors.
+struct Fp8BlockLaunch {
+	const void *in8;
+	void *out8;
+	void *stream;
+	const void *w1, *w2;      // packFp8TowerWeights().w of the two convolutions
+	const int *scaleA1, *scaleA2;
+	const float *b1, *b2;
+	int inExp, midExp, outExp;
+	int H, W;
+};
+void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream);
 // e4m3(max(x, 0) * 2^exponent) of a 16-bit tower tensor (allocation starts)
 void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int exponent,
     hipStream_t stream);

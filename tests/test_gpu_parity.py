@@ -793,6 +793,7 @@ def test_fp8_tower_bytes_do_not_depend_on_the_grid(monkeypatch):
     blob = M.serialize(cfg, M.make_seeded_weights(cfg))
     frames = M.synthetic_frames(6, cfg.frame_height, cfg.frame_width, seed=1234, kind="noise")
     monkeypatch.setenv("JU_NO_GRAPH", "1")   # the grid override acts on new launches only
+    monkeypatch.setenv("JU_TOWER", "convs")  # the one-launch-per-convolution kernel (the grid knob is its)
 
     def run(grid):
         if grid:
@@ -811,6 +812,33 @@ def test_fp8_tower_bytes_do_not_depend_on_the_grid(monkeypatch):
         assert np.array_equal(trunk, ref_trunk), grid
         for a, b in zip(outs, ref):
             assert np.array_equal(a, b), grid
+
+
+def test_fp8_block_and_per_conv_kernels_give_the_same_bytes(monkeypatch):
+    """The 8-bit tower runs one launch per residual block (res_block_fp8_kernel: the
+    intermediate e4m3 tensor stays in LDS); JU_TOWER=convs keeps one launch per convolution.
+    Per output element both execute the same instruction sequence, so the bytes are equal --
+    at a ragged small size, at the benchmark size and at the PS2 size (several tiles per CU)."""
+    for cfg, n in [(small_config(frame_height=34, frame_width=70, gen_blocks=3), 3),
+                   (M.PRESETS["psp-fast"], 2), (M.PRESETS["ps2-quality"], 2)]:
+        blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+        frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=1234, kind="noise")
+        runs = {}
+        for mode in ("blocks", "convs"):
+            if mode == "convs":
+                monkeypatch.setenv("JU_TOWER", "convs")
+            else:
+                monkeypatch.delenv("JU_TOWER", raising=False)
+            rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+            launches = rt.time_steps("tower", 0)[1]
+            outs = [rt.process_image(f).copy() for f in frames]
+            runs[mode] = (outs, rt.read_tensor("trunk").copy(), launches)
+            rt.close()
+        monkeypatch.delenv("JU_TOWER", raising=False)
+        assert runs["blocks"][2] == 1 + cfg.gen_blocks and runs["convs"][2] == 1 + 2 * cfg.gen_blocks
+        assert np.array_equal(runs["blocks"][1], runs["convs"][1])
+        for a, b in zip(runs["blocks"][0], runs["convs"][0]):
+            assert np.array_equal(a, b)
 
 
 def test_fp8_rejects_a_calibration_tensor_of_the_wrong_length():
