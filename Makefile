@@ -10,7 +10,7 @@ CXXFLAGS   := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wall
               -Wno-unused-parameter
 HIPFLAGS   := --offload-arch=$(ARCH) $(CXXFLAGS)
 SRCS_CPP   := model.cpp engine.cpp c_api.cpp core_api.cpp log.cpp comm.cpp graphics.cpp
-SRCS_HIP   := conv_kernels.hip tower_kernels.hip frame_kernels.hip fp8_kernels.hip flow_kernels.hip
+SRCS_HIP   := conv_kernels.hip tower_kernels.hip frame_kernels.hip fp8_kernels.hip flow_kernels.hip tower8_kernels.hip
 OBJS       := $(addprefix $(OBJ)/,$(SRCS_CPP:.cpp=.o)) $(addprefix $(OBJ)/,$(SRCS_HIP:.hip=.o))
 
 all: $(OUT)/libJoshUpscale.so

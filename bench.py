@@ -141,7 +141,16 @@ def main() -> int:
         achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_MFMA_TFLOPS
         fp8_roofline = None
-        if fp8:
+        if fp8 and launches == 1:
+            # the one-launch 8-bit tower: MFMA-bound by arithmetic, priced against the block-scaled e4m3 peak
+            peak = PEAK_FP8_TFLOPS
+        elif fp8 and launches == 1 + cfg.gen_blocks:
+            # one launch per residual block (more regions than CUs): step 0 is the quantise kernel
+            ms, _, fl1 = rt.time_steps("tower#1", args.roofline_iters)
+            launches, flops_per_launch = cfg.gen_blocks, fl1
+            achieved = fl1 / (ms * 1e-3) / 1e12
+            peak = PEAK_FP8_TFLOPS
+        elif fp8:
             # 8-bit tower: step 0 of the stage is the quantise kernel, then per block the first
             # convolution (e4m3 in, e4m3 out: MFMA-bound by arithmetic) and the second (+ the
             # fp16 residual stream in and out: memory-bound, and the one most time goes to)
@@ -197,8 +206,11 @@ def main() -> int:
                 "whole_frame_tflops": total_flops * fps / world / 1e12,
             },
             "roofline": {
-                "kernel": "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch"
-                          if launches == 1 else "conv_tower_kernel 3x3 64->64 (one residual-block conv)",
+                "kernel": ("tower8_resident_kernel: all 3x3 64->64 e4m3 convs of the residual blocks, one launch" if fp8
+                           else "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch")
+                          if launches == 1 else
+                          ("res_block_fp8_kernel: one residual block (two 3x3 64->64 e4m3 convs) per launch" if fp8
+                           else "res_block_kernel / conv_tower_kernel: 3x3 64->64 residual-block convs"),
                 "bound": "mfma", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",

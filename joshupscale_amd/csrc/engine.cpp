@@ -174,6 +174,7 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 	cw.cinReal = f.cin;
 	if (m_Fp8Tower && name.rfind("generator/block_", 0) == 0 && f.cout == 64 && f.cin == 64) {
 		const Fp8ConvWeights q = packFp8TowerWeights(f);
+		m_Fp8Folded.emplace(name, f);
 		Fp8Conv dev;
 		dev.w = DeviceBuffer(q.w.size());
 		dev.w.upload(q.w.data(), q.w.size());
@@ -503,14 +504,36 @@ void Engine::buildProgram(int set) {
 		                }});
 	}
 	// ---- generator ----
-	if (!m_Resident) {
+	if (!m_Resident || m_Fp8Tower) {  // (the 16-bit resident tower runs conv_1 as its layer 0)
 		addConvStep(&prog, "gen_head", "generator/conv_1", Op("gen_in"), none, Op("trunk_a"), H, W,
 		    true, false);
 	}
 	const char *xs[2] = {"trunk_a", "trunk_b"};
 	int a = 0;
 	bool tailInTower = false;
-	if (m_Resident) {
+	if (m_Resident && m_Fp8Tower) {
+		// the 8-bit tower in one launch: trunk_a (conv_1's output) -> trunk_b
+		ResidentTower8Params rp{};
+		rp.in = m_Tensors.at("trunk_a").buf.get();
+		rp.out = m_Tensors.at("trunk_b").buf.get();
+		rp.weights = m_Fp8TowerW.get();
+		rp.scaleA = m_Fp8TowerScaleA.as<int>();
+		rp.bias = m_Fp8TowerBias.as<float>();
+		rp.scaleB = m_Fp8TowerScaleB.as<int>();
+		rp.outMul = m_Fp8TowerMul.as<float>();
+		rp.mailbox = m_ResMail.get();
+		rp.counters = m_ResFlags.as<unsigned>();
+		rp.error = m_ResErrorDev;
+		rp.H = H;
+		rp.W = W;
+		rp.GX = m_ResGX;
+		rp.GY = m_ResGY;
+		rp.RH = m_ResRH;
+		rp.nLayers = 2 * c.genBlocks;
+		prog.push_back({"tower", 2.0 * H * W * 9.0 * 64.0 * 64 * 2 * c.genBlocks,
+		    [=](hipStream_t s) { launchResidentTower8(dt, rp, s); }});
+		a = 1;
+	} else if (m_Resident) {
 		// one launch for the whole tower
 		ResidentTowerParams rp{};
 		rp.in = Op("gen_in").ptr;  // dense [H][W][64]; conv_1 is layer 0 of the launch
@@ -721,8 +744,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		const char *mode = std::getenv("JU_TOWER");
 		int cus = 0;
 		JU_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-		// (the 8-bit tower has a per-layer kernel only)
-		bool wanted = !(mode && (std::string(mode) == "layers" || std::string(mode) == "convs")) && !m_Fp8Tower;
+		bool wanted = !(mode && (std::string(mode) == "layers" || std::string(mode) == "convs"));
 		m_BlockFused = !(mode && std::string(mode) == "convs");
 		if (wanted && c.genActivation != 0) {
 			// the resident kernel's halo slots carry their epoch tag in the sign bits of
@@ -739,7 +761,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 			m_TowerW.upload(m_TowerHostW.data(), m_TowerHostW.size() * 2);
 			m_TowerB = DeviceBuffer(m_TowerHostB.size() * 4);
 			m_TowerB.upload(m_TowerHostB.data(), m_TowerHostB.size() * 4);
-			m_ResMail = DeviceBuffer(residentMailboxBytes(m_ResGX, m_ResGY));
+			m_ResMail = DeviceBuffer(m_Fp8Tower ? residentMailboxBytes8(m_ResGX, m_ResGY)
+			                                    : residentMailboxBytes(m_ResGX, m_ResGY));
 			m_ResFlags = DeviceBuffer(residentCounterBytes(m_ResGX, m_ResGY));  // publish counts per region
 			m_ResError = PinnedWords(64);
 			m_ResErrorDev = m_ResError.device();
@@ -814,6 +837,34 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 			const TensorView &am = model.tensor("generator/fp8_amax", {2 * c.genBlocks});
 			for (int i = 0; i < 2 * c.genBlocks; ++i) m_Fp8Exp[i] = fp8ActivationExponent(am.data[i]);
 		}
+		if (m_ResidentCapable) {
+			// operands of the one-launch 8-bit tower, convolution by convolution
+			const int L = 2 * c.genBlocks;
+			std::vector<unsigned char> w;
+			std::vector<int> scaleA, scaleB(L);
+			std::vector<float> bias, mul(L + 1);
+			for (int i = 0; i < L; ++i) {
+				const std::string name = "generator/block_" + std::to_string(i / 2 + 1) + (i % 2 ? "/conv_2" : "/conv_1");
+				const Fp8ConvWeights q = packFp8TowerWeights(m_Fp8Folded.at(name));
+				w.insert(w.end(), q.w.begin(), q.w.end());
+				scaleA.insert(scaleA.end(), q.scaleA.begin(), q.scaleA.end());
+				const std::vector<float> &b = m_Fp8Folded.at(name).bias;
+				bias.insert(bias.end(), b.begin(), b.end());
+				scaleB[i] = 127 - m_Fp8Exp[i];
+				mul[i] = std::ldexp(1.0f, i + 1 < L ? m_Fp8Exp[i + 1] : 0);  // (the last copy has no reader)
+			}
+			mul[L] = std::ldexp(1.0f, m_Fp8Exp[0]);
+			auto up = [](DeviceBuffer *d, const void *src, std::size_t n) {
+				*d = DeviceBuffer(n);
+				d->upload(src, n);
+			};
+			up(&m_Fp8TowerW, w.data(), w.size());
+			up(&m_Fp8TowerScaleA, scaleA.data(), scaleA.size() * 4);
+			up(&m_Fp8TowerBias, bias.data(), bias.size() * 4);
+			up(&m_Fp8TowerScaleB, scaleB.data(), scaleB.size() * 4);
+			up(&m_Fp8TowerMul, mul.data(), mul.size() * 4);
+		}
+		m_Fp8Folded.clear();
 	}
 	addTensor("tail_y", lr * 128);
 	addTensor("tower_profile", 256 * 4 * 8 * 2, true);  // u64 cycle sums of the diagnostic tower variant

@@ -160,8 +160,11 @@ private:
 	};
 	bool m_Fp8Tower = false;
 	std::map<std::string, Fp8Conv> m_Fp8Convs;
+	std::map<std::string, FoldedConv> m_Fp8Folded;  // (construction only)
 	DeviceBuffer m_Fp8X, m_Fp8T;
 	std::vector<int> m_Fp8Exp;
+	// resident 8-bit tower (tower8_resident_kernel): every block's operands in one buffer each
+	DeviceBuffer m_Fp8TowerW, m_Fp8TowerScaleA, m_Fp8TowerBias, m_Fp8TowerScaleB, m_Fp8TowerMul;
 	DeviceBuffer m_TailW2, m_TailB2, m_TailW2Frag;
 	DeviceBuffer m_TemporalAcc;  // 32.32 fixed-point sum of |gen - pre_warp| (temporal filter)
 	// flow auto-encoder: which blocks run as ONE launch (flow_block_kernel: both convs, the

@@ -220,6 +220,31 @@ void setTowerVariant(int variant);
 // Test hook: launch the resident tower `n` workgroups short, so that the bounded
 // neighbour waits expire (exercises the engine's fallback to the per-layer path).
 void setResidentFault(int n);
+int residentFaultForTests();
+
+// ---- resident 8-bit tower (tower8_kernels.hip): every residual block of the e4m3 tower in
+// one launch; the 16-bit stream and the two e4m3 tiles stay in LDS.  in / out: 16-bit tower
+// tensors (allocation starts): generator conv_1's output in, the last block's stream out.
+// Per convolution i of the 2 B: weights (packFp8TowerWeights, 36864 B each), scaleA[i][64],
+// bias[i][64], scaleB[i] (E8M0 code of its input tensor's scale), outMul[i] (2^e of the
+// e4m3 tensor its output feeds); outMul[2 B] = the scale of the tower's input tensor.
+struct ResidentTower8Params {
+	const void *in;
+	void *out;
+	const void *weights;
+	const int *scaleA;
+	const float *bias;
+	const int *scaleB;
+	const float *outMul;
+	void *mailbox;       // residentMailboxBytes8, zeroed with the counters
+	unsigned *counters;  // residentCounterBytes
+	unsigned *error;
+	int H, W;
+	int GX, GY, RH;
+	int nLayers;
+};
+std::size_t residentMailboxBytes8(int GX, int GY);
+void launchResidentTower8(DType dt, const ResidentTower8Params &p, hipStream_t stream);
 
 // ---- flow-net helpers -------------------------------------------------------
 // cur frame (u8 BGRX, signed row stride) + previous packed history ->

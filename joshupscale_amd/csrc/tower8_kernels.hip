@@ -1,0 +1,466 @@
+// gfx950 (CDNA4, MI355X): the 8-bit (OCP e4m3) residual tower as ONE launch
+// (reference scripts/training/models.py:193-254, 538-550; quantisation scheme: fp8.h).
+//
+//  * tower8_resident_kernel   all 2 B convolutions of the B residual blocks, activations
+//                             resident in LDS, halo exchange through the global mailbox
+//
+// The per-block form (res_block_fp8_kernel) moves the 16-bit residual stream and the
+// e4m3 copies through memory once per block: 50 MB per block at 480 x 270, i.e. the memory
+// rate (16 us per block), although the matrix instructions of a block are 5 us.  Here each
+// workgroup (one per CU) owns a region of 32 x RH (<= 16) pixels for the whole tower, as in
+// tower_resident_kernel, and keeps three tiles in LDS:
+//     S   the 16-bit residual stream            (RH + 2) x 34 px x 128 B   (pointwise: no halo used)
+//     X8  e4m3(S * 2^ex), conv A's input         (RH + 2) x 34 px x 64 B    with a one-pixel halo ring
+//     T8  e4m3(relu(conv A) * 2^et)              the same
+//   conv A:  X8 -> ReLU -> e4m3 -> T8 interior;   exchange T8's edge ring
+//   conv B:  T8 -> + S -> ReLU -> S (in place) and X8 interior (next block's scale);
+//            exchange X8's edge ring
+// on v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64: one tap of the 64-channel input per
+// instruction; both power-of-two scales are undone by its E8M0 scale operands).  A wave =
+// (cout half, row-pair parity) keeps its 9 A fragments per layer in registers (72 VGPRs,
+// double-buffered: the next layer's stream in behind the current layer's instructions).
+// The halo exchange is tower_resident_kernel's (self-validating 16-byte slots, one
+// write-through store each, sc1 loads, epochs from persistent publish counts) on records
+// of half the size: e4m3 values of post-ReLU tensors are non-negative, so every BYTE's
+// sign bit is free and each dword carries the 2-bit epoch twice.
+// Per output element the instruction sequence is that of conv_tower_fp8_kernel /
+// res_block_fp8_kernel, so all three paths produce the same bytes.
+#include "kernel_common.h"
+
+namespace ju {
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+constexpr int kT8RW = 32, kT8MaxRH = 16, kT8Pitch = 34;
+constexpr int kT8SRow = kT8Pitch * 128;                 // stream row, bytes
+constexpr int kT8QRow = kT8Pitch * 64;                  // e4m3 row, bytes
+constexpr int kT8OffS = 0;
+constexpr int kT8OffX = (kT8MaxRH + 2) * kT8SRow;       // 78336
+constexpr int kT8OffT = kT8OffX + (kT8MaxRH + 2) * kT8QRow;
+constexpr int kT8OffMisc = kT8OffT + (kT8MaxRH + 2) * kT8QRow;  // 156672
+// misc: fail flag (64 B), per-layer bias x 2 slots (512 B), per-layer weight scale codes x 2 slots (512 B)
+constexpr int kT8Lds = kT8OffMisc + 64 + 512 + 512;
+constexpr int kT8MailSlots = 4 * 32 * 4;                // 16-byte slots per region per parity
+constexpr unsigned long long kT8TimeoutTicks = 20000000ull;  // 0.2 s of s_memrealtime
+
+__device__ __forceinline__ void t8Glds16(const void *g, void *l) {
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+	    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+// e4m3 of four non-negative values, saturating (the hardware conversion returns NaN above 448)
+__device__ __forceinline__ int t8Quantize4(float a, float b, float c, float d, float mul) {
+	a = fminf(a * mul, 448.0f);
+	b = fminf(b * mul, 448.0f);
+	c = fminf(c * mul, 448.0f);
+	d = fminf(d * mul, 448.0f);
+	int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+	return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+
+struct Tower8Params {
+	const void *in;            // 16-bit stream (generator conv_1's output), tower layout, allocation start
+	void *out;                 // 16-bit stream after the last block, tower layout, allocation start
+	const unsigned char *weights;  // nLayers x 36864 B (packFp8TowerWeights)
+	const int *scaleA;         // nLayers x 64 E8M0 codes
+	const float *bias;         // nLayers x 64
+	const int *scaleB;         // nLayers: E8M0 code of each convolution's input tensor scale
+	const float *outMul;       // nLayers: 2^e of the e4m3 tensor each convolution's output feeds
+	uint4 *mail;               // [regions][2][kT8MailSlots]
+	unsigned *count;           // [regions][2] publishes so far (persistent)
+	unsigned *error;
+	int H, W, pitch;
+	int GX, GY, RH;
+	int nLayers;               // 2 x blocks
+	int fault;                 // test hook: workgroups launched short (they never publish)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
+	const int ch = wave & 1, rp = wave >> 1;
+	int region;
+	{  // XCD-contiguous regions (tower_resident_kernel)
+		const int n = gridDim.x, x = blockIdx.x & 7;
+		int start = 0;
+		for (int y = 0; y < x; ++y) start += (n - y + 7) >> 3;
+		region = start + (blockIdx.x >> 3);
+	}
+	const int gxr = region % p.GX, gyr = region / p.GX;
+	const int x0 = gxr * kT8RW, y0 = gyr * p.RH;
+	const int rwv = min(kT8RW, p.W - x0), rhv = min(p.RH, p.H - y0);
+	volatile int *failFlag = reinterpret_cast<volatile int *>(smem + kT8OffMisc);
+	float *ldsBias = reinterpret_cast<float *>(smem + kT8OffMisc + 64);
+	int *ldsScale = reinterpret_cast<int *>(smem + kT8OffMisc + 64 + 512);
+	unsigned pubCount[2] = {p.count[region * 2], p.count[region * 2 + 1]};
+
+	// ---- zero everything (borders, out-of-image area, overrun pads stay zero) ----
+	for (int i = tid; i < kT8OffMisc / 16; i += 256) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+	if (tid == 0) *failFlag = 0;
+	__syncthreads();
+
+	// ---- the stream: region + halo from the complete global tensor (pixels outside the image stay zero) ----
+	{
+		const T *in = static_cast<const T *>(p.in);
+		const int nPix = (rhv + 2) * kT8Pitch;
+		const int nInstr = (nPix + 7) / 8;  // 8 pixels (1 KiB) per wave-instruction
+		for (int i = wave; i < nInstr; i += 4) {
+			const int q = i * 8 + (lane >> 3);
+			const int rr = q / kT8Pitch, cc = q - rr * kT8Pitch;
+			const int c = (lane & 7) ^ ((cc >> 1) & 7);
+			const int gy = y0 - 1 + rr, gx = x0 - 1 + cc;
+			if (q < nPix && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+				t8Glds16(in + ((size_t)(gy + 1) * p.pitch + gx + 1) * 64 + c * 8, smem + kT8OffS + i * 1024);
+			}
+		}
+	}
+	// ---- weights of layer 0, bias / scale codes of layer 0 ----
+	typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+	const __amdgpu_buffer_rsrc_t wRsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    const_cast<unsigned char *>(p.weights), 0, p.nLayers * 36864, 0x00020000);
+	const unsigned wLane = static_cast<unsigned>((ch * 64 + lane) * 32);
+	auto loadWeights = [&](int layer, i32x8(&w)[9]) {
+#pragma unroll
+		for (int t = 0; t < 9; ++t) {
+			const u32x4w lo = __builtin_amdgcn_raw_buffer_load_b128(wRsrc, wLane, layer * 36864 + t * 4096, 0);
+			const u32x4w hi = __builtin_amdgcn_raw_buffer_load_b128(wRsrc, wLane, layer * 36864 + t * 4096 + 16, 0);
+			w[t] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+		}
+	};
+	i32x8 w0[9], w1[9];
+	loadWeights(0, w0);
+	if (wave == 0) {
+		ldsBias[lane] = p.bias[lane];
+		ldsScale[lane] = p.scaleA[lane];
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	// ---- X8 = e4m3(relu(S) * 2^e0) over the whole tile incl. halo (zero stays zero) ----
+	{
+		const float mul0 = p.outMul[p.nLayers];  // scale of the tower's input tensor (slot nLayers)
+		const int nChunk = (rhv + 2) * kT8Pitch * 4;  // 16-byte e4m3 chunks = 16 channels each
+		for (int e = tid; e < nChunk; e += 256) {
+			const int c = e & 3, q = e >> 2;
+			const int rr = q / kT8Pitch, cc = q - rr * kT8Pitch;
+			const unsigned char *src = smem + kT8OffS + rr * kT8SRow + cc * 128;
+			const unsigned sw = (cc >> 1) & 7;
+			const Vec8<T> a = *reinterpret_cast<const Vec8<T> *>(src + (((2 * c) ^ sw) << 4));
+			const Vec8<T> b = *reinterpret_cast<const Vec8<T> *>(src + (((2 * c + 1) ^ sw) << 4));
+			float v[16];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				v[k] = fmaxf(static_cast<float>(a[k]), 0.0f);
+				v[8 + k] = fmaxf(static_cast<float>(b[k]), 0.0f);
+			}
+			i32x4 o;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) o[k] = t8Quantize4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], mul0);
+			*reinterpret_cast<i32x4 *>(smem + kT8OffX + rr * kT8QRow + cc * 64 + ((c ^ ((cc >> 2) & 3)) << 4)) = o;
+		}
+	}
+	__syncthreads();
+
+	// B fragments of one horizontal tap of a row pair: 4 input rows x 32 bytes per lane
+	auto loadFrags = [&](int off, int unit, int dx, i32x8(&fb)[4]) {
+		const int x = px + dx;
+		const int sw = (x >> 2) & 3;
+		const unsigned char *col = smem + off + (2 * unit) * kT8QRow + x * 64;
+		const unsigned char *colLo = col + (((2 * hh) ^ sw) << 4);
+		const unsigned char *colHi = col + (((2 * hh + 1) ^ sw) << 4);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const i32x4 lo = *reinterpret_cast<const i32x4 *>(colLo + r * kT8QRow);
+			const i32x4 hi = *reinterpret_cast<const i32x4 *>(colHi + r * kT8QRow);
+			fb[r] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+		}
+	};
+
+	// one convolution over the region; SECOND: conv B of a block (+ stream, both outputs)
+	auto computeLayer = [&](auto secondTag, const int layer, const i32x8(&w)[9]) {
+		constexpr bool SECOND = decltype(secondTag)::value;
+		constexpr int inOff = SECOND ? kT8OffT : kT8OffX;
+		constexpr int outOff = SECOND ? kT8OffX : kT8OffT;
+		const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
+		const int scA = ldsScale[(layer & 1) * 64 + ch * 32 + px];
+		const int scB = p.scaleB[layer];
+		const float mul = p.outMul[layer];
+		const int np2 = (rhv + 1) >> 1;  // row pairs (an odd last row: its partner row is masked)
+		const int sw = ((px + 1) >> 2) & 3;
+		for (int u = rp; u < np2; u += 2) {
+			f32x16 acc[2];
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const f32x4 bg = *reinterpret_cast<const f32x4 *>(biasPtr + 8 * g);
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = bg[i];
+				}
+			}
+			i32x8 f0[4], f1[4];
+			loadFrags(inOff, u, 0, f0);
+			loadFrags(inOff, u, 1, f1);
+#pragma unroll
+			for (int dx = 0; dx < 3; ++dx) {
+				if (dx == 1) loadFrags(inOff, u, 2, f0);
+#pragma unroll
+				for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+					for (int r = 0; r < 2; ++r) {
+						acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w[dy * 3 + dx], (dx == 1 ? f1 : f0)[r + dy], acc[r],
+						    0, 0, 0, scA, 0, scB);
+					}
+				}
+			}
+			// ---- epilogue ----
+			if (px < rwv) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+					const int row = 2 * u + r;  // region row; buffer row index row + 1
+					if (row < rhv) {
+						unsigned char *q8 = smem + outOff + (row + 1) * kT8QRow + (px + 1) * 64;
+						if constexpr (SECOND) {
+							unsigned char *srec = smem + kT8OffS + (row + 1) * kT8SRow + (px + 1) * 128 + hh * 8;
+							const unsigned ssw = ((px + 1) >> 1) & 7;
+							Vec4<T> rv[4];
+#pragma unroll
+							for (int g = 0; g < 4; ++g) {
+								rv[g] = *reinterpret_cast<const Vec4<T> *>(srec + ((static_cast<unsigned>(ch * 4 + g) ^ ssw) << 4));
+							}
+#pragma unroll
+							for (int g = 0; g < 4; ++g) {
+								float v[4];
+#pragma unroll
+								for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[r][4 * g + i] + static_cast<float>(rv[g][i]), 0.0f);
+								*reinterpret_cast<Vec4<T> *>(srec + ((static_cast<unsigned>(ch * 4 + g) ^ ssw) << 4)) =
+								    pack4<T>(v[0], v[1], v[2], v[3]);
+								*reinterpret_cast<int *>(q8 + (((2 * ch + (g >> 1)) ^ sw) << 4) + (g & 1) * 8 + hh * 4) =
+								    t8Quantize4(v[0], v[1], v[2], v[3], mul);
+							}
+						} else {
+#pragma unroll
+							for (int g = 0; g < 4; ++g) {
+								*reinterpret_cast<int *>(q8 + (((2 * ch + (g >> 1)) ^ sw) << 4) + (g & 1) * 8 + hh * 4) =
+								    t8Quantize4(fmaxf(acc[r][4 * g], 0.0f), fmaxf(acc[r][4 * g + 1], 0.0f),
+								        fmaxf(acc[r][4 * g + 2], 0.0f), fmaxf(acc[r][4 * g + 3], 0.0f), mul);
+							}
+						}
+					}
+				}
+			}
+		}
+	};
+
+	// ---- edge ring -> mailbox, neighbours' mailboxes -> halo ring (64-byte records: 4 chunks) ----
+	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * kT8MailSlots * 16), 0x00020000);
+	constexpr int kSc1 = 16;
+	auto ldsChunk = [&](int off, int rr, int cc, int c) -> unsigned char * {
+		return smem + off + rr * kT8QRow + cc * 64 + ((c ^ ((cc >> 2) & 3)) << 4);
+	};
+	// 2-bit epoch (writes to the slot so far & 3) in the sign bits of every byte pair: each
+	// dword carries it twice (bits 7, 23 = e & 1; bits 15, 31 = e >> 1)
+	auto epochMask = [&](int par) -> unsigned {
+		const unsigned e = pubCount[par] & 3u;
+		return (e & 1u) * 0x00800080u | (e >> 1) * 0x80008000u;
+	};
+	auto publish = [&](int off, int layer) {
+		const int ppar = (layer + 1) & 1;
+		pubCount[ppar] += 1u;
+		const unsigned tm = epochMask(ppar);
+		const unsigned base = (unsigned)((region * 2 + ppar) * kT8MailSlots) * 16u;
+#pragma unroll
+		for (int it = 0; it < kT8MailSlots / 256; ++it) {
+			const int idx = it * 256 + tid;
+			const int strip = idx >> 7, e = (idx >> 2) & 31, c = idx & 3;
+			int rr, cc;
+			bool valid;
+			if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
+			else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
+			else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
+			else { rr = e + 1; cc = rwv; valid = e < rhv; }
+			if (valid) {
+				u32x4w v = *reinterpret_cast<const u32x4w *>(ldsChunk(off, rr, cc, c));
+				v = (v & 0x7f7f7f7fu) | tm;
+				__builtin_amdgcn_raw_buffer_store_b128(v, mailRsrc, base + idx * 16, 0, kSc1);
+			}
+		}
+	};
+	auto fillHalo = [&](int off, int layer) -> bool {
+		const u64 t0 = __builtin_amdgcn_s_memrealtime();
+		const int par = (layer + 1) & 1;
+		const unsigned tm = epochMask(par);
+		constexpr int NS = kT8MailSlots / 256 + 1;  // 4 sides x 32 entries x 4 chunks, + the 4 corners
+		unsigned hsrc[NS];
+		unsigned char *hd[NS];
+		unsigned pending = 0;
+#pragma unroll
+		for (int it = 0; it < NS; ++it) {
+			int nx = gxr, ny = gyr, strip, se, rr, cc, c;
+			bool valid;
+			if (it < NS - 1) {
+				const int idx = it * 256 + tid;
+				const int hp = idx >> 2;
+				c = idx & 3;
+				const int side = hp >> 5, e = hp & 31;
+				if (side < 2) {  // row above / below: their bottom / top row strip
+					ny += side == 0 ? -1 : 1;
+					strip = side == 0 ? 1 : 0;
+					rr = side == 0 ? 0 : rhv + 1;
+					se = e;
+					cc = e + 1;
+					valid = e < rwv;
+				} else {  // column left / right: their right / left column strip
+					nx += side == 2 ? -1 : 1;
+					strip = side == 2 ? 3 : 2;
+					se = e;
+					rr = e + 1;
+					cc = side == 2 ? 0 : rwv + 1;
+					valid = e < rhv;
+				}
+			} else {  // corners: threads 0..15 = 4 corners x 4 chunks, from the diagonal neighbour's row strips
+				const int k = tid >> 2;
+				c = tid & 3;
+				const bool up = k < 2, left = (k & 1) == 0;
+				ny += up ? -1 : 1;
+				nx += left ? -1 : 1;
+				strip = up ? 1 : 0;
+				se = left ? kT8RW - 1 : 0;
+				rr = up ? 0 : rhv + 1;
+				cc = left ? 0 : rwv + 1;
+				valid = tid < 16;
+			}
+			valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
+			const int nreg = valid ? ny * p.GX + nx : region;
+			hsrc[it] = (unsigned)((nreg * 2 + par) * kT8MailSlots + (strip * 32 + se) * 4 + c) * 16u;
+			hd[it] = ldsChunk(off, rr, cc, c);
+			if (valid) pending |= 1u << it;
+		}
+		while (__any(pending != 0)) {
+			u32x4w hv[NS];
+#pragma unroll
+			for (int it = 0; it < NS; ++it) hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, hsrc[it], 0, kSc1);
+#pragma unroll
+			for (int it = 0; it < NS; ++it) {
+				const u32x4w tg = hv[it] & 0x80808080u;
+				const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
+				if ((pending >> it & 1u) && ok) {
+					*reinterpret_cast<u32x4w *>(hd[it]) = hv[it] & 0x7f7f7f7fu;
+					pending &= ~(1u << it);
+				}
+			}
+			if (pending != 0) {
+				if (__builtin_amdgcn_s_memrealtime() - t0 > kT8TimeoutTicks) {
+					*failFlag = 1;
+					__hip_atomic_store((gu32 *)p.error, 0x800u + (unsigned)layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					break;
+				}
+				__builtin_amdgcn_s_sleep(1);
+			}
+		}
+		__syncthreads();
+		return *failFlag == 0;
+	};
+
+	// ---- the tower ----
+	const int L = p.nLayers;
+	float biasNext = 0.f;
+	int scaleNext = 0;
+	auto layerStep = [&](auto secondTag, const int i, const i32x8(&wc)[9], i32x8(&wn)[9]) -> bool {
+		constexpr bool SECOND = decltype(secondTag)::value;
+		const bool more = i + 1 < L;
+		// the halo of this layer's INPUT: layer i - 1's output ring (layer 0 reads the tile as loaded)
+		if (i > 0) {
+			if (!fillHalo(SECOND ? kT8OffT : kT8OffX, i - 1)) return false;
+		}
+		if (more) {
+			loadWeights(i + 1, wn);
+			if (wave == 0) {
+				biasNext = p.bias[(i + 1) * 64 + lane];
+				scaleNext = p.scaleA[(i + 1) * 64 + lane];
+			}
+		}
+		computeLayer(secondTag, i, wc);
+		if (more && wave == 0) {
+			ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
+			ldsScale[((i + 1) & 1) * 64 + lane] = scaleNext;
+		}
+		__syncthreads();
+		if (more) publish(SECOND ? kT8OffX : kT8OffT, i);
+		return true;
+	};
+	using First = std::false_type;
+	using Second = std::true_type;
+	for (int i = 0; i + 1 < L; i += 2) {
+		if (!layerStep(First{}, i, w0, w1)) return;
+		if (!layerStep(Second{}, i + 1, w1, w0)) return;
+	}
+	if (tid == 0) {
+		p.count[region * 2] = pubCount[0];
+		p.count[region * 2 + 1] = pubCount[1];
+	}
+	// ---- the stream's interior -> global tower-layout tensor ----
+	{
+		T *out = static_cast<T *>(p.out);
+		for (int i = tid; i < rhv * kT8RW * 8; i += 256) {
+			const int c = i & 7;
+			const int pxl = (i >> 3) % kT8RW;
+			const int row = (i >> 3) / kT8RW;
+			if (pxl < rwv) {
+				const int rr = row + 1, cc = pxl + 1;
+				const uint4 v = *reinterpret_cast<const uint4 *>(
+				    smem + kT8OffS + rr * kT8SRow + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
+				*reinterpret_cast<uint4 *>(out + ((size_t)(y0 + rr) * p.pitch + x0 + cc) * 64 + c * 8) = v;
+			}
+		}
+	}
+}
+
+template <typename T>
+void launchTower8T(const Tower8Params &p, hipStream_t stream) {
+	auto kern = tower8_resident_kernel<T>;
+	static std::atomic<std::uint64_t> ldsDone{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), kT8Lds, &ldsDone, "fp8 resident tower");
+	const int grid = p.GX * p.GY - (p.fault < p.GX * p.GY ? p.fault : 0);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kT8Lds, stream, p);
+	hipCheckLaunch("tower8_resident");
+}
+
+}  // namespace
+
+std::size_t residentMailboxBytes8(int GX, int GY) {
+	return static_cast<std::size_t>(GX) * GY * 2 * kT8MailSlots * 16;
+}
+
+void launchResidentTower8(DType dt, const ResidentTower8Params &q, hipStream_t stream) {
+	Tower8Params p{};
+	p.in = q.in;
+	p.out = q.out;
+	p.weights = static_cast<const unsigned char *>(q.weights);
+	p.scaleA = q.scaleA;
+	p.bias = q.bias;
+	p.scaleB = q.scaleB;
+	p.outMul = q.outMul;
+	p.mail = static_cast<uint4 *>(q.mailbox);
+	p.count = q.counters;
+	p.error = q.error;
+	p.H = q.H;
+	p.W = q.W;
+	p.pitch = towerPitch(q.W);
+	p.GX = q.GX;
+	p.GY = q.GY;
+	p.RH = q.RH;
+	p.nLayers = q.nLayers;
+	p.fault = residentFaultForTests();
+	if (p.nLayers < 2 || (p.nLayers & 1)) throw std::invalid_argument("fp8 resident tower: layer count must be 2 x blocks");
+	if (dt == kF16) launchTower8T<f16>(p, stream);
+	else launchTower8T<bf16>(p, stream);
+}
+
+}  // namespace ju

@@ -1023,6 +1023,7 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 
 void setTowerVariant(int v) { g_TowerVariant = v; }
 void setResidentFault(int n) { g_ResidentFault = n; }
+int residentFaultForTests() { return g_ResidentFault; }
 
 bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH) {
 	const int gx = (W + kResRW - 1) / kResRW;

@@ -814,31 +814,38 @@ def test_fp8_tower_bytes_do_not_depend_on_the_grid(monkeypatch):
             assert np.array_equal(a, b), grid
 
 
-def test_fp8_block_and_per_conv_kernels_give_the_same_bytes(monkeypatch):
-    """The 8-bit tower runs one launch per residual block (res_block_fp8_kernel: the
-    intermediate e4m3 tensor stays in LDS); JU_TOWER=convs keeps one launch per convolution.
-    Per output element both execute the same instruction sequence, so the bytes are equal --
-    at a ragged small size, at the benchmark size and at the PS2 size (several tiles per CU)."""
-    for cfg, n in [(small_config(frame_height=34, frame_width=70, gen_blocks=3), 3),
-                   (M.PRESETS["psp-fast"], 2), (M.PRESETS["ps2-quality"], 2)]:
+def test_fp8_resident_block_and_per_conv_kernels_give_the_same_bytes(monkeypatch):
+    """The 8-bit tower has three forms: ONE launch (tower8_resident_kernel: the stream and
+    both e4m3 tiles stay in LDS, halo exchange through the mailbox; geometries with at most
+    one 32 x 16 region per CU), one launch per residual block (JU_TOWER=layers,
+    res_block_fp8_kernel: the intermediate e4m3 tensor stays in LDS) and one per convolution
+    (JU_TOWER=convs).  Per output element all three execute the same instruction sequence,
+    so the bytes are equal -- at a ragged small size, at the benchmark size, and at the PS2
+    size (no resident form there: several tiles per CU)."""
+    for cfg, n, resident in [(small_config(frame_height=34, frame_width=70, gen_blocks=3), 3, True),
+                             (small_config(frame_height=30, frame_width=48, gen_blocks=1), 2, True),
+                             (M.PRESETS["psp-quality"], 2, True), (M.PRESETS["ps2-quality"], 2, False)]:
         blob = M.serialize(cfg, M.make_seeded_weights(cfg))
         frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=1234, kind="noise")
         runs = {}
-        for mode in ("blocks", "convs"):
-            if mode == "convs":
-                monkeypatch.setenv("JU_TOWER", "convs")
-            else:
+        for mode in ("resident", "layers", "convs"):
+            if mode == "resident":
                 monkeypatch.delenv("JU_TOWER", raising=False)
+            else:
+                monkeypatch.setenv("JU_TOWER", mode)
             rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+            assert rt.stat("resident_tower") == (1.0 if mode == "resident" and resident else 0.0)
             launches = rt.time_steps("tower", 0)[1]
             outs = [rt.process_image(f).copy() for f in frames]
             runs[mode] = (outs, rt.read_tensor("trunk").copy(), launches)
             rt.close()
         monkeypatch.delenv("JU_TOWER", raising=False)
-        assert runs["blocks"][2] == 1 + cfg.gen_blocks and runs["convs"][2] == 1 + 2 * cfg.gen_blocks
-        assert np.array_equal(runs["blocks"][1], runs["convs"][1])
-        for a, b in zip(runs["blocks"][0], runs["convs"][0]):
-            assert np.array_equal(a, b)
+        assert runs["resident"][2] == (1 if resident else 1 + cfg.gen_blocks)
+        assert runs["layers"][2] == 1 + cfg.gen_blocks and runs["convs"][2] == 1 + 2 * cfg.gen_blocks
+        for mode in ("resident", "layers"):
+            assert np.array_equal(runs[mode][1], runs["convs"][1]), mode
+            for x, y in zip(runs[mode][0], runs["convs"][0]):
+                assert np.array_equal(x, y), mode
 
 
 def test_fp8_rejects_a_calibration_tensor_of_the_wrong_length():
