@@ -260,3 +260,33 @@ def test_two_resident_runtimes_enqueue_concurrently():
         assert rts[k].stat("resident_tower") == 1 and rts[k].stat("fallbacks") == 0
         assert torch.equal(outs[k].cpu(), solo[k]), k
         rts[k].close()
+
+
+def test_fp8_resident_failure_falls_back_to_the_block_kernels(monkeypatch):
+    """The one-launch 8-bit tower has the same bounded waits and the same way out as the
+    16-bit one: on a timeout the engine re-runs the frame on the per-block kernels -- which
+    compute the same bytes -- and comes back after JU_RESIDENT_RETRY clean frames."""
+    from helpers import small_config
+    monkeypatch.setenv("JU_RESIDENT_RETRY", "2")
+    monkeypatch.setenv("JU_NO_GRAPH", "1")
+    cfg = small_config()
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames = M.synthetic_frames(6, 30, 48, seed=47, kind="smooth")
+    ref_rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+    want = [ref_rt.process_image(f).copy() for f in frames]
+    ref_rt.close()
+    rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+    assert rt.stat("resident_tower") == 1
+    lib = R.load_library()
+    got = [rt.process_image(frames[0]).copy()]
+    lib.ju_debug_set(b"resident_fault", 1)
+    try:
+        got.append(rt.process_image(frames[1]).copy())
+    finally:
+        lib.ju_debug_set(b"resident_fault", 0)
+    assert rt.stat("resident_tower") == 0 and rt.stat("fallbacks") == 1
+    got += [rt.process_image(f).copy() for f in frames[2:4]]
+    assert rt.stat("resident_tower") == 1                       # back after two clean frames
+    got += [rt.process_image(f).copy() for f in frames[4:]]
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))  # every form computes the same bytes
+    rt.close()
