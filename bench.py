@@ -33,7 +33,7 @@ from joshupscale_amd import runtime as R  # noqa: E402
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0  # HBM3E, same guide
 PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled e4m3 MFMA (same guide: twice the bf16 rate)
-TRAFFIC_PROFILE = "r01_tower_traffic.json"  # PMC summary of the dominant kernel (tools/pmc_traffic.sh)
+TRAFFIC_PROFILE = "r02_tower_traffic.json"  # PMC summary of the dominant kernel (tools/pmc_traffic.sh)
 
 
 def cpu_baseline(blob: bytes, cfg, frames: np.ndarray, budget_s: float) -> dict:
