@@ -139,9 +139,14 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	};
 	i32x8 w0[9], w1[9];
 	loadWeights(0, w0);
+	if (p.nLayers > 1) loadWeights(1, w1);
 	if (wave == 0) {
 		ldsBias[lane] = p.bias[lane];
 		ldsScale[lane] = p.scaleA[lane];
+		if (p.nLayers > 1) {
+			ldsBias[64 + lane] = p.bias[64 + lane];
+			ldsScale[64 + lane] = p.scaleA[64 + lane];
+		}
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__syncthreads();
@@ -396,34 +401,40 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	const int L = p.nLayers;
 	float biasNext = 0.f;
 	int scaleNext = 0;
-	auto layerStep = [&](auto secondTag, const int i, const i32x8(&wc)[9], i32x8(&wn)[9]) -> bool {
+	auto layerStep = [&](auto secondTag, const int i, i32x8(&wc)[9]) -> bool {
 		constexpr bool SECOND = decltype(secondTag)::value;
 		const bool more = i + 1 < L;
-		// the halo of this layer's INPUT: layer i - 1's output ring (layer 0 reads the tile as loaded)
-		if (i > 0 && !(p.skip & 1)) {
-			if (!fillHalo(SECOND ? kT8OffT : kT8OffX, i - 1)) return false;
-		}
-		if (more) {
-			loadWeights(i + 1, wn);
-			if (wave == 0) {
-				biasNext = p.bias[(i + 1) * 64 + lane];
-				scaleNext = p.scaleA[(i + 1) * 64 + lane];
-			}
-		}
 		computeLayer(secondTag, i, wc);
-		if (more && wave == 0) {
+		__syncthreads();
+		// operands of layer i+1 (fetched one step ago) into the slots layer i-1 used; the
+		// sweep's closing barrier orders them before the next layer's reads
+		if (i >= 1 && more && wave == 0) {
 			ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
 			ldsScale[((i + 1) & 1) * 64 + lane] = scaleNext;
 		}
-		__syncthreads();
 		if (more && !(p.skip & 1)) publish(SECOND ? kT8OffX : kT8OffT, i);
+		// this layer's weight registers are free: refill them for layer i+2 while the
+		// neighbours' stores travel, THEN sweep (tower_kernels.hip, same order)
+		if (i + 2 < L) {
+			loadWeights(i + 2, wc);
+			if (wave == 0) {
+				biasNext = p.bias[(i + 2) * 64 + lane];
+				scaleNext = p.scaleA[(i + 2) * 64 + lane];
+			}
+		}
+		// the halo of the next layer's INPUT: this layer's output ring
+		if (more && !(p.skip & 1)) {
+			if (!fillHalo(SECOND ? kT8OffX : kT8OffT, i)) return false;
+		} else {
+			__syncthreads();
+		}
 		return true;
 	};
 	using First = std::false_type;
 	using Second = std::true_type;
 	for (int i = 0; i + 1 < L; i += 2) {
-		if (!layerStep(First{}, i, w0, w1)) return;
-		if (!layerStep(Second{}, i + 1, w1, w0)) return;
+		if (!layerStep(First{}, i, w0)) return;
+		if (!layerStep(Second{}, i + 1, w1)) return;
 	}
 	if (tid == 0) {
 		p.count[region * 2] = pubCount[0];

@@ -498,10 +498,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		return __builtin_bit_cast(Vec8<T>, v);
 	};
 	// Fragment f = (dy*3+dx)*4+ks is first used in macro-step dx*4+ks of a layer's first
-	// unit.  The 24 fragments with dx < 2 are double-buffered (the next layer's set is
-	// fetched during the current layer); the 12 with dx = 2 are needed only ~1.6k cycles
-	// into the layer, so ONE set suffices: it is refilled at the head of its own layer
-	// and lands behind the first eight macro-steps.  48 registers less than two full sets.
+	// unit.  The 24 fragments with dx < 2 are double-buffered (a layer's set is refilled for
+	// the layer after next as soon as the layer has published); the 12 with dx = 2 exist
+	// once and are refilled for the next layer at the same point.  48 registers less than
+	// two full sets.
 	Vec8<T> w0[24], w1[24], wl[12];
 	auto earlyIdx = [](int f) { return (f / 12) * 8 + (f % 12); };      // dx < 2: f % 12 < 8
 	auto lateIdx = [](int f) { return (f / 12) * 4 + (f % 12) - 8; };   // dx = 2
@@ -518,8 +518,13 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 	};
 	loadWeights(0, w0);
-	float biasNext = 0.f;  // wave 0: next layer's bias in flight (one value per lane)
-	if (wave == 0) ldsBias[lane] = p.bias[lane];
+	loadLateWeights(0);
+	if (p.nLayers > 1) loadWeights(1, w1);
+	float biasNext = 0.f;  // wave 0: the bias of the layer after next in flight (one value per lane)
+	if (wave == 0) {
+		ldsBias[lane] = p.bias[lane];
+		if (p.nLayers > 1) ldsBias[64 + lane] = p.bias[64 + lane];
+	}
 
 	// per-lane LDS address parts (the swizzle depends only on the column: rows are 32 px)
 	// B fragment of macro-step (dx, ks): byte offset inside a row =
@@ -851,29 +856,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int L = p.nLayers;
 	// RES / PAR are compile-time: a runtime `if (residual)` around the epilogue's LDS
 	// read makes hipcc branch and wait per element (+1 us per layer, measured).
-	auto layerStep = [&](auto resTag, auto parTag, const int i, const Vec8<T>(&wc)[24],
-	                     Vec8<T>(&wn)[24]) -> bool {
+	auto layerStep = [&](auto resTag, auto parTag, const int i, Vec8<T>(&wc)[24]) -> bool {
 		constexpr int PAR = decltype(parTag)::value;
 		constexpr int inOff = PAR ? kResOffB : kResOffA;
 		constexpr int outOff = PAR ? kResOffA : kResOffB;
 		const bool more = i + 1 < L;
 		const u64 t0 = stamp();
-		// vmcnt is in-order: the next layer's weight stream (36 loads per lane) is issued
-		// AFTER the halo loads so they never queue behind it, and lands behind the MFMAs.
-		if (i > 0 && xchg) {
-			if (!fillHalo(inOff, i - 1)) return false;
-		}
-		const u64 t1 = stamp();
-		// (Interleaving these 36 loads into the first unit's MFMA loop was tried: the
-		// burst costs ~2.2k cycles of issue stall per layer -- four waves push 144 KB
-		// through the CU's 64 B/clk address path -- but the interleaved form was no
-		// faster end to end and doubled the code.)
-		loadLateWeights(i);  // this layer's dx = 2 fragments: first used in macro-step 8
-		if (more) {
-			loadWeights(i + 1, wn);
-			if (wave == 0) biasNext = p.bias[(i + 1) * 64 + lane];
-		}
-		const u64 t2 = stamp();
 		computeLayer(resTag, i, inOff, outOff, wc);
 		if constexpr (VARIANT == 5) {
 			// per-layer maximum over the frame -> debug[i] (non-negative floats order like
@@ -884,21 +872,41 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(p.debug) + i, __float_as_uint(m));
 			calibMax = 0.f;
 		}
+		const u64 t1 = stamp();
+		__syncthreads();
+		// bias of layer i+1 (fetched one step ago) into the slot layer i-1 used; the sweep's
+		// closing barrier orders it before the next layer's reads
+		if (i >= 1 && more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
+		const u64 t2 = stamp();
+		if (more && xchg) publish(outOff, i);
 		const u64 t3 = stamp();
-		if (more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
+		// The weight stream goes out BETWEEN the publish and the sweep: its ~2.2k cycles of
+		// issue (four waves push 144 KB through the CU's 64 B/clk address path) pass while
+		// the neighbours' write-through stores travel, so the sweep's first pass mostly finds
+		// every slot (vmcnt is in-order: the halo loads return behind the weights, which is
+		// when they would have been valid anyway).  This layer's registers are free: the
+		// early set is refilled for layer i+2, the late set for layer i+1.  (Round 1 had the
+		// stream after the sweep: sweep ~4k + stream 2.2k cycles in series; streaming it from
+		// inside the K loop or behind the sweep's loads was measured no faster.)
+		if (more) {
+			loadLateWeights(i + 1);
+			if (i + 2 < L) {
+				loadWeights(i + 2, wc);
+				if (wave == 0) biasNext = p.bias[(i + 2) * 64 + lane];
+			}
+		}
+		const u64 t4 = stamp();
 		if (more && xchg) {
-			__syncthreads();  // (publish starts with this barrier; split out for the profile)
-			const u64 t4 = stamp();
-			publish(outOff, i);
-			const u64 t5 = stamp();
-			prof[3] += t4 - t3;
-			prof[4] += t5 - t4;
+			if (!fillHalo(outOff, i)) return false;
 		} else {
 			__syncthreads();
 		}
-		prof[0] += t1 - t0;
-		prof[1] += t2 - t1;
-		prof[2] += t3 - t2;
+		const u64 t5 = stamp();
+		prof[0] += t5 - t4;
+		prof[1] += t4 - t3;
+		prof[2] += t1 - t0;
+		prof[3] += t2 - t1;
+		prof[4] += t3 - t2;
 		return true;
 	};
 	using No = std::false_type;
@@ -906,15 +914,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	using P0 = std::integral_constant<int, 0>;
 	using P1 = std::integral_constant<int, 1>;
 	if (HEAD) {  // conv_1, then (conv1, conv2+skip) pairs: L is odd
-		if (!layerStep(No{}, P0{}, 0, w0, w1)) return;
+		if (!layerStep(No{}, P0{}, 0, w0)) return;
 		for (int i = 1; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P1{}, i, w1, w0)) return;
-			if (!layerStep(Yes{}, P0{}, i + 1, w0, w1)) return;
+			if (!layerStep(No{}, P1{}, i, w1)) return;
+			if (!layerStep(Yes{}, P0{}, i + 1, w0)) return;
 		}
 	} else {  // (conv1, conv2+skip) pairs: L is even
 		for (int i = 0; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P0{}, i, w0, w1)) return;
-			if (!layerStep(Yes{}, P1{}, i + 1, w1, w0)) return;
+			if (!layerStep(No{}, P0{}, i, w0)) return;
+			if (!layerStep(Yes{}, P1{}, i + 1, w1)) return;
 		}
 	}
 	const int finalOff = (L & 1) ? kResOffB : kResOffA;
