@@ -290,97 +290,113 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
 	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * kT8MailSlots * 16), 0x00020000);
 	constexpr int kSc1 = 16;
-	auto ldsChunk = [&](int off, int rr, int cc, int c) -> unsigned char * {
-		return smem + off + rr * kT8QRow + cc * 64 + ((c ^ ((cc >> 2) & 3)) << 4);
-	};
 	// 2-bit epoch (writes to the slot so far & 3) in the sign bits of every byte pair: each
 	// dword carries it twice (bits 7, 23 = e & 1; bits 15, 31 = e >> 1)
 	auto epochMask = [&](int par) -> unsigned {
 		const unsigned e = pubCount[par] & 3u;
 		return (e & 1u) * 0x00800080u | (e >> 1) * 0x80008000u;
 	};
-	auto publish = [&](int off, int layer) {
+	// slot descriptors, computed once (tower_kernels.hip): the buffer enters as the LDS
+	// instructions' immediate offset, the slot parity as the buffer instructions' scalar offset
+	auto chunkOff = [&](int rr, int cc, int c) -> unsigned {
+		return (unsigned)(rr * kT8QRow + cc * 64 + ((c ^ ((cc >> 2) & 3)) << 4));
+	};
+	constexpr int NP = kT8MailSlots / 256;  // 4 strips x 32 entries x 4 chunks
+	constexpr int NS = NP + 1;              // 4 sides x 32 entries x 4 chunks, + the 4 corners
+	unsigned pubLds[NP];
+	unsigned pubValid = 0;
+#pragma unroll
+	for (int it = 0; it < NP; ++it) {
+		const int idx = it * 256 + tid;
+		const int strip = idx >> 7, e = (idx >> 2) & 31, c = idx & 3;
+		int rr, cc;
+		bool valid;
+		if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
+		else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
+		else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
+		else { rr = e + 1; cc = rwv; valid = e < rhv; }
+		pubLds[it] = chunkOff(rr, cc, c);
+		if (valid) pubValid |= 1u << it;
+	}
+	const unsigned pubBase = (unsigned)(region * 2 * kT8MailSlots) * 16u + (unsigned)tid * 16u;
+	unsigned sweepSrc[NS], sweepLds[NS];
+	unsigned sweepValid = 0;
+#pragma unroll
+	for (int it = 0; it < NS; ++it) {
+		int nx = gxr, ny = gyr, strip, se, rr, cc, c;
+		bool valid;
+		if (it < NS - 1) {
+			const int idx = it * 256 + tid;
+			const int hp = idx >> 2;
+			c = idx & 3;
+			const int side = hp >> 5, e = hp & 31;
+			if (side < 2) {  // row above / below: their bottom / top row strip
+				ny += side == 0 ? -1 : 1;
+				strip = side == 0 ? 1 : 0;
+				rr = side == 0 ? 0 : rhv + 1;
+				se = e;
+				cc = e + 1;
+				valid = e < rwv;
+			} else {  // column left / right: their right / left column strip
+				nx += side == 2 ? -1 : 1;
+				strip = side == 2 ? 3 : 2;
+				se = e;
+				rr = e + 1;
+				cc = side == 2 ? 0 : rwv + 1;
+				valid = e < rhv;
+			}
+		} else {  // corners: threads 0..15 = 4 corners x 4 chunks, from the diagonal neighbour's row strips
+			const int k = tid >> 2;
+			c = tid & 3;
+			const bool up = k < 2, left = (k & 1) == 0;
+			ny += up ? -1 : 1;
+			nx += left ? -1 : 1;
+			strip = up ? 1 : 0;
+			se = left ? kT8RW - 1 : 0;
+			rr = up ? 0 : rhv + 1;
+			cc = left ? 0 : rwv + 1;
+			valid = tid < 16;
+		}
+		valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
+		const int nreg = valid ? ny * p.GX + nx : region;
+		sweepSrc[it] = (unsigned)((nreg * 2) * kT8MailSlots + (strip * 32 + se) * 4 + c) * 16u;
+		sweepLds[it] = chunkOff(rr, cc, c);
+		if (valid) sweepValid |= 1u << it;
+	}
+	constexpr unsigned kParityBytes = kT8MailSlots * 16u;
+	auto publish = [&](auto offTag, int layer) {
+		constexpr int off = decltype(offTag)::value;
 		const int ppar = (layer + 1) & 1;
 		pubCount[ppar] += 1u;
 		const unsigned tm = epochMask(ppar);
-		const unsigned base = (unsigned)((region * 2 + ppar) * kT8MailSlots) * 16u;
+		const unsigned soff = ppar ? kParityBytes : 0u;
+		u32x4w v[NP];
 #pragma unroll
-		for (int it = 0; it < kT8MailSlots / 256; ++it) {
-			const int idx = it * 256 + tid;
-			const int strip = idx >> 7, e = (idx >> 2) & 31, c = idx & 3;
-			int rr, cc;
-			bool valid;
-			if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
-			else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
-			else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
-			else { rr = e + 1; cc = rwv; valid = e < rhv; }
-			if (valid) {
-				u32x4w v = *reinterpret_cast<const u32x4w *>(ldsChunk(off, rr, cc, c));
-				v = (v & 0x7f7f7f7fu) | tm;
-				__builtin_amdgcn_raw_buffer_store_b128(v, mailRsrc, base + idx * 16, 0, kSc1);
+		for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4w *>(smem + off + pubLds[it]);
+#pragma unroll
+		for (int it = 0; it < NP; ++it) {
+			if (pubValid >> it & 1u) {
+				__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7f7f7f7fu) | tm, mailRsrc, pubBase + it * 4096, soff, kSc1);
 			}
 		}
 	};
-	auto fillHalo = [&](int off, int layer) -> bool {
+	auto fillHalo = [&](auto offTag, int layer) -> bool {
+		constexpr int off = decltype(offTag)::value;
 		const u64 t0 = __builtin_amdgcn_s_memrealtime();
 		const int par = (layer + 1) & 1;
 		const unsigned tm = epochMask(par);
-		constexpr int NS = kT8MailSlots / 256 + 1;  // 4 sides x 32 entries x 4 chunks, + the 4 corners
-		unsigned hsrc[NS];
-		unsigned char *hd[NS];
-		unsigned pending = 0;
-#pragma unroll
-		for (int it = 0; it < NS; ++it) {
-			int nx = gxr, ny = gyr, strip, se, rr, cc, c;
-			bool valid;
-			if (it < NS - 1) {
-				const int idx = it * 256 + tid;
-				const int hp = idx >> 2;
-				c = idx & 3;
-				const int side = hp >> 5, e = hp & 31;
-				if (side < 2) {  // row above / below: their bottom / top row strip
-					ny += side == 0 ? -1 : 1;
-					strip = side == 0 ? 1 : 0;
-					rr = side == 0 ? 0 : rhv + 1;
-					se = e;
-					cc = e + 1;
-					valid = e < rwv;
-				} else {  // column left / right: their right / left column strip
-					nx += side == 2 ? -1 : 1;
-					strip = side == 2 ? 3 : 2;
-					se = e;
-					rr = e + 1;
-					cc = side == 2 ? 0 : rwv + 1;
-					valid = e < rhv;
-				}
-			} else {  // corners: threads 0..15 = 4 corners x 4 chunks, from the diagonal neighbour's row strips
-				const int k = tid >> 2;
-				c = tid & 3;
-				const bool up = k < 2, left = (k & 1) == 0;
-				ny += up ? -1 : 1;
-				nx += left ? -1 : 1;
-				strip = up ? 1 : 0;
-				se = left ? kT8RW - 1 : 0;
-				rr = up ? 0 : rhv + 1;
-				cc = left ? 0 : rwv + 1;
-				valid = tid < 16;
-			}
-			valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
-			const int nreg = valid ? ny * p.GX + nx : region;
-			hsrc[it] = (unsigned)((nreg * 2 + par) * kT8MailSlots + (strip * 32 + se) * 4 + c) * 16u;
-			hd[it] = ldsChunk(off, rr, cc, c);
-			if (valid) pending |= 1u << it;
-		}
+		const unsigned soff = par ? kParityBytes : 0u;
+		unsigned pending = sweepValid;
 		while (__any(pending != 0)) {
 			u32x4w hv[NS];
 #pragma unroll
-			for (int it = 0; it < NS; ++it) hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, hsrc[it], 0, kSc1);
+			for (int it = 0; it < NS; ++it) hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, sweepSrc[it], soff, kSc1);
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
 				const u32x4w tg = hv[it] & 0x80808080u;
 				const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
 				if ((pending >> it & 1u) && ok) {
-					*reinterpret_cast<u32x4w *>(hd[it]) = hv[it] & 0x7f7f7f7fu;
+					*reinterpret_cast<u32x4w *>(smem + off + sweepLds[it]) = hv[it] & 0x7f7f7f7fu;
 					pending &= ~(1u << it);
 				}
 			}
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
 			ldsScale[((i + 1) & 1) * 64 + lane] = scaleNext;
 		}
-		if (more && !(p.skip & 1)) publish(SECOND ? kT8OffX : kT8OffT, i);
+		if (more && !(p.skip & 1)) publish(std::integral_constant<int, SECOND ? kT8OffX : kT8OffT>{}, i);
 		// this layer's weight registers are free: refill them for layer i+2 while the
 		// neighbours' stores travel, THEN sweep (tower_kernels.hip, same order)
 		if (i + 2 < L) {
@@ -424,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		}
 		// the halo of the next layer's INPUT: this layer's output ring
 		if (more && !(p.skip & 1)) {
-			if (!fillHalo(SECOND ? kT8OffX : kT8OffT, i)) return false;
+			if (!fillHalo(std::integral_constant<int, SECOND ? kT8OffX : kT8OffT>{}, i)) return false;
 		} else {
 			__syncthreads();
 		}

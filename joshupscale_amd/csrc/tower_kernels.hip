@@ -717,10 +717,6 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
 	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * kResMailSlots * 16), 0x00020000);
 	constexpr int kSc1 = 16;  // cache-policy bit of sc1 (write-through store / L2-bypassing load)
-	// LDS address of 16-byte chunk c of pixel (rr, cc) in buffer `off`
-	auto ldsChunk = [&](int off, int rr, int cc, int c) -> unsigned char * {
-		return smem + off + rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4);
-	};
 	// Self-validating slots: every tower output is post-ReLU (>= 0), so the sign bit
 	// of each of the 8 values in a 16-byte slot is free.  EVERY dword carries the same
 	// 2-bit epoch e = (number of writes to this slot so far) & 3 in its two sign bits:
@@ -736,100 +732,120 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		const unsigned e = pubCount[par] & 3u;
 		return (e & 1u) << 15 | (e >> 1) << 31;
 	};
+	// Slot descriptors, computed ONCE: they depend on the lane and the region only.  The
+	// buffer (A / B) enters as the LDS instructions' immediate offset and the slot parity as
+	// the buffer instructions' scalar offset, so publish and sweep are loads, stores and the
+	// tag arithmetic, nothing else -- in this kernel every other instruction is serial time.
+	constexpr int NP = kResMailSlots / 256;  // publish: 4 strips x 32 entries x 8 chunks
+	constexpr int NS = NP + 1;               // sweep: 4 sides x 32 entries x 8 chunks, + the 4 corners
+	unsigned pubLds[NP];                     // LDS byte offset inside a buffer of the chunk to publish
+	unsigned pubValid = 0;
+#pragma unroll
+	for (int it = 0; it < NP; ++it) {
+		const int idx = it * 256 + tid;
+		const int strip = idx >> 8, e = (idx >> 3) & 31, c = idx & 7;
+		int rr, cc;
+		bool valid;
+		if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
+		else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
+		else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
+		else { rr = e + 1; cc = rwv; valid = e < rhv; }
+		pubLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
+		if (valid) pubValid |= 1u << it;
+	}
+	const unsigned pubBase = (unsigned)(region * 2 * kResMailSlots) * 16u + (unsigned)tid * 16u;
+	unsigned sweepSrc[NS];  // mailbox byte offset of the neighbour's slot, parity 0
+	unsigned sweepLds[NS];  // LDS byte offset inside a buffer of the halo chunk it fills
+	unsigned sweepValid = 0;
+#pragma unroll
+	for (int it = 0; it < NS; ++it) {
+		int nx = gxr, ny = gyr, strip, se, rr, cc, c;
+		bool valid;
+		if (it < NS - 1) {
+			const int idx = it * 256 + tid;
+			const int hp = idx >> 3;
+			c = idx & 7;
+			const int side = hp >> 5, e = hp & 31;
+			// side 0: row above, 1: row below, 2: column left, 3: column right
+			if (side < 2) {
+				ny += side == 0 ? -1 : 1;
+				strip = side == 0 ? 1 : 0;  // their bottom row / their top row
+				rr = side == 0 ? 0 : rhv + 1;
+				se = e;
+				cc = e + 1;
+				valid = e < rwv;
+			} else {
+				nx += side == 2 ? -1 : 1;
+				strip = side == 2 ? 3 : 2;  // their right column / their left column
+				se = e;
+				rr = e + 1;
+				cc = side == 2 ? 0 : rwv + 1;
+				valid = e < rhv;
+			}
+		} else {
+			// corners: threads 0..31 = 4 corners x 8 chunks; the diagonal neighbour's
+			// bottom/top row strip, last/first entry (interior columns are 32 wide)
+			const int k = tid >> 3;
+			c = tid & 7;
+			const bool up = k < 2, left = (k & 1) == 0;
+			ny += up ? -1 : 1;
+			nx += left ? -1 : 1;
+			strip = up ? 1 : 0;
+			se = left ? kResRW - 1 : 0;
+			rr = up ? 0 : rhv + 1;
+			cc = left ? 0 : rwv + 1;
+			valid = tid < 32;
+		}
+		valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
+		const int nreg = valid ? ny * p.GX + nx : region;
+		sweepSrc[it] = (unsigned)((nreg * 2) * kResMailSlots + (strip * 32 + se) * 8 + c) * 16u;
+		sweepLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
+		if (valid) sweepValid |= 1u << it;
+	}
+	constexpr unsigned kParityBytes = kResMailSlots * 16u;
 	// `layer`: the layer whose output (in buffer `off`) is published
-	auto publish = [&](int off, int layer) {
+	auto publish = [&](auto offTag, int layer) {
+		constexpr int off = decltype(offTag)::value;
 		// (the caller has just passed the workgroup barrier: the region's output is in LDS)
 		const int ppar = (layer + 1) & 1;
 		pubCount[ppar] += 1u;
 		const unsigned tm = epochMask(ppar);
-		const unsigned base = (unsigned)((region * 2 + ppar) * kResMailSlots) * 16u;
+		const unsigned soff = ppar ? kParityBytes : 0u;
+		u32x4 v[NP];
 #pragma unroll
-		for (int it = 0; it < kResMailSlots / 256; ++it) {
-			const int idx = it * 256 + tid;
-			const int strip = idx >> 8, e = (idx >> 3) & 31, c = idx & 7;
-			int rr, cc;
-			bool valid;
-			if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
-			else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
-			else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
-			else { rr = e + 1; cc = rwv; valid = e < rhv; }
-			if (valid) {
-				u32x4 v = *reinterpret_cast<const u32x4 *>(ldsChunk(off, rr, cc, c));
-				v = (v & 0x7fff7fffu) | tm;
-				__builtin_amdgcn_raw_buffer_store_b128(v, mailRsrc, base + idx * 16, 0, kSc1);
+		for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4 *>(smem + off + pubLds[it]);
+#pragma unroll
+		for (int it = 0; it < NP; ++it) {
+			if (pubValid >> it & 1u) {
+				__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7fff7fffu) | tm, mailRsrc,
+				    pubBase + it * 4096, soff, kSc1);
 			}
 		}
 	};
 	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
 	// returns false on timeout (uniform across the workgroup)
-	auto fillHalo = [&](int off, int layer) -> bool {
+	auto fillHalo = [&](auto offTag, int layer) -> bool {
+		constexpr int off = decltype(offTag)::value;
 		const u64 t0 = __builtin_amdgcn_s_memrealtime();
 		const int par = (layer + 1) & 1;
 		// (this region published the same layer a moment ago: its count is the neighbours')
 		const unsigned tm = epochMask(par);
-		constexpr int NS = kResMailSlots / 256 + 1;  // 4 sides x 32 entries x 8 chunks, + the 4 corners
-		unsigned hsrc[NS];
-		unsigned char *hd[NS];
-		unsigned pending = 0;
-#pragma unroll
-		for (int it = 0; it < NS; ++it) {
-			int nx = gxr, ny = gyr, strip, se, rr, cc, c;
-			bool valid;
-			if (it < NS - 1) {
-				const int idx = it * 256 + tid;
-				const int hp = idx >> 3;
-				c = idx & 7;
-				const int side = hp >> 5, e = hp & 31;
-				// side 0: row above, 1: row below, 2: column left, 3: column right
-				if (side < 2) {
-					ny += side == 0 ? -1 : 1;
-					strip = side == 0 ? 1 : 0;  // their bottom row / their top row
-					rr = side == 0 ? 0 : rhv + 1;
-					se = e;
-					cc = e + 1;
-					valid = e < rwv;
-				} else {
-					nx += side == 2 ? -1 : 1;
-					strip = side == 2 ? 3 : 2;  // their right column / their left column
-					se = e;
-					rr = e + 1;
-					cc = side == 2 ? 0 : rwv + 1;
-					valid = e < rhv;
-				}
-			} else {
-				// corners: threads 0..31 = 4 corners x 8 chunks; the diagonal neighbour's
-				// bottom/top row strip, last/first entry (interior columns are 32 wide)
-				const int k = tid >> 3;
-				c = tid & 7;
-				const bool up = k < 2, left = (k & 1) == 0;
-				ny += up ? -1 : 1;
-				nx += left ? -1 : 1;
-				strip = up ? 1 : 0;
-				se = left ? kResRW - 1 : 0;
-				rr = up ? 0 : rhv + 1;
-				cc = left ? 0 : rwv + 1;
-				valid = tid < 32;
-			}
-			valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
-			const int nreg = valid ? ny * p.GX + nx : region;
-			hsrc[it] = (unsigned)((nreg * 2 + par) * kResMailSlots + (strip * 32 + se) * 8 + c) * 16u;
-			hd[it] = ldsChunk(off, rr, cc, c);
-			if (valid) pending |= 1u << it;
-		}
+		const unsigned soff = par ? kParityBytes : 0u;
+		unsigned pending = sweepValid;
 		// sweep: all loads of a pass in flight together, sc1 (never a stale L1/L2 line);
-		// a slot is accepted only when all 8 tag bits match
+		// a slot is accepted only when all four dwords carry the expected epoch
 		while (__any(pending != 0)) {
 			u32x4 hv[NS];
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
-				hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, hsrc[it], 0, kSc1);
+				hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, sweepSrc[it], soff, kSc1);
 			}
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
 				const u32x4 tg = hv[it] & 0x80008000u;
 				const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
 				if ((pending >> it & 1u) && ok) {
-					*reinterpret_cast<u32x4 *>(hd[it]) = hv[it] & 0x7fff7fffu;
+					*reinterpret_cast<u32x4 *>(smem + off + sweepLds[it]) = hv[it] & 0x7fff7fffu;
 					pending &= ~(1u << it);
 				}
 			}
@@ -878,7 +894,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		// closing barrier orders it before the next layer's reads
 		if (i >= 1 && more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
 		const u64 t2 = stamp();
-		if (more && xchg) publish(outOff, i);
+		if (more && xchg) publish(std::integral_constant<int, outOff>{}, i);
 		const u64 t3 = stamp();
 		// The weight stream goes out BETWEEN the publish and the sweep: its ~2.2k cycles of
 		// issue (four waves push 144 KB through the CU's 64 B/clk address path) pass while
@@ -897,7 +913,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 		const u64 t4 = stamp();
 		if (more && xchg) {
-			if (!fillHalo(outOff, i)) return false;
+			if (!fillHalo(std::integral_constant<int, outOff>{}, i)) return false;
 		} else {
 			__syncthreads();
 		}
