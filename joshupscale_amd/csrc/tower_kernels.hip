@@ -561,38 +561,73 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 	};
 	// ------------------------------------------------------------------------
-	// one convolution layer over the region: in/out are LDS buffer offsets
+	// one convolution layer over the region, in segments
 	// ------------------------------------------------------------------------
-	auto computeLayer = [&](auto residualTag, const int layer, const int inOff, const int outOff,
-	                        const Vec8<T>(&w)[24]) {
-		constexpr bool residual = decltype(residualTag)::value;
+	// A unit is a row pair (or the odd last row) x 32 columns x this wave's 32 output
+	// channels: 12 macro-steps (dx, ks) of 6 (3) MFMAs.  The steps run dx = 1 FIRST: those
+	// read no halo column, so for a unit that touches no halo row (every unit but the
+	// region's first and last pair) they depend on nothing a neighbour sends.  Up to
+	// kPreRun such units per wave run these four steps -- a third of their MFMAs -- while
+	// the halo loads of the layer's input are in flight ("pre-run"), and finish after the
+	// sweep; the exchange round trip (~2.8k cycles per layer) hides behind them.
+	constexpr int kOrder[12] = {4, 5, 6, 7, 0, 1, 2, 3, 8, 9, 10, 11};
+#ifndef JU_PRERUN
+#define JU_PRERUN 1
+#endif
+	constexpr int kPreRun = JU_PRERUN;
+	f32x16 accPre[kPreRun > 0 ? kPreRun : 1][2];
+	Vec8<T> fb[2][4];
+	auto issue = [&](unsigned rowAddr, int m, int set, int j) {
+		const int dx = m >> 2, ks = m & 3;
+		const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
+		if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
+		else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4352" : "=v"(fb[set][1]) : "v"(a));
+		else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8704" : "=v"(fb[set][2]) : "v"(a));
+		else asm volatile("ds_read_b128 %0, %1 offset:13056" : "=v"(fb[set][3]) : "v"(a));
+	};
+	// rows of this wave: full pairs u = rp, rp+2, ... and, for an odd region height, the
+	// last row as a single-row unit on the wave group with fewer pairs
+	const int np2 = rhv >> 1;
+	const bool mySingle = (rhv & 1) && rp == (np2 & 1);
+	// pre-run units: preFirst, preFirst + 2, ... (pairs whose four input rows are interior)
+	const int preFirst = rp ? 1 : 2;
+	int nPre = 0;
+#pragma unroll
+	for (int k = 0; k < kPreRun; ++k) {
+		const int u = preFirst + 2 * k;
+		if (u < np2 && 2 * u + 3 <= rhv) nPre = k + 1;
+	}
+	const int preEnd = preFirst + 2 * nPre;  // first unit of this wave's parity at or after preFirst that is NOT pre-run
+	auto isPre = [&](int u) { return u >= preFirst && u < preEnd; };
+	// next unit of this wave after `u` that runs whole (not pre-run), or -1
+	auto nextWhole = [&](int u) {
+		int v = u + 2;
+		if (isPre(v)) v = preEnd;
+		return v < np2 ? v : -1;
+	};
+	const int firstWhole = isPre(rp) ? (preEnd < np2 ? preEnd : -1) : (rp < np2 ? rp : -1);
 
-		const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
-
-		// rows of this wave: full pairs j = rp, rp+2, ... and, for an odd region
-		// height, the last row as a single-row unit on the wave group with fewer pairs
-		const int np2 = rhv >> 1;
-		const int nUnits = np2 + (rhv & 1);
-		Vec8<T> fb[2][4];
-		auto issue = [&](unsigned rowAddr, int m, int set, int j) {
-			const int dx = m >> 2, ks = m & 3;
-			const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
-			if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
-			else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4352" : "=v"(fb[set][1]) : "v"(a));
-			else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8704" : "=v"(fb[set][2]) : "v"(a));
-			else asm volatile("ds_read_b128 %0, %1 offset:13056" : "=v"(fb[set][3]) : "v"(a));
-		};
-		auto rowAddrOf = [&](int unit) { return ldsBase + inOff + (2 * unit) * kResRowBytes; };
-
-		// ROWS = 2: a row pair; ROWS = 1: the odd last row.  `primed`: this unit's
-		// first 4 fragments were already issued by the previous unit's last step.
-		auto unitBody = [&](auto rowsTag, const int unit, const bool primed, const int nextUnit) {
-			constexpr int ROWS = decltype(rowsTag)::value;
-			const u64 tu0 = stamp();
-			constexpr int NR = ROWS + 2;      // input rows / fragment reads per macro-step
-			constexpr int NM = 3 * ROWS;      // MFMAs per macro-step
-			const int ra = 1 + 2 * unit;      // first output row (buffer row index)
-			f32x16 acc[ROWS];
+	// KIND 0: pre-run (accumulator init + positions 0..3); 1: finish (positions 4..11 +
+	// epilogue); 2: whole unit.  `primed`: the first step's fragments are already in flight
+	// in set 0.  nextUnit >= 0: prime that unit's first step at the end -- position 0
+	// (nextFinish false: a pre-run or whole unit) or 4 (a finish) -- so that its fragments
+	// travel while this unit's epilogue runs.
+	auto unitSeg = [&](auto rowsTag, auto kindTag, auto resTag, auto inTag, auto outTag, f32x16(&acc)[2],
+	                   const int layer, const int unit, const bool primed, const int nextUnit,
+	                   const bool nextFinish, const Vec8<T>(&w)[24]) {
+		constexpr int ROWS = decltype(rowsTag)::value;
+		constexpr int KIND = decltype(kindTag)::value;
+		constexpr bool residual = decltype(resTag)::value;
+		constexpr int inOff = decltype(inTag)::value;
+		constexpr int outOff = decltype(outTag)::value;
+		constexpr int P0 = KIND == 1 ? 4 : 0;
+		constexpr int P1 = KIND == 0 ? 4 : 12;
+		const u64 tu0 = stamp();
+		constexpr int NR = ROWS + 2;      // input rows / fragment reads per macro-step
+		constexpr int NM = 3 * ROWS;      // MFMAs per macro-step
+		const int ra = 1 + 2 * unit;      // first output row (buffer row index)
+		if constexpr (KIND != 1) {
+			const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
 				const f32x4 bg = *reinterpret_cast<const f32x4 *>(biasPtr + 8 * g);
@@ -602,55 +637,63 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = bg[i];
 				}
 			}
-			const unsigned rowAddr = rowAddrOf(unit);
-			if (!(VARIANT & 2)) {
-				if (!primed) {
-					asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-					__builtin_amdgcn_sched_barrier(0);
+		}
+		const unsigned rowAddr = ldsBase + inOff + (2 * unit) * kResRowBytes;
+		if (!(VARIANT & 2)) {
+			if (!primed) {
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-					for (int j = 0; j < NR; ++j) issue(rowAddr, 0, 0, j);
-				}
+				for (int j = 0; j < NR; ++j) issue(rowAddr, kOrder[P0], 0, j);
+			}
 #pragma unroll
-				for (int m = 0; m < 12; ++m) {
-					const int set = m & 1;
-					const bool more = (m + 1 < 12);
-					const int dx = m >> 2, ks = m & 3;
+			for (int pos = P0; pos < P1; ++pos) {
+				const int m = kOrder[pos];
+				const int set = (pos - P0) & 1;
+				const bool more = (pos + 1 < P1);
+				const int dx = m >> 2, ks = m & 3;
 #pragma unroll
-					for (int k = 0; k < NM; ++k) {
-						// MFMA k = (dy, r): ROWS=2 -> (k>>1, k&1); ROWS=1 -> (k, 0); it needs
-						// fragment r+dy, fragments are read (and return) in order 0..NR-1
-						const int dy = ROWS == 2 ? (k >> 1) : k;
-						const int r = ROWS == 2 ? (k & 1) : 0;
-						const int need = r + dy;
-						const bool fresh = ROWS == 2 ? (k == 0 || k == 1 || k == 3 || k == 5) : true;
-						if (fresh) {
-							// outstanding allowed = younger reads of this step + next step's issued so far
-							const int issuedNext = more ? (k < NR ? k : NR) : 0;
-							const int allowed = (NR - 1 - need) + issuedNext;
-							if (allowed >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-							else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-							else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-							else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-							else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-							__builtin_amdgcn_sched_barrier(0);
-						}
-						acc[r] = mfma32(dx < 2 ? w[dy * 8 + dx * 4 + ks] : wl[dy * 4 + ks], fb[set][need], acc[r]);
-						if (more && k < NR) issue(rowAddr, m + 1, set ^ 1, k);
+				for (int k = 0; k < NM; ++k) {
+					// MFMA k = (dy, r): ROWS=2 -> (k>>1, k&1); ROWS=1 -> (k, 0); it needs
+					// fragment r+dy, fragments are read (and return) in order 0..NR-1
+					const int dy = ROWS == 2 ? (k >> 1) : k;
+					const int r = ROWS == 2 ? (k & 1) : 0;
+					const int need = r + dy;
+					const bool fresh = ROWS == 2 ? (k == 0 || k == 1 || k == 3 || k == 5) : true;
+					if (fresh) {
+						// outstanding allowed = younger reads of this step + next step's issued so far
+						const int issuedNext = more ? (k < NR ? k : NR) : 0;
+						const int allowed = (NR - 1 - need) + issuedNext;
+						if (allowed >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+						else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+						else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+						else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 						__builtin_amdgcn_sched_barrier(0);
 					}
-				}
-				// prime the next unit (always a pair or single with >= 3 input rows): its
-				// first fragments travel while this unit's epilogue runs
-				if (nextUnit >= 0) {
-					const unsigned na = rowAddrOf(nextUnit);
-					const bool nextSingle = (nextUnit == np2);
-#pragma unroll
-					for (int j = 0; j < 3; ++j) issue(na, 0, 0, j);
-					if (!nextSingle) issue(na, 0, 0, 3);
+					acc[r] = mfma32(dx < 2 ? w[dy * 8 + dx * 4 + ks] : wl[dy * 4 + ks], fb[set][need], acc[r]);
+					if (more && k < NR) issue(rowAddr, kOrder[pos + 1 < 12 ? pos + 1 : 11], set ^ 1, k);
 					__builtin_amdgcn_sched_barrier(0);
 				}
 			}
-			const u64 tu1 = stamp();
+			// prime the next segment (a pair, or the single row: >= 3 input rows)
+			if (nextUnit >= 0) {
+				const unsigned na = ldsBase + inOff + (2 * nextUnit) * kResRowBytes;
+				const bool nextSingle = (nextUnit == np2);
+				if (nextFinish) {
+#pragma unroll
+					for (int j = 0; j < 4; ++j) issue(na, kOrder[4], 0, j);
+				} else {
+#pragma unroll
+					for (int j = 0; j < 3; ++j) issue(na, kOrder[0], 0, j);
+					if (!nextSingle) issue(na, kOrder[0], 0, 3);
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		const u64 tu1 = stamp();
+		prof[5] += tu1 - tu0;
+		if constexpr (KIND != 0) {
 			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
 			// (row ra + r <= rhv always: units are whole pairs, or the odd last row)
 			if (px < rwv) {
@@ -691,23 +734,49 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				}
 			}
 			const u64 tu2 = stamp();
-			prof[5] += tu1 - tu0;
 			prof[6] += tu2 - tu1;
-		};
-
-		// pairs u = rp, rp+2, ... ; the odd last row goes to the wave group with fewer
-		// pairs (group 0 when both have the same number)
-		using R2 = std::integral_constant<int, 2>;
-		using R1 = std::integral_constant<int, 1>;
-		const bool mySingle = (rhv & 1) && rp == (np2 & 1);
-		bool primed = false;
-		for (int u = rp; u < np2; u += 2) {
-			const int nu = (u + 2 < np2) ? u + 2 : (mySingle ? np2 : -1);
-			unitBody(R2{}, u, primed, nu);
-			primed = nu >= 0 && !(VARIANT & 2);
 		}
-		if (mySingle) unitBody(R1{}, np2, primed, -1);
-		(void)nUnits;
+	};
+	using R2 = std::integral_constant<int, 2>;
+	using R1 = std::integral_constant<int, 1>;
+	using KPre = std::integral_constant<int, 0>;
+	using KFin = std::integral_constant<int, 1>;
+	using KWhole = std::integral_constant<int, 2>;
+	// the halo-independent third of up to kPreRun units of `layer` (input buffer inTag)
+	auto preRun = [&](auto inTag, auto outTag, const int layer, const Vec8<T>(&w)[24]) {
+		bool primed = false;
+#pragma unroll
+		for (int k = 0; k < kPreRun; ++k) {
+			if (k < nPre) {
+				const int nu = (k + 1 < nPre) ? preFirst + 2 * (k + 1) : -1;
+				unitSeg(R2{}, KPre{}, std::false_type{}, inTag, outTag, accPre[k], layer, preFirst + 2 * k, primed, nu,
+				    false, w);
+				primed = nu >= 0 && !(VARIANT & 2);
+			}
+		}
+	};
+	// the rest of the layer: the pre-run units' remaining steps, then the other units whole
+	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const Vec8<T>(&w)[24]) {
+		const int afterPre = firstWhole >= 0 ? firstWhole : (mySingle ? np2 : -1);
+		bool primed = false;
+#pragma unroll
+		for (int k = 0; k < kPreRun; ++k) {
+			if (k < nPre) {
+				const bool nextIsPre = k + 1 < nPre;
+				const int nu = nextIsPre ? preFirst + 2 * (k + 1) : afterPre;
+				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre[k], layer, preFirst + 2 * k, primed, nu, nextIsPre, w);
+				primed = nu >= 0 && !(VARIANT & 2);
+			}
+		}
+		f32x16 acc[2];
+		for (int u = firstWhole; u >= 0;) {
+			const int nw = nextWhole(u);
+			const int nu = nw >= 0 ? nw : (mySingle ? np2 : -1);
+			unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, w);
+			primed = nu >= 0 && !(VARIANT & 2);
+			u = nw;
+		}
+		if (mySingle) unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, w);
 	};
 
 	// ------------------------------------------------------------------------
@@ -824,8 +893,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	};
 	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
 	// returns false on timeout (uniform across the workgroup)
-	auto fillHalo = [&](auto offTag, int layer) -> bool {
+	auto fillHalo = [&](auto offTag, int layer, auto &&behindFirstPass) -> bool {
 		constexpr int off = decltype(offTag)::value;
+		bool first = true;
 		const u64 t0 = __builtin_amdgcn_s_memrealtime();
 		const int par = (layer + 1) & 1;
 		// (this region published the same layer a moment ago: its count is the neighbours')
@@ -839,6 +909,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
 				hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, sweepSrc[it], soff, kSc1);
+			}
+			if (first) {  // (loads the caller wants in flight BEHIND the first pass; vmcnt is in-order)
+				__builtin_amdgcn_sched_barrier(0);
+				behindFirstPass();
+				__builtin_amdgcn_sched_barrier(0);
+				first = false;
 			}
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
@@ -859,6 +935,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				__builtin_amdgcn_s_sleep(1);
 			}
 		}
+		if (first) behindFirstPass();  // (a wave none of whose lanes has a slot to fetch)
 		__syncthreads();
 		return *failFlag == 0;
 	};
@@ -872,13 +949,13 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int L = p.nLayers;
 	// RES / PAR are compile-time: a runtime `if (residual)` around the epilogue's LDS
 	// read makes hipcc branch and wait per element (+1 us per layer, measured).
-	auto layerStep = [&](auto resTag, auto parTag, const int i, Vec8<T>(&wc)[24]) -> bool {
+	auto layerStep = [&](auto resTag, auto parTag, const int i, Vec8<T>(&wc)[24], const Vec8<T>(&wn)[24]) -> bool {
 		constexpr int PAR = decltype(parTag)::value;
-		constexpr int inOff = PAR ? kResOffB : kResOffA;
-		constexpr int outOff = PAR ? kResOffA : kResOffB;
+		using InT = std::integral_constant<int, PAR ? kResOffB : kResOffA>;
+		using OutT = std::integral_constant<int, PAR ? kResOffA : kResOffB>;
 		const bool more = i + 1 < L;
 		const u64 t0 = stamp();
-		computeLayer(resTag, i, inOff, outOff, wc);
+		finishLayer(resTag, InT{}, OutT{}, i, wc);
 		if constexpr (VARIANT == 5) {
 			// per-layer maximum over the frame -> debug[i] (non-negative floats order like
 			// their bit patterns, so an integer atomic max does it)
@@ -889,32 +966,35 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			calibMax = 0.f;
 		}
 		const u64 t1 = stamp();
-		__syncthreads();
-		// bias of layer i+1 (fetched one step ago) into the slot layer i-1 used; the sweep's
-		// closing barrier orders it before the next layer's reads
+		// bias of layer i+1 (fetched one step ago) into the slot layer i-1 used: its last
+		// readers passed the previous step's barrier, the next layer's pre-run reads it
+		// behind this step's
 		if (i >= 1 && more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
+		__syncthreads();
 		const u64 t2 = stamp();
-		if (more && xchg) publish(std::integral_constant<int, outOff>{}, i);
+		if (more && xchg) publish(OutT{}, i);
 		const u64 t3 = stamp();
 		// The weight stream goes out BETWEEN the publish and the sweep: its ~2.2k cycles of
 		// issue (four waves push 144 KB through the CU's 64 B/clk address path) pass while
-		// the neighbours' write-through stores travel, so the sweep's first pass mostly finds
-		// every slot (vmcnt is in-order: the halo loads return behind the weights, which is
-		// when they would have been valid anyway).  This layer's registers are free: the
-		// early set is refilled for layer i+2, the late set for layer i+1.  (Round 1 had the
-		// stream after the sweep: sweep ~4k + stream 2.2k cycles in series; streaming it from
-		// inside the K loop or behind the sweep's loads was measured no faster.)
-		if (more) {
-			loadLateWeights(i + 1);
-			if (i + 2 < L) {
-				loadWeights(i + 2, wc);
-				if (wave == 0) biasNext = p.bias[(i + 2) * 64 + lane];
-			}
+		// the neighbours' write-through stores travel (vmcnt is in-order: the halo loads
+		// return behind the weights, which is when they would have been valid anyway).
+		// This layer's registers are free: the early set is refilled for layer i+2, the
+		// late set for layer i+1.  Measured: sweep first / between the two sets / after
+		// both = 452 / 438 / 430 us per tower; an extra 256-1024 cycles of sleep before the
+		// sweep -3 ... +10 us.  (Round 1 had the stream after the sweep: ~4k + 2.2k cycles in
+		// series; streaming from inside the K loop was no faster.)
+		if (more) loadLateWeights(i + 1);
+		if (i + 2 < L) {
+			loadWeights(i + 2, wc);
+			if (wave == 0) biasNext = p.bias[(i + 2) * 64 + lane];
 		}
 		const u64 t4 = stamp();
 		if (more && xchg) {
-			if (!fillHalo(std::integral_constant<int, outOff>{}, i)) return false;
+			// the next layer's halo-independent steps run behind the first pass's loads
+			const bool okFill = fillHalo(OutT{}, i, [&] { preRun(OutT{}, InT{}, i + 1, wn); });
+			if (!okFill) return false;
 		} else {
+			if (more) preRun(OutT{}, InT{}, i + 1, wn);
 			__syncthreads();
 		}
 		const u64 t5 = stamp();
@@ -929,16 +1009,17 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	using Yes = std::true_type;
 	using P0 = std::integral_constant<int, 0>;
 	using P1 = std::integral_constant<int, 1>;
+	preRun(std::integral_constant<int, kResOffA>{}, std::integral_constant<int, kResOffB>{}, 0, w0);
 	if (HEAD) {  // conv_1, then (conv1, conv2+skip) pairs: L is odd
-		if (!layerStep(No{}, P0{}, 0, w0)) return;
+		if (!layerStep(No{}, P0{}, 0, w0, w1)) return;
 		for (int i = 1; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P1{}, i, w1)) return;
-			if (!layerStep(Yes{}, P0{}, i + 1, w0)) return;
+			if (!layerStep(No{}, P1{}, i, w1, w0)) return;
+			if (!layerStep(Yes{}, P0{}, i + 1, w0, w1)) return;
 		}
 	} else {  // (conv1, conv2+skip) pairs: L is even
 		for (int i = 0; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P0{}, i, w0)) return;
-			if (!layerStep(Yes{}, P1{}, i + 1, w1)) return;
+			if (!layerStep(No{}, P0{}, i, w0, w1)) return;
+			if (!layerStep(Yes{}, P1{}, i + 1, w1, w0)) return;
 		}
 	}
 	const int finalOff = (L & 1) ? kResOffB : kResOffA;
