@@ -452,7 +452,6 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int rwv = min(kResRW, p.W - x0);  // valid columns / rows of this region
 	const int rhv = min(p.RH, p.H - y0);
 	volatile int *failFlag = reinterpret_cast<volatile int *>(smem + kResOffMisc);
-	float *ldsBias = reinterpret_cast<float *>(smem + kResOffMisc + 64);
 	// Publishes into this region's two slot parities so far, over ALL launches (zeroed with
 	// the mailbox).  Every region publishes the same layers, so a consumer knows its
 	// neighbours' counts from its own.
@@ -493,38 +492,45 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const __amdgpu_buffer_rsrc_t wRsrc = __builtin_amdgcn_make_buffer_rsrc(
 	    const_cast<void *>(p.weights), 0, p.nLayers * 73728, 0x00020000);
 	const unsigned wLaneOff = (unsigned)((hh * 64 + ch * 32 + px) * 16);
-	auto loadWeightFrag = [&](int layer, int f) -> Vec8<T> {
+	auto loadWeightFrag = [&](int layer, int f) __attribute__((always_inline)) -> Vec8<T> {
 		const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(wRsrc, wLaneOff, layer * 73728 + f * 2048, 0);
 		return __builtin_bit_cast(Vec8<T>, v);
 	};
-	// Fragment f = (dy*3+dx)*4+ks is first used in macro-step dx*4+ks of a layer's first
-	// unit.  The 24 fragments with dx < 2 are double-buffered (a layer's set is refilled for
-	// the layer after next as soon as the layer has published); the 12 with dx = 2 exist
-	// once and are refilled for the next layer at the same point.  48 registers less than
-	// two full sets.
-	Vec8<T> w0[24], w1[24], wl[12];
-	auto earlyIdx = [](int f) { return (f / 12) * 8 + (f % 12); };      // dx < 2: f % 12 < 8
-	auto lateIdx = [](int f) { return (f / 12) * 4 + (f % 12) - 8; };   // dx = 2
-	auto loadWeights = [&](int layer, Vec8<T>(&w)[24]) {
+	// Fragment f = (dy*3+dx)*4+ks, ONE set of 36 (144 registers).  A layer's registers are
+	// free once its last unit is through the K loop; the next layer's set streams in right
+	// after the publish, the 12 fragments with dx = 1 first: the pre-run (below) uses them,
+	// and by the time the other 24 and the halo loads have been issued they have landed.
+	Vec8<T> wm[12], ws[24];
+	auto loadMidWeights = [&](int layer) __attribute__((always_inline)) {
 #pragma unroll
 		for (int f = 0; f < 36; ++f) {
-			if (f % 12 < 8) w[earlyIdx(f)] = loadWeightFrag(layer, f);
+			if ((f >> 2) % 3 == 1) wm[(f / 12) * 4 + (f & 3)] = loadWeightFrag(layer, f);
 		}
 	};
-	auto loadLateWeights = [&](int layer) {
+	auto loadSideWeights = [&](int layer) __attribute__((always_inline)) {
 #pragma unroll
 		for (int f = 0; f < 36; ++f) {
-			if (f % 12 >= 8) wl[lateIdx(f)] = loadWeightFrag(layer, f);
+			const int dx = (f >> 2) % 3;
+			if (dx != 1) ws[(f / 12) * 8 + (dx >> 1) * 4 + (f & 3)] = loadWeightFrag(layer, f);
 		}
 	};
-	loadWeights(0, w0);
-	loadLateWeights(0);
-	if (p.nLayers > 1) loadWeights(1, w1);
-	float biasNext = 0.f;  // wave 0: the bias of the layer after next in flight (one value per lane)
-	if (wave == 0) {
-		ldsBias[lane] = p.bias[lane];
-		if (p.nLayers > 1) ldsBias[64 + lane] = p.bias[64 + lane];
-	}
+	loadMidWeights(0);
+	loadSideWeights(0);
+	// The layer's bias, as this lane's 16 accumulator values of a row (channel ch*32 + 8g + 4hh
+	// + i at index 4g + i): the C operand of every unit's first MFMAs, so no accumulator is
+	// ever initialised by moves.  Fetched at the head of the weight stream.
+	const __amdgpu_buffer_rsrc_t biasRsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    const_cast<float *>(p.bias), 0, p.nLayers * 256, 0x00020000);
+	f32x16 biasVec;
+	auto loadBias = [&](int layer) __attribute__((always_inline)) {
+#pragma unroll
+		for (int g = 0; g < 4; ++g) {
+			const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(biasRsrc, (unsigned)((ch * 32 + 4 * hh + 8 * g) * 4), layer * 256, 0);
+#pragma unroll
+			for (int i = 0; i < 4; ++i) biasVec[4 * g + i] = __uint_as_float(v[i]);  // (bit_cast of a vector element reads element 0)
+		}
+	};
+	loadBias(0);
 
 	// per-lane LDS address parts (the swizzle depends only on the column: rows are 32 px)
 	// B fragment of macro-step (dx, ks): byte offset inside a row =
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// VARIANT 4 (diagnostic build only): per-wave cycle sums of the phases below
 	u64 prof[7] = {0, 0, 0, 0, 0, 0, 0};
 	float calibMax = 0.f;  // VARIANT 5: largest post-ReLU output of the current layer (this lane)
-	auto stamp = [&]() -> u64 {
+	auto stamp = [&]() __attribute__((always_inline)) -> u64 {
 		if constexpr (VARIANT == 4) {
 			__builtin_amdgcn_sched_barrier(0);
 			u64 t;
@@ -572,12 +578,17 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// sweep; the exchange round trip (~2.8k cycles per layer) hides behind them.
 	constexpr int kOrder[12] = {4, 5, 6, 7, 0, 1, 2, 3, 8, 9, 10, 11};
 #ifndef JU_PRERUN
-#define JU_PRERUN 1
+#define JU_PRERUN 2
 #endif
 	constexpr int kPreRun = JU_PRERUN;
-	f32x16 accPre[kPreRun > 0 ? kPreRun : 1][2];
+#ifndef JU_PREBEFORE
+#define JU_PREBEFORE 1
+#endif
+	constexpr int kPreBefore = JU_PREBEFORE;  // how many of them run BEFORE the halo loads are issued
+	f32x16 accPre0[2], accPre1[2], accPre2[2];  // (separate objects: an array indexed by the slot would live in scratch)
+	static_assert(kPreRun >= 0 && kPreRun <= 3, "at most three interior units per wave");
 	Vec8<T> fb[2][4];
-	auto issue = [&](unsigned rowAddr, int m, int set, int j) {
+	auto issue = [&](unsigned rowAddr, int m, int set, int j) __attribute__((always_inline)) {
 		const int dx = m >> 2, ks = m & 3;
 		const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
 		if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
@@ -598,14 +609,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		if (u < np2 && 2 * u + 3 <= rhv) nPre = k + 1;
 	}
 	const int preEnd = preFirst + 2 * nPre;  // first unit of this wave's parity at or after preFirst that is NOT pre-run
-	auto isPre = [&](int u) { return u >= preFirst && u < preEnd; };
+	auto isPre = [&](int u) __attribute__((always_inline)) { return u >= preFirst && u < preEnd; };
 	// next unit of this wave after `u` that runs whole (not pre-run), or -1
-	auto nextWhole = [&](int u) {
+	auto nextWhole = [&](int u) __attribute__((always_inline)) {
 		int v = u + 2;
 		if (isPre(v)) v = preEnd;
 		return v < np2 ? v : -1;
 	};
 	const int firstWhole = isPre(rp) ? (preEnd < np2 ? preEnd : -1) : (rp < np2 ? rp : -1);
+	const bool streamsInUnit = (firstWhole >= 0 || mySingle) && !(VARIANT & 2);  // the next layer's weights stream behind the last unit
 
 	// KIND 0: pre-run (accumulator init + positions 0..3); 1: finish (positions 4..11 +
 	// epilogue); 2: whole unit.  `primed`: the first step's fragments are already in flight
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// travel while this unit's epilogue runs.
 	auto unitSeg = [&](auto rowsTag, auto kindTag, auto resTag, auto inTag, auto outTag, f32x16(&acc)[2],
 	                   const int layer, const int unit, const bool primed, const int nextUnit,
-	                   const bool nextFinish, const Vec8<T>(&w)[24]) {
+	                   const bool nextFinish, const bool streamNext = false) __attribute__((always_inline)) {
 		constexpr int ROWS = decltype(rowsTag)::value;
 		constexpr int KIND = decltype(kindTag)::value;
 		constexpr bool residual = decltype(resTag)::value;
@@ -626,17 +638,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		constexpr int NR = ROWS + 2;      // input rows / fragment reads per macro-step
 		constexpr int NM = 3 * ROWS;      // MFMAs per macro-step
 		const int ra = 1 + 2 * unit;      // first output row (buffer row index)
-		if constexpr (KIND != 1) {
-			const float *biasPtr = ldsBias + (layer & 1) * 64 + ch * 32 + 4 * hh;
+		if constexpr (KIND != 1 && (VARIANT & 2)) {
 #pragma unroll
-			for (int g = 0; g < 4; ++g) {
-				const f32x4 bg = *reinterpret_cast<const f32x4 *>(biasPtr + 8 * g);
-#pragma unroll
-				for (int r = 0; r < ROWS; ++r) {
-#pragma unroll
-					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = bg[i];
-				}
-			}
+			for (int r = 0; r < ROWS; ++r) acc[r] = biasVec;
 		}
 		const unsigned rowAddr = ldsBase + inOff + (2 * unit) * kResRowBytes;
 		if (!(VARIANT & 2)) {
@@ -671,9 +675,28 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 						else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 						__builtin_amdgcn_sched_barrier(0);
 					}
-					acc[r] = mfma32(dx < 2 ? w[dy * 8 + dx * 4 + ks] : wl[dy * 4 + ks], fb[set][need], acc[r]);
+					// (a unit's first MFMA of each row takes the bias as its C operand)
+					acc[r] = mfma32(dx == 1 ? wm[dy * 4 + ks] : ws[dy * 8 + (dx >> 1) * 4 + ks], fb[set][need],
+					    (KIND != 1 && pos == P0 && dy == 0) ? biasVec : acc[r]);
 					if (more && k < NR) issue(rowAddr, kOrder[pos + 1 < 12 ? pos + 1 : 11], set ^ 1, k);
 					__builtin_amdgcn_sched_barrier(0);
+				}
+				// The wave's LAST unit of the layer: the three fragments of this step (and, after
+				// the first step, the bias) are dead now -- the next layer's go into the same
+				// registers from here, one step at a time, so the 36 loads per lane travel
+				// behind this unit's MFMAs instead of as a burst between the layers (four waves
+				// x 36 KB through the CU's 64 B/clk address path: ~2.4k cycles of issue).
+				if constexpr (KIND == 2) {
+					if (streamNext) {
+						if (pos == 0) loadBias(layer + 1);
+#pragma unroll
+						for (int dy = 0; dy < 3; ++dy) {
+							const Vec8<T> nf = loadWeightFrag(layer + 1, (dy * 3 + dx) * 4 + ks);
+							if (dx == 1) wm[dy * 4 + ks] = nf;
+							else ws[dy * 8 + (dx >> 1) * 4 + ks] = nf;
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}
 				}
 			}
 			// prime the next segment (a pair, or the single row: >= 3 input rows)
@@ -743,40 +766,45 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	using KFin = std::integral_constant<int, 1>;
 	using KWhole = std::integral_constant<int, 2>;
 	// the halo-independent third of up to kPreRun units of `layer` (input buffer inTag)
-	auto preRun = [&](auto inTag, auto outTag, const int layer, const Vec8<T>(&w)[24]) {
-		bool primed = false;
-#pragma unroll
-		for (int k = 0; k < kPreRun; ++k) {
+	// slots [LO, HI) of the pre-run
+	auto preRun = [&](auto inTag, auto outTag, auto loTag, auto hiTag, const int layer, const bool primedFirst)
+	                  __attribute__((always_inline)) {
+		constexpr int LO = decltype(loTag)::value, HI = decltype(hiTag)::value;
+		auto slot = [&](f32x16(&acc)[2], const int k) __attribute__((always_inline)) {
 			if (k < nPre) {
 				const int nu = (k + 1 < nPre) ? preFirst + 2 * (k + 1) : -1;
-				unitSeg(R2{}, KPre{}, std::false_type{}, inTag, outTag, accPre[k], layer, preFirst + 2 * k, primed, nu,
-				    false, w);
-				primed = nu >= 0 && !(VARIANT & 2);
+				unitSeg(R2{}, KPre{}, std::false_type{}, inTag, outTag, acc, layer, preFirst + 2 * k,
+				    (k > 0 || primedFirst) && !(VARIANT & 2), nu, false);
 			}
-		}
+		};
+		if constexpr (LO <= 0 && 0 < HI) slot(accPre0, 0);
+		if constexpr (LO <= 1 && 1 < HI) slot(accPre1, 1);
+		if constexpr (LO <= 2 && 2 < HI) slot(accPre2, 2);
 	};
 	// the rest of the layer: the pre-run units' remaining steps, then the other units whole
-	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const Vec8<T>(&w)[24]) {
+	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const bool streamW) __attribute__((always_inline)) {
 		const int afterPre = firstWhole >= 0 ? firstWhole : (mySingle ? np2 : -1);
-		bool primed = false;
-#pragma unroll
-		for (int k = 0; k < kPreRun; ++k) {
+		auto slot = [&](f32x16(&acc)[2], const int k) __attribute__((always_inline)) {
 			if (k < nPre) {
 				const bool nextIsPre = k + 1 < nPre;
 				const int nu = nextIsPre ? preFirst + 2 * (k + 1) : afterPre;
-				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre[k], layer, preFirst + 2 * k, primed, nu, nextIsPre, w);
-				primed = nu >= 0 && !(VARIANT & 2);
+				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, acc, layer, preFirst + 2 * k, k > 0 && !(VARIANT & 2), nu, nextIsPre);
 			}
-		}
+		};
+		if constexpr (kPreRun > 0) slot(accPre0, 0);
+		if constexpr (kPreRun > 1) slot(accPre1, 1);
+		if constexpr (kPreRun > 2) slot(accPre2, 2);
+		// (every finish segment primes its successor when there is one)
+		bool primed = nPre > 0 && afterPre >= 0 && !(VARIANT & 2);
 		f32x16 acc[2];
 		for (int u = firstWhole; u >= 0;) {
 			const int nw = nextWhole(u);
 			const int nu = nw >= 0 ? nw : (mySingle ? np2 : -1);
-			unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, w);
+			unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, streamW && nu < 0);
 			primed = nu >= 0 && !(VARIANT & 2);
 			u = nw;
 		}
-		if (mySingle) unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, w);
+		if (mySingle) unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, streamW);
 	};
 
 	// ------------------------------------------------------------------------
@@ -797,7 +825,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// it needs this region's next layer first), and the mailbox starts zeroed with the
 	// counts (e = 0 never matches a first write, e = 1).  The producer needs neither a drain
 	// nor a release: ONE hop instead of store-ack -> flag -> load.
-	auto epochMask = [&](int par) -> unsigned {
+	auto epochMask = [&](int par) __attribute__((always_inline)) -> unsigned {
 		const unsigned e = pubCount[par] & 3u;
 		return (e & 1u) << 15 | (e >> 1) << 31;
 	};
@@ -873,7 +901,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	}
 	constexpr unsigned kParityBytes = kResMailSlots * 16u;
 	// `layer`: the layer whose output (in buffer `off`) is published
-	auto publish = [&](auto offTag, int layer) {
+	auto publish = [&](auto offTag, int layer) __attribute__((always_inline)) {
 		constexpr int off = decltype(offTag)::value;
 		// (the caller has just passed the workgroup barrier: the region's output is in LDS)
 		const int ppar = (layer + 1) & 1;
@@ -893,7 +921,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	};
 	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
 	// returns false on timeout (uniform across the workgroup)
-	auto fillHalo = [&](auto offTag, int layer, auto &&behindFirstPass) -> bool {
+	auto fillHalo = [&](auto offTag, int layer, auto &&behindFirstPass) __attribute__((always_inline)) -> bool {
 		constexpr int off = decltype(offTag)::value;
 		bool first = true;
 		const u64 t0 = __builtin_amdgcn_s_memrealtime();
@@ -949,13 +977,13 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int L = p.nLayers;
 	// RES / PAR are compile-time: a runtime `if (residual)` around the epilogue's LDS
 	// read makes hipcc branch and wait per element (+1 us per layer, measured).
-	auto layerStep = [&](auto resTag, auto parTag, const int i, Vec8<T>(&wc)[24], const Vec8<T>(&wn)[24]) -> bool {
+	auto layerStep = [&](auto resTag, auto parTag, const int i) __attribute__((always_inline)) -> bool {
 		constexpr int PAR = decltype(parTag)::value;
 		using InT = std::integral_constant<int, PAR ? kResOffB : kResOffA>;
 		using OutT = std::integral_constant<int, PAR ? kResOffA : kResOffB>;
 		const bool more = i + 1 < L;
 		const u64 t0 = stamp();
-		finishLayer(resTag, InT{}, OutT{}, i, wc);
+		finishLayer(resTag, InT{}, OutT{}, i, more && streamsInUnit);
 		if constexpr (VARIANT == 5) {
 			// per-layer maximum over the frame -> debug[i] (non-negative floats order like
 			// their bit patterns, so an integer atomic max does it)
@@ -966,35 +994,45 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			calibMax = 0.f;
 		}
 		const u64 t1 = stamp();
-		// bias of layer i+1 (fetched one step ago) into the slot layer i-1 used: its last
-		// readers passed the previous step's barrier, the next layer's pre-run reads it
-		// behind this step's
-		if (i >= 1 && more && wave == 0) ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
 		__syncthreads();
 		const u64 t2 = stamp();
 		if (more && xchg) publish(OutT{}, i);
+		// the pre-run's first fragments (interior rows of this layer's output) travel
+		// while the weight stream is issued
+		const bool primePre = more && nPre > 0 && !(VARIANT & 2);
+		if (primePre) {
+			const unsigned na = ldsBase + OutT::value + (2 * preFirst) * kResRowBytes;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) issue(na, kOrder[0], 0, j);
+			__builtin_amdgcn_sched_barrier(0);
+		}
 		const u64 t3 = stamp();
 		// The weight stream goes out BETWEEN the publish and the sweep: its ~2.2k cycles of
 		// issue (four waves push 144 KB through the CU's 64 B/clk address path) pass while
 		// the neighbours' write-through stores travel (vmcnt is in-order: the halo loads
 		// return behind the weights, which is when they would have been valid anyway).
-		// This layer's registers are free: the early set is refilled for layer i+2, the
-		// late set for layer i+1.  Measured: sweep first / between the two sets / after
+		// This layer's weight registers are free: the next layer's set goes into them.  Measured: sweep first / between the two sets / after
 		// both = 452 / 438 / 430 us per tower; an extra 256-1024 cycles of sleep before the
 		// sweep -3 ... +10 us.  (Round 1 had the stream after the sweep: ~4k + 2.2k cycles in
 		// series; streaming from inside the K loop was no faster.)
-		if (more) loadLateWeights(i + 1);
-		if (i + 2 < L) {
-			loadWeights(i + 2, wc);
-			if (wave == 0) biasNext = p.bias[(i + 2) * 64 + lane];
+		if (more && !streamsInUnit) {  // (a wave without a whole unit: tiny regions)
+			loadBias(i + 1);
+			loadMidWeights(i + 1);
+			loadSideWeights(i + 1);
 		}
 		const u64 t4 = stamp();
 		if (more && xchg) {
 			// the next layer's halo-independent steps run behind the first pass's loads
-			const bool okFill = fillHalo(OutT{}, i, [&] { preRun(OutT{}, InT{}, i + 1, wn); });
+			using Z = std::integral_constant<int, 0>;
+			using Split = std::integral_constant<int, kPreBefore>;
+			using N = std::integral_constant<int, kPreRun>;
+			preRun(OutT{}, InT{}, Z{}, Split{}, i + 1, primePre);
+			const bool okFill = fillHalo(OutT{}, i, [&]() __attribute__((always_inline)) {
+				preRun(OutT{}, InT{}, Split{}, N{}, i + 1, primePre);
+			});
 			if (!okFill) return false;
 		} else {
-			if (more) preRun(OutT{}, InT{}, i + 1, wn);
+			if (more) preRun(OutT{}, InT{}, std::integral_constant<int, 0>{}, std::integral_constant<int, kPreRun>{}, i + 1, primePre);
 			__syncthreads();
 		}
 		const u64 t5 = stamp();
@@ -1009,17 +1047,18 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	using Yes = std::true_type;
 	using P0 = std::integral_constant<int, 0>;
 	using P1 = std::integral_constant<int, 1>;
-	preRun(std::integral_constant<int, kResOffA>{}, std::integral_constant<int, kResOffB>{}, 0, w0);
+	preRun(std::integral_constant<int, kResOffA>{}, std::integral_constant<int, kResOffB>{}, std::integral_constant<int, 0>{},
+	    std::integral_constant<int, kPreRun>{}, 0, false);
 	if (HEAD) {  // conv_1, then (conv1, conv2+skip) pairs: L is odd
-		if (!layerStep(No{}, P0{}, 0, w0, w1)) return;
+		if (!layerStep(No{}, P0{}, 0)) return;
 		for (int i = 1; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P1{}, i, w1, w0)) return;
-			if (!layerStep(Yes{}, P0{}, i + 1, w0, w1)) return;
+			if (!layerStep(No{}, P1{}, i)) return;
+			if (!layerStep(Yes{}, P0{}, i + 1)) return;
 		}
 	} else {  // (conv1, conv2+skip) pairs: L is even
 		for (int i = 0; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P0{}, i, w0, w1)) return;
-			if (!layerStep(Yes{}, P1{}, i + 1, w1, w0)) return;
+			if (!layerStep(No{}, P0{}, i)) return;
+			if (!layerStep(Yes{}, P1{}, i + 1)) return;
 		}
 	}
 	const int finalOff = (L & 1) ? kResOffB : kResOffA;
