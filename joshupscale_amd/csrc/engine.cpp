@@ -154,6 +154,11 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 	} else if (flowConvIsFused(name)) {
 		cw.nb = 1;  // flow_block_kernel: one 32-cout block of fragments per wave
 		cw.rw = 1;
+	} else if (m_FlowFused && name.rfind("flow/", 0) == 0 && f.taps == 9 && (cinMap.size() == 128 || cinMap.size() == 256) &&
+	           f.cout % 32 == 0 && H * W <= 32768) {
+		cw.nb = 1;  // conv_splitk_kernel (the coarse levels of the flow net): 32-cout blocks of fragments
+		cw.rw = 1;
+		cw.splitK = true;
 	} else {
 		convTiling(H, W, f.cout, &cw.nb, &cw.rw);
 	}
@@ -264,6 +269,10 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 	s.flops = 2.0 * H * W * cw.taps * cw.cinReal * cw.cout;
 	if (tower) {
 		s.run = [dt, p](hipStream_t st) { launchConvTower(dt, p, st); };
+	} else if (cw.splitK && convSplitKSupported(p)) {
+		if (!m_Zeros.get()) m_Zeros = DeviceBuffer(256);  // (DeviceBuffer memory starts zeroed)
+		const void *zeros = m_Zeros.get();
+		s.run = [dt, p, zeros](hipStream_t st) { launchConvSplitK(dt, p, zeros, st); };
 	} else {
 		s.run = [dt, p](hipStream_t st) { launchConv(dt, p, st); };
 	}

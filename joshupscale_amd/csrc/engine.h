@@ -109,6 +109,7 @@ private:
 		DeviceBuffer bias;
 		int cinP = 0, cout = 0, taps = 9, cinReal = 0;
 		int nb = 2, rw = 2;  // tile shape the weights were packed for
+		bool splitK = false;  // a coarse flow layer that runs as conv_splitk_kernel (packed with nb = 1)
 	};
 
 	Tensor &addTensor(const std::string &name, std::size_t count, bool f32 = false,
@@ -166,6 +167,7 @@ private:
 	// resident 8-bit tower (tower8_resident_kernel): every block's operands in one buffer each
 	DeviceBuffer m_Fp8TowerW, m_Fp8TowerScaleA, m_Fp8TowerBias, m_Fp8TowerScaleB, m_Fp8TowerMul;
 	DeviceBuffer m_TailW2, m_TailB2, m_TailW2Frag;
+	DeviceBuffer m_Zeros;  // a zero page: the source of out-of-image pixels for LDS-DMA tile staging
 	DeviceBuffer m_TemporalAcc;  // 32.32 fixed-point sum of |gen - pre_warp| (temporal filter)
 	// flow auto-encoder: which blocks run as ONE launch (flow_block_kernel: both convs, the
 	// pool, and the preceding bilinear x2).  Unit k < 2*nb = block k+1, the last = the head

@@ -44,6 +44,22 @@ constexpr int kF8Lds = 2 * kF8TileBytes + 4 * kF8Slice;  // 77824: two workgroup
 // instructions, or with one workgroup per CU, results are bit-stable.  Cause not
 // understood; the plain global path below is the one every other kernel here uses.)
 // 16 bytes per lane, memory -> LDS without a VGPR round trip (lands at l + lane * 16)
+// Probe builds only (tools/probes/fp8_stale_tile.sh, never the product): JU_FP8_MUBUF moves the
+// same bytes with buffer instructions, JU_FP8_NOWAIT drops the explicit DMA waits in front of the
+// barriers -- the two ingredients of the stale-tile report, separately switchable.
+#if defined(JU_FP8_MUBUF)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t probeBuffer(const void *base) {
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
+}
+__device__ __forceinline__ void dmaToLds16(const unsigned char *base, unsigned uniformOff, unsigned laneOff,
+    void *l) {
+	__builtin_amdgcn_raw_ptr_buffer_load_lds(probeBuffer(base), (__attribute__((address_space(3))) void *)l, 16,
+	    static_cast<int>(laneOff), static_cast<int>(uniformOff), 0, 0);
+}
+__device__ __forceinline__ void store16(unsigned char *base, unsigned uniformOff, unsigned laneOff, i32x4 v) {
+	__builtin_amdgcn_raw_buffer_store_b128(v, probeBuffer(base), static_cast<int>(laneOff), static_cast<int>(uniformOff), 0);
+}
+#else
 __device__ __forceinline__ void dmaToLds16(const unsigned char *base, unsigned uniformOff, unsigned laneOff,
     void *l) {
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + uniformOff + laneOff),
@@ -52,6 +68,12 @@ __device__ __forceinline__ void dmaToLds16(const unsigned char *base, unsigned u
 __device__ __forceinline__ void store16(unsigned char *base, unsigned uniformOff, unsigned laneOff, i32x4 v) {
 	*reinterpret_cast<i32x4 *>(base + uniformOff + laneOff) = v;
 }
+#endif
+#if defined(JU_FP8_NOWAIT)
+#define JU_F8_DMA_WAIT() ((void)0)
+#else
+#define JU_F8_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
 
 // e4m3 of four non-negative values, saturating (the hardware conversion returns NaN
 // above 448: tools/probes/fp8_mfma_probe.hip), packed into one dword
@@ -161,7 +183,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 
 	// the first tile has landed.  hipcc does not count a buffer load to LDS as an LDS write
 	// the barrier's fence must wait for (it emitted vmcnt(23) here: rare stale tiles)
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	JU_F8_DMA_WAIT();
 	__syncthreads();
 
 	int buf = 0;
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 
 		// every wave is done with this tile's input; the next tile and the skip records
 		// have landed (explicit wait: see the prologue)
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		JU_F8_DMA_WAIT();
 		__syncthreads();
 
 		// ---- epilogue: bias is in the accumulator; + skip, ReLU ----
