@@ -44,31 +44,36 @@ constexpr int kF8Lds = 2 * kF8TileBytes + 4 * kF8Slice;  // 77824: two workgroup
 // instructions, or with one workgroup per CU, results are bit-stable.  Cause not
 // understood; the plain global path below is the one every other kernel here uses.)
 // 16 bytes per lane, memory -> LDS without a VGPR round trip (lands at l + lane * 16)
-// Probe builds only (tools/probes/fp8_stale_tile.sh, never the product): JU_FP8_MUBUF moves the
-// same bytes with buffer instructions, JU_FP8_NOWAIT drops the explicit DMA waits in front of the
-// barriers -- the two ingredients of the stale-tile report, separately switchable.
+// Probe builds only (tools/probes/fp8_stale_tile.sh, never the product): JU_FP8_MUBUF_LD / _ST (or
+// JU_FP8_MUBUF for both) move the same bytes with buffer instructions, JU_FP8_NOWAIT drops the
+// explicit DMA waits in front of the barriers -- the ingredients of the stale-tile report,
+// separately switchable.
 #if defined(JU_FP8_MUBUF)
+#define JU_FP8_MUBUF_LD 1
+#define JU_FP8_MUBUF_ST 1
+#endif
+#if defined(JU_FP8_MUBUF_LD) || defined(JU_FP8_MUBUF_ST)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t probeBuffer(const void *base) {
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
 }
+#endif
 __device__ __forceinline__ void dmaToLds16(const unsigned char *base, unsigned uniformOff, unsigned laneOff,
     void *l) {
+#if defined(JU_FP8_MUBUF_LD)
 	__builtin_amdgcn_raw_ptr_buffer_load_lds(probeBuffer(base), (__attribute__((address_space(3))) void *)l, 16,
 	    static_cast<int>(laneOff), static_cast<int>(uniformOff), 0, 0);
-}
-__device__ __forceinline__ void store16(unsigned char *base, unsigned uniformOff, unsigned laneOff, i32x4 v) {
-	__builtin_amdgcn_raw_buffer_store_b128(v, probeBuffer(base), static_cast<int>(laneOff), static_cast<int>(uniformOff), 0);
-}
 #else
-__device__ __forceinline__ void dmaToLds16(const unsigned char *base, unsigned uniformOff, unsigned laneOff,
-    void *l) {
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + uniformOff + laneOff),
 	    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+#endif
 }
 __device__ __forceinline__ void store16(unsigned char *base, unsigned uniformOff, unsigned laneOff, i32x4 v) {
+#if defined(JU_FP8_MUBUF_ST)
+	__builtin_amdgcn_raw_buffer_store_b128(v, probeBuffer(base), static_cast<int>(laneOff), static_cast<int>(uniformOff), 0);
+#else
 	*reinterpret_cast<i32x4 *>(base + uniformOff + laneOff) = v;
-}
 #endif
+}
 #if defined(JU_FP8_NOWAIT)
 #define JU_F8_DMA_WAIT() ((void)0)
 #else

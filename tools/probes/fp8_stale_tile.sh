@@ -12,7 +12,7 @@
 # first tile is read before it has landed); the other two pass.
 set -u
 cd "$(dirname "$0")/../.."
-VARIANTS="mubuf_nowait:-DJU_FP8_MUBUF -DJU_FP8_NOWAIT|mubuf_wait:-DJU_FP8_MUBUF|global_nowait:-DJU_FP8_NOWAIT"
+VARIANTS="mubuf_nowait:-DJU_FP8_MUBUF -DJU_FP8_NOWAIT|mubuf_wait:-DJU_FP8_MUBUF|mubuf_ld:-DJU_FP8_MUBUF_LD|mubuf_st:-DJU_FP8_MUBUF_ST|global_nowait:-DJU_FP8_NOWAIT"
 if [ "${1:-}" = build ]; then
   make -s || exit 1
   mkdir -p build/probes
@@ -26,7 +26,7 @@ if [ "${1:-}" = build ]; then
   done
   exit 0
 fi
-for n in mubuf_nowait mubuf_wait global_nowait; do
+for n in ${PROBE_VARIANTS:-mubuf_nowait mubuf_wait mubuf_ld mubuf_st global_nowait}; do
   for rep in 1 2 3; do
     JU_LIBRARY=build/probes/libju_fp8_$n.so timeout 300 python3 -m pytest tests/test_gpu_parity.py -q -m gpu \
       -k test_fp8_tower_bytes_do_not_depend_on_the_grid 2>&1 | grep -E "passed|failed" | sed "s/^/$n run $rep: /"
