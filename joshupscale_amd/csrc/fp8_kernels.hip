@@ -231,7 +231,8 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 		// 32 bytes: channels 32h .. 32h+31 of the lane's pixel) feed 12 instructions ----
 		const unsigned char *tileBase = smT + buf * kF8TileBytes;
 #pragma unroll
-		for (int dx = 0; dx < 3; ++dx) {
+		for (int t = 0; t < 3; ++t) {
+			const int dx = t == 0 ? 1 : (t == 1 ? 0 : 2);  // tap order of all three 8-bit kernels: 1, 0, 2
 			// (keeps hipcc from hoisting all 18 fragments above the first instruction:
 			// 144 VGPRs, spills)
 			__builtin_amdgcn_sched_barrier(0);
@@ -482,21 +483,22 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 			if (p.skip & 2) goto epiA;
 			loadFrags(smX, pair, 0, f0);
 			loadFrags(smX, pair, 1, f1);
-#pragma unroll
-			for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 0], f0[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
-			}
-			loadFrags(smX, pair, 2, f0);
+			// (tap order 1, 0, 2: see tower8_kernels.hip)
 #pragma unroll
 			for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
 				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 1], f1[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
 			}
+			loadFrags(smX, pair, 2, f1);
 #pragma unroll
 			for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 2], f0[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
+				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 0], f0[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
+			}
+#pragma unroll
+			for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 2], f1[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
 			}
 		epiA:
 			if (p.skip & 32) continue;
@@ -552,8 +554,9 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 			loadFrags(smT, pair, 1, f1);
 			}
 #pragma unroll
-			for (int dx = 0; dx < ((p.skip & 4) ? 0 : 3); ++dx) {
-				if (dx == 1) loadFrags(smT, pair, 2, f0);
+			for (int t = 0; t < ((p.skip & 4) ? 0 : 3); ++t) {
+				const int dx = t == 0 ? 1 : (t == 1 ? 0 : 2);
+				if (t == 1) loadFrags(smT, pair, 2, f1);
 #pragma unroll
 				for (int dy = 0; dy < 3; ++dy) {
 					const i32x4 lo = *reinterpret_cast<const i32x4 *>(wbLane + (dy * 3 + dx) * 4096);
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 					const i32x8 w = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
 					for (int r = 0; r < 2; ++r) {
-						acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, (dx == 1 ? f1 : f0)[r + dy], acc[r], 0, 0, 0, scA2, 0, p.scaleB2);
+						acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, (t == 1 ? f0 : f1)[r + dy], acc[r], 0, 0, 0, scA2, 0, p.scaleB2);
 					}
 				}
 			}

@@ -229,9 +229,12 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			unsigned char *srec = smem + kT8OffS + (2 * u + 1) * kT8SRow + (px + 1) * 128 + hh * 8;
 			Vec4<T> rv[2][4];
 #pragma unroll
-			for (int dx = 0; dx < ((p.skip & 2) ? 0 : 3); ++dx) {
-				if (dx == 1) {
-					loadFrags(inOff, u, 2, f0);
+			// taps in the order dx = 1, 0, 2 (all three 8-bit kernels: the fp32 summation order is
+			// part of their byte equality): the middle tap reads no halo column
+			for (int t = 0; t < ((p.skip & 2) ? 0 : 3); ++t) {
+				const int dx = t == 0 ? 1 : (t == 1 ? 0 : 2);
+				if (t == 1) {
+					loadFrags(inOff, u, 2, f1);
 					if constexpr (SECOND) {
 #pragma unroll
 						for (int r = 0; r < 2; ++r) {
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 				for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
 					for (int r = 0; r < 2; ++r) {
-						acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w[dy * 3 + dx], (dx == 1 ? f1 : f0)[r + dy], acc[r],
+						acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w[dy * 3 + dx], (t == 1 ? f0 : f1)[r + dy], acc[r],
 						    0, 0, 0, scA, 0, scB);
 					}
 				}
