@@ -19,7 +19,7 @@ import csv, glob, os, collections, json, re
 R=os.environ['GRAFT_REPO_ROOT']
 def short(k):
     k=k.split('(')[0]
-    m=re.search(r'(\d+)(tower8_resident_kernel|tower_resident_kernel|res_block_fp8_kernel|res_block_kernel|flow_block_kernel|conv_tower_fp8_kernel|conv_tower_kernel|quantize_tower_kernel|conv_mfma_kernel|tail_fused_kernel|warp_pack_kernel|pack_frames_kernel|upsample2_kernel|maxpool2_kernel)(.*)', k)
+    m=re.search(r'(\d+)(tower8_resident_kernel|tower_resident_kernel|res_block_fp8_kernel|res_block_kernel|flow_block_kernel|conv_splitk_kernel|conv_tower_fp8_kernel|conv_tower_kernel|quantize_tower_kernel|conv_mfma_kernel|tail_fused_kernel|warp_pack_kernel|pack_frames_kernel|upsample2_kernel|maxpool2_kernel)(.*)', k)
     if not m: return None
     name=m.group(2)
     if name=='conv_tower_fp8_kernel':
@@ -27,6 +27,9 @@ def short(k):
     if name=='flow_block_kernel':
         p=re.search(r'Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELi(\d)', m.group(3))
         if p: name+=f'<cin{p.group(1)},cmid{p.group(2)},th{p.group(3)},ups{p.group(4)},pool{p.group(5)},out{p.group(6)}>'
+    if name=='conv_splitk_kernel':
+        p=re.search(r'Li(\d+)ELi(\d+)ELb(\d)', m.group(3))
+        if p: name+=f'<cin{p.group(1)},cb{p.group(2)},pool{p.group(3)}>'
     if name=='conv_mfma_kernel':
         p=re.search(r'Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)', m.group(3))
         if p: name+=f'<taps{p.group(1)},ck{p.group(2)},nb{p.group(3)},rw{p.group(4)},dbuf{p.group(5)}>'
