@@ -588,6 +588,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	f32x16 accPre0[2], accPre1[2], accPre2[2];  // (separate objects: an array indexed by the slot would live in scratch)
 	static_assert(kPreRun >= 0 && kPreRun <= 3, "at most three interior units per wave");
 	Vec8<T> fb[2][4];
+	// (The reads are asm so that they can be issued a macro-step ahead with counted waits.  To the
+	// compiler an asm output is defined when the statement ends -- it may copy the register before
+	// the data has landed -- so a fragment's live range is kept to the one macro-step between its
+	// read and its MFMAs and nothing else is read this way: reading the residual early the same way
+	// was tried and produced rare wrong values under this kernel's register pressure.  The
+	// determinism soak and the parity suite guard it.)
 	auto issue = [&](unsigned rowAddr, int m, int set, int j) __attribute__((always_inline)) {
 		const int dx = m >> 2, ks = m & 3;
 		const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
