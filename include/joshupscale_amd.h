@@ -189,12 +189,13 @@ JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double
 /* How the runtime has been executing: "graph_replays" / "eager_runs" (per-frame programs
  * submitted as one hipGraph replay / as individual launches so far), "direct_graphs"
  * (graphs cached for JU_LOC_DEVICE frame tuples), "resident_tower" / "resident_flow"
- * (1 when the one-launch tower kernel is in use), "launches_per_frame". */
+ * (1 when the one-launch tower kernel is in use), "launches_per_frame", "tower_variant". */
 JU_API int ju_get_stat(const ju_runtime *runtime, const char *key, double *value);
 
 /* Developer switches (timing ablations and fault injection; never needed by a
- * caller).  Keys: "tower_variant" 0..5 (0 = product kernel, 4 = phase profile, 5 =
- * per-layer output maxima for quantisation calibration); "resident_fault" n
+ * caller).  Keys: "tower_variant" (0 = product kernel, 4 = phase profile, 5 = per-layer
+ * output maxima for quantisation calibration, 8 = the resident tower's plain schedule:
+ * same bytes, tests compare it with the product's); "resident_fault" n
  * (launch the resident tower n workgroups short: tests the fallback). */
 JU_API int ju_debug_set(const char *key, int value);
 

@@ -1427,6 +1427,7 @@ double Engine::stat(const std::string &key) const {
 	if (key == "resident_flow") return m_ResidentFlow ? 1.0 : 0.0;
 	if (key == "fallbacks") return static_cast<double>(m_Fallbacks);
 	if (key == "launches_per_frame") return static_cast<double>(m_Program[0].size());
+	if (key == "tower_variant") return static_cast<double>(towerVariant());  // (developer switch, tests)
 	if (key == "direct_graphs") {
 		double n = 0;
 		for (const auto &kv : m_DirectGraphs) n += kv.second.graph.valid() ? 1 : 0;

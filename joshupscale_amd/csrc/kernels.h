@@ -223,6 +223,7 @@ void launchResidentTower(DType dt, const ResidentTowerParams &p, hipStream_t str
 
 // Timing-only ablation switch of the tower kernel (0 = product kernel).
 void setTowerVariant(int variant);
+int towerVariant();
 // Test hook: launch the resident tower `n` workgroups short, so that the bounded
 // neighbour waits expire (exercises the engine's fallback to the per-layer path).
 void setResidentFault(int n);

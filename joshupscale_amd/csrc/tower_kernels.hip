@@ -580,11 +580,17 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #ifndef JU_PRERUN
 #define JU_PRERUN 2
 #endif
-	constexpr int kPreRun = JU_PRERUN;
+	// VARIANT 8 (tests): the PLAIN schedule -- no pre-run, weights as a burst after the publish, units
+	// in their natural order -- with the same arithmetic per output element (same tap order, bias as
+	// the C operand), so its bytes must equal the product kernel's: the cross-check that the
+	// product's schedule (accumulators kept across the sweep, registers refilled behind MFMAs, asm
+	// fragment reads under its register pressure) loses or corrupts nothing.
+	constexpr bool kPlain = VARIANT == 8;
+	constexpr int kPreRun = kPlain ? 0 : JU_PRERUN;
 #ifndef JU_PREBEFORE
 #define JU_PREBEFORE 1
 #endif
-	constexpr int kPreBefore = JU_PREBEFORE;  // how many of them run BEFORE the halo loads are issued
+	constexpr int kPreBefore = kPlain ? 0 : JU_PREBEFORE;  // how many of them run BEFORE the halo loads are issued
 	f32x16 accPre0[2], accPre1[2], accPre2[2];  // (separate objects: an array indexed by the slot would live in scratch)
 	static_assert(kPreRun >= 0 && kPreRun <= 3, "at most three interior units per wave");
 	Vec8<T> fb[2][4];
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		return v < np2 ? v : -1;
 	};
 	const int firstWhole = isPre(rp) ? (preEnd < np2 ? preEnd : -1) : (rp < np2 ? rp : -1);
-	const bool streamsInUnit = (firstWhole >= 0 || mySingle) && !(VARIANT & 2);  // the next layer's weights stream behind the last unit
+	const bool streamsInUnit = (firstWhole >= 0 || mySingle) && !(VARIANT & 2) && !kPlain;  // the next layer's weights stream behind the last unit
 
 	// KIND 0: pre-run (accumulator init + positions 0..3); 1: finish (positions 4..11 +
 	// epilogue); 2: whole unit.  `primed`: the first step's fragments are already in flight
@@ -1172,6 +1178,7 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 }
 
 void setTowerVariant(int v) { g_TowerVariant = v; }
+int towerVariant() { return g_TowerVariant; }
 void setResidentFault(int n) { g_ResidentFault = n; }
 int residentFaultForTests() { return g_ResidentFault; }
 
@@ -1233,10 +1240,12 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 		return;
 	}
 	if (dt == kF16) {
-		launchResidentT<f16, 0, true>(p, stream);
+		if (g_TowerVariant == 8) launchResidentT<f16, 8, true>(p, stream);
+		else launchResidentT<f16, 0, true>(p, stream);
 		return;
 	}
 	switch (g_TowerVariant) {
+	case 8: launchResidentT<bf16, 8, true>(p, stream); break;
 	case 1: launchResidentT<bf16, 1, true>(p, stream); break;
 	case 2: launchResidentT<bf16, 2, true>(p, stream); break;
 	case 3: launchResidentT<bf16, 3, true>(p, stream); break;

@@ -118,6 +118,41 @@ def test_full_size_resident_tower_against_the_per_block_kernels(monkeypatch, dty
         assert st["max"] <= (2 if dtype == R.DTYPE_BF16 else 1) and st["frac_gt1"] <= 1e-3, (t, st)
 
 
+@pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16])
+def test_resident_tower_schedule_does_not_change_the_bytes(dtype):
+    """The product schedule of tower_resident_kernel (two units' halo-independent steps run around
+    the halo loads with their accumulators kept across the sweep, the next layer's weights refilled
+    behind the last unit's MFMAs, hand-issued fragment reads under 480 registers) against the PLAIN
+    schedule of the same kernel (debug variant 8: no pre-run, weight burst, natural unit order).
+    Both execute the same arithmetic per output element, so the frames must be EQUAL -- a lost
+    halo, a fragment register copied before its data landed, or a weight register refilled too
+    early shows as a difference here, where the comparison against the per-block kernels (other
+    summation order) only bounds it."""
+    lib = R.load_library()
+    cases = [(M.PRESETS["psp-quality"], 4), (M.PRESETS["psp-fast"], 3)]
+    from helpers import small_config
+    cases.append((small_config(frame_height=34, frame_width=50, gen_blocks=3), 4))
+    cases.append((small_config(frame_height=17, frame_width=33, gen_blocks=2), 3))
+    for cfg, n in cases:
+        blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+        frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=11, kind="noise")
+        outs = {}
+        for variant in (0, 8):
+            lib.ju_debug_set(b"tower_variant", variant)
+            try:
+                rt = R.Runtime(blob, 0, dtype)
+                assert rt.stat("resident_tower") == 1 and rt.stat("tower_variant") == variant
+                outs[variant] = [rt.process_image(f).copy() for f in frames]
+                trunk = rt.read_tensor("trunk").copy()
+                outs[(variant, "trunk")] = trunk
+                rt.close()
+            finally:
+                lib.ju_debug_set(b"tower_variant", 0)
+        assert np.array_equal(outs[(0, "trunk")], outs[(8, "trunk")]), (cfg.frame_height, cfg.frame_width)
+        for a, b in zip(outs[0], outs[8]):
+            assert np.array_equal(a, b), (cfg.frame_height, cfg.frame_width)
+
+
 def test_device_frame_graphs_equal_eager_launches(monkeypatch):
     """Config 3 (psp-fast, fp16, latency-optimised graph capture): on device frames the
     cached graph of a frame-buffer tuple replays exactly what the eager launches do, for a
