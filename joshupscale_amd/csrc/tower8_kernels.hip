@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	};
 	auto fillHalo = [&](auto offTag, int layer) -> bool {
 		constexpr int off = decltype(offTag)::value;
-		const u64 t0 = __builtin_amdgcn_s_memrealtime();
+		u64 t0 = 0;  // (the clock is read only once a pass has failed: a scalar-memory round trip)
 		const int par = (layer + 1) & 1;
 		const unsigned tm = epochMask(par);
 		const unsigned soff = par ? kParityBytes : 0u;
@@ -404,7 +404,9 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 				}
 			}
 			if (pending != 0) {
-				if (__builtin_amdgcn_s_memrealtime() - t0 > kT8TimeoutTicks) {
+				const u64 now = __builtin_amdgcn_s_memrealtime();
+				if (t0 == 0) t0 = now;
+				if (now - t0 > kT8TimeoutTicks) {
 					*failFlag = 1;
 					__hip_atomic_store((gu32 *)p.error, 0x800u + (unsigned)layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					break;

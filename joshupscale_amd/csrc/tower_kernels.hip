@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	auto fillHalo = [&](auto offTag, int layer, auto &&behindFirstPass) __attribute__((always_inline)) -> bool {
 		constexpr int off = decltype(offTag)::value;
 		bool first = true;
-		const u64 t0 = __builtin_amdgcn_s_memrealtime();
+		u64 t0 = 0;  // (the clock is read only once a pass has failed: a scalar-memory round trip)
 		const int par = (layer + 1) & 1;
 		// (this region published the same layer a moment ago: its count is the neighbours')
 		const unsigned tm = epochMask(par);
@@ -966,7 +966,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				}
 			}
 			if (pending != 0) {
-				if (__builtin_amdgcn_s_memrealtime() - t0 > kResTimeoutTicks) {
+				const u64 now = __builtin_amdgcn_s_memrealtime();
+				if (t0 == 0) t0 = now;
+				if (now - t0 > kResTimeoutTicks) {
 					*failFlag = 1;
 					__hip_atomic_store((gu32 *)p.error, 0x700u + (unsigned)layer, __ATOMIC_RELAXED,
 					    __HIP_MEMORY_SCOPE_SYSTEM);
