@@ -935,7 +935,6 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// returns false on timeout (uniform across the workgroup)
 	auto fillHalo = [&](auto offTag, int layer, auto &&behindFirstPass) __attribute__((always_inline)) -> bool {
 		constexpr int off = decltype(offTag)::value;
-		bool first = true;
 		u64 t0 = 0;  // (the clock is read only once a pass has failed: a scalar-memory round trip)
 		const int par = (layer + 1) & 1;
 		// (this region published the same layer a moment ago: its count is the neighbours')
@@ -944,18 +943,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		unsigned pending = sweepValid;
 		// sweep: all loads of a pass in flight together, sc1 (never a stale L1/L2 line);
 		// a slot is accepted only when all four dwords carry the expected epoch
-		while (__any(pending != 0)) {
-			u32x4 hv[NS];
+		u32x4 hv[NS];
+		auto loadPass = [&]() __attribute__((always_inline)) {
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
 				hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, sweepSrc[it], soff, kSc1);
 			}
-			if (first) {  // (loads the caller wants in flight BEHIND the first pass; vmcnt is in-order)
-				__builtin_amdgcn_sched_barrier(0);
-				behindFirstPass();
-				__builtin_amdgcn_sched_barrier(0);
-				first = false;
-			}
+		};
+		auto checkPass = [&]() __attribute__((always_inline)) {
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
 				const u32x4 tg = hv[it] & 0x80008000u;
@@ -965,19 +960,30 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					pending &= ~(1u << it);
 				}
 			}
-			if (pending != 0) {
-				const u64 now = __builtin_amdgcn_s_memrealtime();
-				if (t0 == 0) t0 = now;
-				if (now - t0 > kResTimeoutTicks) {
+		};
+		// The first pass is straight-line code (not the loop's first iteration): what the caller
+		// runs behind its loads -- a pre-run unit, 32 accumulator registers -- is then defined on
+		// one path only and needs no copies where the paths would join.
+		loadPass();
+		__builtin_amdgcn_sched_barrier(0);
+		behindFirstPass();  // (work the caller wants done while the loads travel; vmcnt is in-order)
+		__builtin_amdgcn_sched_barrier(0);
+		checkPass();
+		while (__any(pending != 0)) {
+			const u64 now = __builtin_amdgcn_s_memrealtime();
+			if (t0 == 0) t0 = now;
+			if (now - t0 > kResTimeoutTicks) {
+				if (pending != 0) {
 					*failFlag = 1;
 					__hip_atomic_store((gu32 *)p.error, 0x700u + (unsigned)layer, __ATOMIC_RELAXED,
 					    __HIP_MEMORY_SCOPE_SYSTEM);
-					break;
 				}
-				__builtin_amdgcn_s_sleep(1);
+				break;
 			}
+			__builtin_amdgcn_s_sleep(1);
+			loadPass();
+			checkPass();
 		}
-		if (first) behindFirstPass();  // (a wave none of whose lanes has a slot to fetch)
 		__syncthreads();
 		return *failFlag == 0;
 	};
