@@ -638,7 +638,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// travel while this unit's epilogue runs.
 	auto unitSeg = [&](auto rowsTag, auto kindTag, auto resTag, auto inTag, auto outTag, f32x16(&acc)[2],
 	                   const int layer, const int unit, const bool primed, const int nextUnit,
-	                   const bool nextFinish, const bool streamNext = false) __attribute__((always_inline)) {
+	                   const bool nextFinish, auto streamTag) __attribute__((always_inline)) {
+		constexpr bool streamNext = decltype(streamTag)::value;  // (compile-time: no branch per macro-step)
 		constexpr int ROWS = decltype(rowsTag)::value;
 		constexpr int KIND = decltype(kindTag)::value;
 		constexpr bool residual = decltype(resTag)::value;
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			if (k < nPre) {
 				const int nu = (k + 1 < nPre) ? preFirst + 2 * (k + 1) : -1;
 				unitSeg(R2{}, KPre{}, std::false_type{}, inTag, outTag, acc, layer, preFirst + 2 * k,
-				    (k > 0 || primedFirst) && !(VARIANT & 2), nu, false);
+				    (k > 0 || primedFirst) && !(VARIANT & 2), nu, false, std::false_type{});
 			}
 		};
 		if constexpr (LO <= 0 && 0 < HI) slot(accPre0, 0);
@@ -800,7 +801,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			if (k < nPre) {
 				const bool nextIsPre = k + 1 < nPre;
 				const int nu = nextIsPre ? preFirst + 2 * (k + 1) : afterPre;
-				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, acc, layer, preFirst + 2 * k, k > 0 && !(VARIANT & 2), nu, nextIsPre);
+				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, acc, layer, preFirst + 2 * k, k > 0 && !(VARIANT & 2), nu, nextIsPre,
+				    std::false_type{});
 			}
 		};
 		if constexpr (kPreRun > 0) slot(accPre0, 0);
@@ -812,11 +814,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		for (int u = firstWhole; u >= 0;) {
 			const int nw = nextWhole(u);
 			const int nu = nw >= 0 ? nw : (mySingle ? np2 : -1);
-			unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, streamW && nu < 0);
+			if (streamW && nu < 0) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, std::true_type{});
+			else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, std::false_type{});
 			primed = nu >= 0 && !(VARIANT & 2);
 			u = nw;
 		}
-		if (mySingle) unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, streamW);
+		if (mySingle) {
+			if (streamW) unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, std::true_type{});
+			else unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, std::false_type{});
+		}
 	};
 
 	// ------------------------------------------------------------------------
