@@ -1,0 +1,15 @@
+#!/bin/bash
+# developer tool, GPU box: interleaved timing of the 8-bit resident tower in several builds of the library
+for r in 1 2 3; do
+  for L in "$@"; do
+    JU_LIBRARY=$L python3 - <<PY
+import os, sys
+sys.path.insert(0, ".")
+from joshupscale_amd import model_file as M, runtime as R
+cfg = M.PRESETS["psp-quality"]
+rt = R.Runtime(M.serialize(cfg, M.make_seeded_weights(cfg)), 0, R.DTYPE_FP8)
+ms = min(rt.time_steps("tower", 20)[0] for _ in range(3))
+print("%-28s %.1f us" % (os.path.basename(os.environ["JU_LIBRARY"]), ms * 1e3))
+PY
+  done
+done
