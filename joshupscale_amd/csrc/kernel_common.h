@@ -74,22 +74,21 @@ inline void ensureDynamicLds(const void *kern, int bytes, std::atomic<std::uint6
 	doneMask->fetch_or(bit, std::memory_order_release);
 }
 
-// four f32 -> packed 16-bit (RNE).  f16: a pairwise vector convert maps to one
-// v_cvt_pk_f16_f32 per two values (element-wise casts cost a convert per value plus
-// merges).  bf16: hipcc scalarises the vector form (more ops, not fewer), and an
-// inline-asm v_cvt_pk_bf16_f32 is not padded with the MFMA -> VALU wait states, so the
-// element-wise casts stay.
+// four f32 -> packed 16-bit (RNE): a pairwise vector convert maps to one v_cvt_pk_f16_f32 /
+// v_cvt_pk_bf16_f32 per two values.  The two halves are joined as INTEGERS: joined as a
+// 4-vector of the 16-bit type, hipcc merges the converts into one 4-wide truncation as soon
+// as an integer operation follows (reluPacked) and then scalarises it for bf16 -- a convert
+// per value plus a v_perm per pair, 48 instructions instead of 16 for a unit's 32 values in
+// the tower epilogue.
 template <typename T>
 __device__ __forceinline__ Vec4<T> pack4(float a, float b, float c, float d) {
-	if constexpr (std::is_same<T, _Float16>::value) {
-		typedef float f32x2p __attribute__((ext_vector_type(2)));
-		typedef T t2p __attribute__((ext_vector_type(2)));
-		const f32x2p lo = {a, b}, hi = {c, d};
-		return __builtin_shufflevector(__builtin_convertvector(lo, t2p), __builtin_convertvector(hi, t2p),
-		    0, 1, 2, 3);
-	} else {
-		return Vec4<T>{static_cast<T>(a), static_cast<T>(b), static_cast<T>(c), static_cast<T>(d)};
-	}
+	typedef float f32x2p __attribute__((ext_vector_type(2)));
+	typedef T t2p __attribute__((ext_vector_type(2)));
+	typedef unsigned u32x2p __attribute__((ext_vector_type(2)));
+	const f32x2p lo = {a, b}, hi = {c, d};
+	const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, t2p));
+	const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, t2p));
+	return __builtin_bit_cast(Vec4<T>, u32x2p{l, h});
 }
 
 inline void hipCheckLaunch(const char *what) {
@@ -190,13 +189,10 @@ __device__ __forceinline__ void tailRow(FetchB fetchB, const unsigned char *smW,
 		for (int g = 0; g < 4; ++g) {
 			Vec4<T> o;
 			if (t.slope < 0.0f) {  // (uniform)
-				o = reluPacked<T>(Vec4<T>{static_cast<T>(acc[nb][4 * g + 0]), static_cast<T>(acc[nb][4 * g + 1]),
-				    static_cast<T>(acc[nb][4 * g + 2]), static_cast<T>(acc[nb][4 * g + 3])});
+				o = reluPacked<T>(pack4<T>(acc[nb][4 * g + 0], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]));
 			} else {
-				o = Vec4<T>{static_cast<T>(leaky(acc[nb][4 * g + 0], t.slope)),
-				    static_cast<T>(leaky(acc[nb][4 * g + 1], t.slope)),
-				    static_cast<T>(leaky(acc[nb][4 * g + 2], t.slope)),
-				    static_cast<T>(leaky(acc[nb][4 * g + 3], t.slope))};
+				o = pack4<T>(leaky(acc[nb][4 * g + 0], t.slope), leaky(acc[nb][4 * g + 1], t.slope),
+				    leaky(acc[nb][4 * g + 2], t.slope), leaky(acc[nb][4 * g + 3], t.slope));
 			}
 			*reinterpret_cast<Vec4<T> *>(smMid + nb * 2048 + px * 64 +
 			                             ((g ^ ((px >> 2) & 3)) << 4) + hh * 8) = o;
