@@ -1105,8 +1105,9 @@ void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream) {
 }
 
 bool convSplitKSupported(const ConvParams &p) {
+	// (a pooled 256-channel layer does not occur in the flow net: not instantiated, not claimed)
 	return p.taps == 9 && (p.cin == 128 || p.cin == 256) && p.cout % 32 == 0 && !p.res && !p.outHead && !p.upsample &&
-	       p.nb == 1 && (!p.pool || (p.H % 2 == 0 && p.W % 2 == 0)) && p.H * p.W <= 32768;
+	       p.nb == 1 && (!p.pool || (p.cin == 128 && p.H % 2 == 0 && p.W % 2 == 0)) && p.H * p.W <= 32768;
 }
 
 void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStream_t stream) {
@@ -1167,7 +1168,6 @@ void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStrea
 	JU_SK_CASE(128, 2, false)
 	JU_SK_CASE(128, 2, true)
 	JU_SK_CASE(256, 1, false)
-	JU_SK_CASE(256, 1, true)
 #undef JU_SK_CASE
 	throw std::invalid_argument("split-K conv: unsupported shape");
 }

@@ -484,7 +484,10 @@ def test_flow_blocks_fused_and_per_layer_paths_agree(monkeypatch, dtype):
     both directions) and at the full benchmark size."""
     for cfg, n in [(small_config(frame_height=34, frame_width=70, gen_blocks=1), 3),
                    (small_config(frame_height=64, frame_width=96, gen_blocks=1, flow_activation="lrelu"), 2),
-                   (M.PRESETS["psp-fast"], 2)]:
+                   (M.PRESETS["psp-fast"], 2),
+                   # 544 x 960: the 1/4-resolution level (136 x 240, 128 channels) has more tiles than
+                   # CUs at every tile height, so conv_splitk_kernel takes two cout blocks per workgroup
+                   (small_config(frame_height=544, frame_width=960, gen_blocks=1), 2)]:
         blob = M.serialize(cfg, M.make_seeded_weights(cfg))
         frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=61, kind="smooth")
         runs = {}
