@@ -385,6 +385,15 @@ static_assert(kResRowBytes == 4352, "the ds_read immediates in tower_resident_ke
 constexpr int kResLds = kResOffMisc + 64 + 512;                     // flag, 2 bias slots
 constexpr int kResMailSlots = 4 * 32 * 8;                           // 16-byte slots per region per parity
 constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of s_memrealtime
+// Pre-run (see the kernel): units per wave whose halo-independent steps run inside the halo exchange,
+// and how many of them go in front of the halo loads.  -D overrides are for A/B builds only
+// (measured: 2 / 1 best; 1 / 0 +6 %, 2 / 2 +2 %, 3 / 1 +5 %).
+#ifndef JU_PRERUN
+#define JU_PRERUN 2
+#endif
+#ifndef JU_PREBEFORE
+#define JU_PREBEFORE 1
+#endif
 
 struct ResidentParams {
 	const void *in;           // first layer's input, addressed at image pixel (0,0)
@@ -577,9 +586,6 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// the halo loads of the layer's input are in flight ("pre-run"), and finish after the
 	// sweep; the exchange round trip (~2.8k cycles per layer) hides behind them.
 	constexpr int kOrder[12] = {4, 5, 6, 7, 0, 1, 2, 3, 8, 9, 10, 11};
-#ifndef JU_PRERUN
-#define JU_PRERUN 2
-#endif
 	// VARIANT 8 (tests): the PLAIN schedule -- no pre-run, weights as a burst after the publish, units
 	// in their natural order -- with the same arithmetic per output element (same tap order, bias as
 	// the C operand), so its bytes must equal the product kernel's: the cross-check that the
@@ -587,9 +593,6 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// fragment reads under its register pressure) loses or corrupts nothing.
 	constexpr bool kPlain = VARIANT == 8;
 	constexpr int kPreRun = kPlain ? 0 : JU_PRERUN;
-#ifndef JU_PREBEFORE
-#define JU_PREBEFORE 1
-#endif
 	constexpr int kPreBefore = kPlain ? 0 : JU_PREBEFORE;  // how many of them run BEFORE the halo loads are issued
 	f32x16 accPre0[2], accPre1[2], accPre2[2];  // (separate objects: an array indexed by the slot would live in scratch)
 	static_assert(kPreRun >= 0 && kPreRun <= 3, "at most three interior units per wave");
