@@ -35,7 +35,12 @@ harness: $(OUT)/libJoshUpscale.so tools/plugin_harness.cpp
 	g++ -O2 -std=c++17 -Iinclude tools/plugin_harness.cpp -o build/plugin_harness \
 	    -L$(OUT) -lJoshUpscale -Wl,-rpath,'$$ORIGIN/../$(OUT)'
 
+# probe build with the JU_FB_SKIP timing-ablation branches compiled in (tools/*_ablate.sh);
+# the product library above never carries them
+ablate:
+	$(MAKE) OBJ=build/obj_ablate OUT=build/ablate KERNELFLAGS="$(KERNELFLAGS) -DJU_ABLATE"
+
 clean:
 	rm -rf build $(OUT)
 
-.PHONY: all clean harness
+.PHONY: all clean harness ablate

@@ -23,6 +23,56 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+
+def pin_rank_to_cpus(local_rank: int, local_world: int) -> dict:
+    """Per-rank CPU affinity, set BEFORE anything touches the GPU (torch is not imported
+    yet): each rank's host thread -- it polls its stream while a frame runs -- gets its own
+    slice of the cores of the NUMA node its GPU hangs off.  sysfs only (amdgpu PCI functions
+    in bus order = the HIP runtime's default device order); when that does not describe
+    `local_world` or more GPUs the allowed cores are simply split evenly by local rank."""
+    info = {"how": "none"}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if local_world <= 1 and "RANK" not in os.environ:
+            return {"how": "unpinned (single process)", "cpus": len(allowed)}
+        cpus = None
+        base = "/sys/bus/pci/drivers/amdgpu"
+        gpus = []
+        if os.path.isdir(base):
+            for d in sorted(os.listdir(base)):
+                node = os.path.join(base, d, "numa_node")
+                cl = os.path.join(base, d, "local_cpulist")
+                if d.count(":") == 2 and os.path.exists(node) and os.path.exists(cl):
+                    gpus.append((d, int(open(node).read().strip() or -1), open(cl).read().strip()))
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if gpus and len(gpus) >= local_world and not visible and local_rank < len(gpus):
+            bdf, node, cpulist = gpus[local_rank]
+            local = set()
+            for part in cpulist.split(","):
+                if part:
+                    lo, _, hi = part.partition("-")
+                    local.update(range(int(lo), int(hi or lo) + 1))
+            local = sorted(local & set(allowed))
+            peers = [i for i, g in enumerate(gpus[:local_world]) if g[1] == node]
+            if local and local_rank in peers:
+                k, n = peers.index(local_rank), len(peers)
+                cpus = local[k * len(local) // n:(k + 1) * len(local) // n] or local
+                info = {"how": "sysfs numa_node of the rank's GPU", "gpu": bdf, "numa_node": node}
+        if cpus is None:
+            n = max(local_world, 1)
+            cpus = allowed[local_rank * len(allowed) // n:(local_rank + 1) * len(allowed) // n] or allowed
+            info = {"how": "allowed cores split evenly by local rank"}
+        os.sched_setaffinity(0, cpus)
+        info.update(cpus=len(cpus), first_cpu=cpus[0], last_cpu=cpus[-1])
+    except Exception as e:  # never fail a run over placement
+        info = {"how": f"unpinned ({type(e).__name__}: {e})"}
+    return info
+
+
+AFFINITY = pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")),
+                            int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -33,6 +83,7 @@ from joshupscale_amd import runtime as R  # noqa: E402
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0  # HBM3E, same guide
 PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled e4m3 MFMA (same guide: twice the bf16 rate)
+PREROLL_FRAMES = 256  # ~0.15 s of frames before --warmup: the GPU's clocks ramp while the first frames run
 TRAFFIC_PROFILE = "r02_tower_traffic.json"  # PMC summary of the dominant kernel (tools/pmc_traffic.sh)
 
 
@@ -68,6 +119,12 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-iters", type=int, default=20)
+    ap.add_argument("--preroll", type=int, default=PREROLL_FRAMES,
+                    help="untimed clock-warm frames in front of --warmup (fixed; not part of the contract's W)")
+    ap.add_argument("--no-prepare", action="store_true",
+                    help="do not register the frame buffers (ju_prepare_frames): graphs are then captured "
+                         "inside ju_process at a pair's second use, and a timed region that contains such a "
+                         "capture or an eager run is refused")
     args = ap.parse_args()
 
     rank, local_rank, world = jdist.env_world()
@@ -88,7 +145,9 @@ def main() -> int:
     blob = None
     if rank == 0:
         blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=42))
+    t_b = time.perf_counter()
     blob = jdist.broadcast_model(blob, device)
+    broadcast_s = time.perf_counter() - t_b
     dt = {"bf16": R.DTYPE_BF16, "fp16": R.DTYPE_F16, "fp8": R.DTYPE_FP8}[args.dtype]
     rt = R.Runtime(blob, device=local_rank, dtype=dt)
 
@@ -104,21 +163,39 @@ def main() -> int:
         ins = [R.host_image(clip[i]) for i in range(len(clip))]
         outs = [R.host_image(out_host)] * len(clip)
     torch.cuda.synchronize()
+    # Set-up: register every frame-buffer pair the loop will use, so that their hipGraphs are
+    # captured HERE (the reference captures its graphs in the constructor,
+    # tensorrt_backend.cc:257-263) and the timed region only replays.
+    prepared = 0
+    if not args.no_prepare:
+        for i in range(len(ins)):
+            prepared += rt.prepare_frames(ins[i], outs[i])
 
     def step(i: int) -> None:
         rt.process(ins[i % len(ins)], outs[i % len(outs)])
 
-    for i in range(args.warmup):
+    def counters() -> dict:
+        return {"replays": rt.stat("graph_replays"), "eager": rt.stat("eager_runs"),
+                "captures": rt.stat("graph_captures")}
+
+    for i in range(args.preroll):  # clock-warm, fixed, outside the contract's warm-up
         step(i)
+    for i in range(args.warmup):
+        step(args.preroll + i)
     jdist.barrier()
     torch.cuda.synchronize()
+    c0 = counters()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(args.preroll + args.warmup + i)
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0
     jdist.barrier()
     elapsed = time.perf_counter() - t0
+    c1 = counters()
+    timed_region = {k: int(c1[k] - c0[k]) for k in c0}
     elapsed = jdist.max_over_ranks(elapsed, device)
+    rank_fps = jdist.gather_floats(args.steps / own_elapsed, device)
 
     # per-frame latency of the synchronous boundary call (outside the timed region):
     # what a caller blocked in processImage sees; SURVEY 8d config 3 asks for p50/p99
@@ -131,6 +208,18 @@ def main() -> int:
         lat.sort()
 
     result = None
+    # a timed region that is not pure steady state is not a measurement of it: refuse
+    graphs_on = os.environ.get("JU_NO_GRAPH", "0") != "1" and os.environ.get("JU_DIRECT_GRAPH", "1") != "0"
+    dirty = graphs_on and (timed_region["captures"] > 0 or timed_region["eager"] > 0)
+    if dirty:
+        print(f"bench.py: rank {rank}: the timed region contained {timed_region['captures']} graph capture(s) and "
+              f"{timed_region['eager']} eager run(s) ({timed_region}); refusing to report a value. Register the "
+              "frame buffers (default) or raise --warmup past two uses of every buffer pair.", file=sys.stderr)
+    if max(jdist.gather_floats(float(dirty), device)) > 0:  # every rank leaves together
+        rt.close()
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return 3
     if rank == 0:
         fps = world * args.steps / elapsed
         # dominant kernel: the 3x3 64->64 convolution of the residual tower,
@@ -193,12 +282,18 @@ def main() -> int:
                             f"{'HBM' if args.location == 'device' else 'host memory (PCIe-inclusive)'}",
                 "weights": "seeded random-init (seed 42), reference default architecture",
                 "streams": world, "parallelism": f"replicas x{world}",
-                "model_broadcast": dict(jdist.LAST_BROADCAST),
+                "model_broadcast": dict(jdist.LAST_BROADCAST, seconds=broadcast_s),
+                "per_rank_fps": {"values": rank_fps, "min": min(rank_fps), "max": max(rank_fps)},
+                "affinity": AFFINITY,
                 "boundary": "ju_process (synchronous processImage)",
+                "timed_region": timed_region,
+                "preroll_frames": args.preroll,
                 "submission": {"graph_replays": rt.stat("graph_replays"), "eager_runs": rt.stat("eager_runs"),
-                               "cached_graphs": rt.stat("direct_graphs"),
+                               "cached_graphs": rt.stat("direct_graphs"), "prepared_captures": prepared,
+                               "inline_captures": rt.stat("graph_captures"),
                                "how": "one hipGraph per (input, output, binding set) tuple of device frames, "
-                                      "captured at the tuple's second use, replayed afterwards"},
+                                      "captured in set-up by ju_prepare_frames (unregistered pairs: at the "
+                                      "tuple's second use), replayed afterwards"},
                 "tower": "resident (one launch)" if rt.stat("resident_tower") else "per-layer launches",
                 "latency_ms": {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
                                "max": lat[-1], "frames": len(lat)},

@@ -107,6 +107,18 @@ JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image
 JU_API int ju_enqueue(ju_runtime *runtime, const ju_image *input, const ju_image *output);
 JU_API int ju_synchronize(ju_runtime *runtime);
 
+/* Registers a pair of JU_LOC_DEVICE frame buffers the caller is going to pass to ju_process /
+ * ju_enqueue: the hipGraphs of the pair (one per binding set) are captured NOW, so that no
+ * later call captures anything -- the reference captures its two graphs in the constructor
+ * (core/src/tensorrt_backend.cc:257-263), never inside process (:270-278).  Nothing executes
+ * and the buffers are not read or written.  Callers reuse a handful of buffers (OBS: one
+ * texture pair, obs_plugin/src/filter.cc:242-279); a caller that does not register still gets
+ * a graph from the second use of a pair on.  JU_LOC_CPU / graphics-resource images need
+ * nothing (their frames go through the staging buffers whose graphs exist from ju_create on):
+ * the call checks the sizes and returns.  *captured (may be NULL) receives the number of
+ * graphs captured by this call: 2 for a new device pair, 0 otherwise. */
+JU_API int ju_prepare_frames(ju_runtime *runtime, const ju_image *input, const ju_image *output, int *captured);
+
 /* Replaces Runtime::getInputWidth/Height, getOutputWidth/Height (core.h:71-82). */
 JU_API int ju_get_size(const ju_runtime *runtime, size_t *input_width, size_t *input_height,
     size_t *output_width, size_t *output_height);
@@ -187,7 +199,9 @@ JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double
     int *launches, double *flops);
 
 /* How the runtime has been executing: "graph_replays" / "eager_runs" (per-frame programs
- * submitted as one hipGraph replay / as individual launches so far), "direct_graphs"
+ * submitted as one hipGraph replay / as individual launches so far), "graph_captures"
+ * (graphs captured INSIDE ju_process / ju_enqueue so far; captures by ju_prepare_frames:
+ * "prepared_captures"), "registered_pairs", "direct_graphs"
  * (graphs cached for JU_LOC_DEVICE frame tuples), "resident_tower" / "resident_flow"
  * (1 when the one-launch tower kernel is in use), "launches_per_frame", "tower_variant". */
 JU_API int ju_get_stat(const ju_runtime *runtime, const char *key, double *value);

@@ -145,6 +145,14 @@ int ju_enqueue(ju_runtime *runtime, const ju_image *input, const ju_image *outpu
 	});
 }
 
+int ju_prepare_frames(ju_runtime *runtime, const ju_image *input, const ju_image *output, int *captured) {
+	if (captured) *captured = 0;
+	return guarded([&] {
+		const int n = engineOf(runtime).prepareFrames(toFrame(input), toFrame(output));
+		if (captured) *captured = n;
+	});
+}
+
 int ju_synchronize(ju_runtime *runtime) {
 	return guarded([&] { engineOf(runtime).synchronize(); });
 }

@@ -31,6 +31,7 @@ struct Rccl {
 	decltype(&ncclAllReduce) allReduce = nullptr;
 	decltype(&ncclCommCount) commCount = nullptr;
 	decltype(&ncclCommDestroy) commDestroy = nullptr;
+	decltype(&ncclCommAbort) commAbort = nullptr;
 	decltype(&ncclGetErrorString) errorString = nullptr;
 };
 
@@ -60,6 +61,7 @@ const Rccl &rccl() {
 		r.allReduce = reinterpret_cast<decltype(r.allReduce)>(sym("ncclAllReduce"));
 		r.commCount = reinterpret_cast<decltype(r.commCount)>(sym("ncclCommCount"));
 		r.commDestroy = reinterpret_cast<decltype(r.commDestroy)>(sym("ncclCommDestroy"));
+		r.commAbort = reinterpret_cast<decltype(r.commAbort)>(sym("ncclCommAbort"));
 		r.errorString = reinterpret_cast<decltype(r.errorString)>(sym("ncclGetErrorString"));
 	});
 	if (!failure.empty()) throw std::runtime_error(failure);
@@ -139,12 +141,40 @@ int ju_comm_create(const void *id, int rank, int world_size, int device_id, ju_c
 int ju_comm_broadcast(ju_comm *comm, void *bytes, size_t size, int root) {
 	return guardedCall([&] {
 		if (comm == nullptr || (bytes == nullptr && size != 0)) throw std::invalid_argument("ju_comm_broadcast: NULL argument");
+		if (comm->comm == nullptr) throw std::runtime_error("ju_comm_broadcast: the communicator was aborted by an earlier failure");
 		if (root < 0 || root >= comm->world) throw std::invalid_argument("ju_comm_broadcast: bad root");
-		if (size == 0) return;
 		ju::DeviceGuard guard(comm->device);
-		// host bytes -> device (root) -> ncclBroadcast of uint8 over xGMI -> host (others)
-		ju::DeviceBuffer dev(size);
-		if (comm->rank == root) JU_HIP(hipMemcpyAsync(dev.get(), bytes, size, hipMemcpyHostToDevice, comm->stream));
+		// Everything that can fail on THIS rank alone happens before the payload collective:
+		// a rank that threw in front of it would leave its peers blocked inside
+		// ncclBroadcast for ever.  If it does fail here the communicator is aborted, so the
+		// peers' pending collective errors out instead of hanging.
+		ju::DeviceBuffer dev, agree;
+		try {
+			dev = ju::DeviceBuffer(size ? size : 1);
+			agree = ju::DeviceBuffer(2 * sizeof(long long));
+			if (comm->rank == root && size) {
+				JU_HIP(hipMemcpyAsync(dev.get(), bytes, size, hipMemcpyHostToDevice, comm->stream));
+				JU_HIP(hipStreamSynchronize(comm->stream));
+			}
+		} catch (...) {
+			(void)ju::rccl().commAbort(comm->comm);
+			comm->comm = nullptr;
+			throw;
+		}
+		// the ranks' sizes must agree: max over ranks of (size, -size) -- every rank sees the
+		// same two numbers and takes the same decision
+		long long sz[2] = {static_cast<long long>(size), -static_cast<long long>(size)};
+		JU_HIP(hipMemcpyAsync(agree.get(), sz, sizeof(sz), hipMemcpyHostToDevice, comm->stream));
+		ju::ncclCheck(ju::rccl().allReduce(agree.get(), agree.get(), 2, ncclInt64, ncclMax, comm->comm, comm->stream),
+		    "ncclAllReduce");
+		JU_HIP(hipMemcpyAsync(sz, agree.get(), sizeof(sz), hipMemcpyDeviceToHost, comm->stream));
+		JU_HIP(hipStreamSynchronize(comm->stream));
+		if (sz[0] != -sz[1]) {
+			throw std::invalid_argument("ju_comm_broadcast: the ranks passed different sizes (" + std::to_string(-sz[1]) +
+			                            " .. " + std::to_string(sz[0]) + " bytes)");
+		}
+		if (size == 0) return;
+		// device (root) -> ncclBroadcast of uint8 over xGMI -> host (others)
 		ju::ncclCheck(ju::rccl().broadcast(dev.get(), dev.get(), size, ncclUint8, root, comm->comm, comm->stream),
 		    "ncclBroadcast");
 		if (comm->rank != root) JU_HIP(hipMemcpyAsync(bytes, dev.get(), size, hipMemcpyDeviceToHost, comm->stream));
@@ -155,8 +185,16 @@ int ju_comm_broadcast(ju_comm *comm, void *bytes, size_t size, int root) {
 int ju_comm_allreduce_max(ju_comm *comm, double *value) {
 	return guardedCall([&] {
 		if (comm == nullptr || value == nullptr) throw std::invalid_argument("ju_comm_allreduce_max: NULL argument");
+		if (comm->comm == nullptr) throw std::runtime_error("ju_comm_allreduce_max: the communicator was aborted");
 		ju::DeviceGuard guard(comm->device);
-		ju::DeviceBuffer dev(sizeof(double));
+		ju::DeviceBuffer dev;
+		try {
+			dev = ju::DeviceBuffer(sizeof(double));
+		} catch (...) {  // (peers must not wait for this rank for ever)
+			(void)ju::rccl().commAbort(comm->comm);
+			comm->comm = nullptr;
+			throw;
+		}
 		JU_HIP(hipMemcpyAsync(dev.get(), value, sizeof(double), hipMemcpyHostToDevice, comm->stream));
 		ju::ncclCheck(ju::rccl().allReduce(dev.get(), dev.get(), 1, ncclFloat64, ncclMax, comm->comm, comm->stream),
 		    "ncclAllReduce");
@@ -168,6 +206,7 @@ int ju_comm_allreduce_max(ju_comm *comm, double *value) {
 int ju_comm_count(const ju_comm *comm, int *count) {
 	return guardedCall([&] {
 		if (comm == nullptr || count == nullptr) throw std::invalid_argument("ju_comm_count: NULL argument");
+		if (comm->comm == nullptr) throw std::runtime_error("ju_comm_count: the communicator was aborted");
 		ju::ncclCheck(ju::rccl().commCount(comm->comm, count), "ncclCommCount");
 	});
 }

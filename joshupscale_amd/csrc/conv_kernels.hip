@@ -543,13 +543,7 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 	// the doubled LDS would cost a second round of workgroups.  (JU_CONV_DBUF=0/1
 	// forces it off/on for A/B timing.)
 	static const char *dbufEnv = std::getenv("JU_CONV_DBUF");
-	static const int cus = [] {
-		int dev = 0, n = 256;
-		if (hipGetDevice(&dev) == hipSuccess) {
-			(void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-		}
-		return n;
-	}();
+	const int cus = currentDeviceCUs();
 	const long wgs = (long)((p.W + kTW - 1) / kTW) * ((p.H + 4 * p.rw - 1) / (4 * p.rw)) *
 	                 (p.cout / (32 * p.nb));
 	// several 64-channel chunks: the loads of chunk c+1 travel behind the MFMAs of chunk

@@ -48,32 +48,41 @@ namespace {
 int padTo16(int c) { return (c + 15) / 16 * 16; }
 
 // Runtimes of this process per device, and the completion event of the frame submitted
-// last by one that uses the resident tower (Engine::chainBefore / chainAfter).
+// last by one that uses the resident tower (Engine::chainBegin / chainEnd).
 struct DeviceChain {
+	// Held by an engine from its wait on `last` until its own completion event is recorded,
+	// so that wait, launches and record are ONE step per device: two threads driving two
+	// resident runtimes cannot both pass the wait against the same previous frame.
+	std::mutex mutex;
 	int engines = 0;
 	const void *lastOwner = nullptr;
 	hipEvent_t last = nullptr;
 };
-std::mutex g_ChainMutex;
-std::map<int, DeviceChain> g_Chains;
+std::mutex g_ChainMapMutex;
+std::map<int, DeviceChain> g_Chains;  // (map nodes never move: references stay valid)
+DeviceChain &chainOf(int device) {
+	std::lock_guard<std::mutex> lock(g_ChainMapMutex);
+	return g_Chains[device];
+}
 }  // namespace
 
-void Engine::chainBefore() {
-	std::lock_guard<std::mutex> lock(g_ChainMutex);
-	DeviceChain &c = g_Chains[m_Device];
+std::unique_lock<std::mutex> Engine::chainBegin() {
+	DeviceChain &c = chainOf(m_Device);
+	std::unique_lock<std::mutex> lock(c.mutex);
 	if (c.engines > 1 && m_Resident && c.last != nullptr && c.lastOwner != this) {
 		JU_HIP(hipStreamWaitEvent(m_Stream, c.last, 0));
 	}
+	return lock;
 }
 
-void Engine::chainAfter() {
-	std::lock_guard<std::mutex> lock(g_ChainMutex);
-	DeviceChain &c = g_Chains[m_Device];
+void Engine::chainEnd(std::unique_lock<std::mutex> &lock) {
+	DeviceChain &c = chainOf(m_Device);
 	if (c.engines > 1 && m_Resident) {
 		m_FrameDone.record(m_Stream);
 		c.last = m_FrameDone.get();
 		c.lastOwner = this;
 	}
+	lock.unlock();
 }
 
 // Which units of the flow auto-encoder (models.py:334-481) run as one launch each.
@@ -885,65 +894,72 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_IO.inStride = static_cast<std::ptrdiff_t>(W) * 4;
 	m_IO.out = m_OutStage.as<std::uint8_t>();
 	m_IO.outStride = static_cast<std::ptrdiff_t>(W) * 16;
-	// One eager pass per binding set: sets the kernels' dynamic-LDS attributes
-	// and surfaces launch errors before anything is captured.
-	for (int s = 0; s < 2; ++s) {
-		for (const Step &st : m_Program[s]) st.run(m_Stream);
-	}
-	m_Stream.synchronize();
-	if (const unsigned code = takeResidentError()) {
-		const bool graph = m_UseGraph;
-		m_UseGraph = false;  // (graphs are captured below)
-		fallbackToLayers(code);
-		m_UseGraph = graph;
-		for (int s = 0; s < 2; ++s) {
-			for (const Step &st : m_Program[s]) st.run(m_Stream);
-		}
-		m_Stream.synchronize();
-	}
-	reset();
-
 	const char *direct = std::getenv("JU_DIRECT");
 	m_PreferDirect = !(direct && direct[0] == '0');
 	const char *noGraph = std::getenv("JU_NO_GRAPH");
-	m_UseGraph = !(noGraph && noGraph[0] == '1');
+	const bool useGraph = !(noGraph && noGraph[0] == '1');
 	if (const char *retry = std::getenv("JU_RESIDENT_RETRY")) m_RetryBase = static_cast<unsigned>(std::atoi(retry));
 	const char *directGraph = std::getenv("JU_DIRECT_GRAPH");
 	m_DirectGraph = !(directGraph && directGraph[0] == '0');
 	if (const char *spin = std::getenv("JU_SYNC_SPIN_US")) m_SpinUs = static_cast<unsigned>(std::atoi(spin));
-	if (m_UseGraph) {
+
+	// From here on this engine launches kernels.  It joins its device's chain first and holds
+	// the chain's lock until it is ready: the eager passes below run the resident tower, which
+	// must not overlap a frame of another resident runtime on this device (each wants a
+	// workgroup on every CU).  Frames those runtimes have in flight are waited for once, here
+	// (they record completion events only while more than one engine exists).
+	DeviceChain &chain = chainOf(m_Device);
+	std::lock_guard<std::mutex> chainLock(chain.mutex);
+	++chain.engines;
+	try {
+		if (chain.engines > 1) JU_HIP(hipDeviceSynchronize());
+		// One eager pass per binding set: sets the kernels' dynamic-LDS attributes
+		// and surfaces launch errors before anything is captured.
+		m_UseGraph = false;
 		for (int s = 0; s < 2; ++s) {
-			m_Graph[s] = GraphExec::capture(m_Stream, [&] {
-				for (const Step &st : m_Program[s]) st.run(m_Stream);
-			});
+			for (const Step &st : m_Program[s]) st.run(m_Stream);
 		}
 		m_Stream.synchronize();
+		if (const unsigned code = takeResidentError()) {
+			fallbackToLayers(code);
+			for (int s = 0; s < 2; ++s) {
+				for (const Step &st : m_Program[s]) st.run(m_Stream);
+			}
+			m_Stream.synchronize();
+		}
+		reset();
+		m_UseGraph = useGraph;
+		if (m_UseGraph) {
+			for (int s = 0; s < 2; ++s) {
+				m_Graph[s] = GraphExec::capture(m_Stream, [&] {
+					for (const Step &st : m_Program[s]) st.run(m_Stream);
+				});
+			}
+			m_Stream.synchronize();
+		}
+		std::ostringstream ss;
+		ss << "engine ready: " << W << "x" << H << " -> " << 4 * W << "x" << 4 * H << ", "
+		   << (m_DType == kF16 ? "fp16" : "bf16") << ", " << m_Program[0].size()
+		   << " launches/frame, tower=" << (m_Resident ? "resident" : "per-layer")
+		   << ", graph=" << (m_UseGraph ? "on" : "off");
+		logMessage(LogLevel::Info, "Engine", ss.str());
+	} catch (...) {
+		--chain.engines;  // (no destructor runs for a half-built engine)
+		throw;
 	}
-	{
-		std::lock_guard<std::mutex> lock(g_ChainMutex);
-		++g_Chains[m_Device].engines;
-	}
-	std::ostringstream ss;
-	ss << "engine ready: " << W << "x" << H << " -> " << 4 * W << "x" << 4 * H << ", "
-	   << (m_DType == kF16 ? "fp16" : "bf16") << ", " << m_Program[0].size()
-	   << " launches/frame, tower=" << (m_Resident ? "resident" : "per-layer")
-	   << ", graph=" << (m_UseGraph ? "on" : "off");
-	logMessage(LogLevel::Info, "Engine", ss.str());
 }
 
 Engine::~Engine() {
 	try {
 		DeviceGuard g(m_Device);
 		(void)hipStreamSynchronize(m_Stream);
-		std::lock_guard<std::mutex> lock(g_ChainMutex);
-		auto it = g_Chains.find(m_Device);
-		if (it != g_Chains.end()) {
-			if (it->second.lastOwner == this) {  // (its event dies with this engine; the work behind it is done)
-				it->second.last = nullptr;
-				it->second.lastOwner = nullptr;
-			}
-			if (it->second.engines > 0) --it->second.engines;
+		DeviceChain &c = chainOf(m_Device);
+		std::lock_guard<std::mutex> lock(c.mutex);
+		if (c.lastOwner == this) {  // (its event dies with this engine; the work behind it is done)
+			c.last = nullptr;
+			c.lastOwner = nullptr;
 		}
+		if (c.engines > 0) --c.engines;
 	} catch (...) {
 	}
 }
@@ -1192,6 +1208,93 @@ void Engine::stageOut(const Frame &out) {
 	}
 }
 
+bool Engine::directEligible(const Frame &in, const Frame &out) const {
+	const FrameSize fs = frameSize();
+	const auto inRow = static_cast<std::ptrdiff_t>(fs.inputWidth * 4);
+	const auto outRow = static_cast<std::ptrdiff_t>(fs.outputWidth * 4);
+	return m_PreferDirect && in.location == Location::Device && out.location == Location::Device &&
+	       in.ptr != nullptr && out.ptr != nullptr && in.width == fs.inputWidth && in.height == fs.inputHeight &&
+	       out.width == fs.outputWidth && out.height == fs.outputHeight &&
+	       (in.stride >= inRow || -in.stride >= inRow) && (out.stride >= outRow || -out.stride >= outRow) &&
+	       (reinterpret_cast<std::uintptr_t>(in.ptr) % 4 == 0) && in.stride % 4 == 0 &&
+	       (reinterpret_cast<std::uintptr_t>(out.ptr) % 8 == 0) && out.stride % 8 == 0;
+}
+
+Engine::DirectEntry &Engine::directEntry(const DirectKey &key) {
+	auto it = m_DirectGraphs.find(key);
+	if (it == m_DirectGraphs.end()) {
+		// evict the least recently used tuple nobody registered
+		if (m_DirectGraphs.size() >= kMaxDirectGraphs + 2 * m_RegisteredPairs.size()) {
+			auto victim = m_DirectGraphs.end();
+			for (auto j = m_DirectGraphs.begin(); j != m_DirectGraphs.end(); ++j) {
+				DirectKey pair = j->first;
+				pair.idx = 0;
+				if (m_RegisteredPairs.count(pair)) continue;
+				if (victim == m_DirectGraphs.end() || j->second.lastUse < victim->second.lastUse) victim = j;
+			}
+			if (victim != m_DirectGraphs.end()) m_DirectGraphs.erase(victim);
+		}
+		it = m_DirectGraphs.emplace(key, DirectEntry{}).first;
+	}
+	return it->second;
+}
+
+// Records binding set idx's launches against m_IO (nothing executes).
+void Engine::captureDirect(DirectEntry *e, int idx) {
+	e->graph = GraphExec::capture(m_Stream, [&] {
+		for (const Step &st : m_Program[idx]) st.run(m_Stream);
+	});
+}
+
+int Engine::prepareFrames(const Frame &in, const Frame &out) {
+	DeviceGuard g(m_Device);
+	const FrameSize fs = frameSize();
+	if (in.location != Location::GraphicsResource &&
+	    (in.ptr == nullptr || in.width != fs.inputWidth || in.height != fs.inputHeight)) {
+		throw std::invalid_argument("prepareFrames: input image must be exactly " + std::to_string(fs.inputWidth) + "x" +
+		                            std::to_string(fs.inputHeight));
+	}
+	if (out.location != Location::GraphicsResource &&
+	    (out.ptr == nullptr || out.width != fs.outputWidth || out.height != fs.outputHeight)) {
+		throw std::invalid_argument("prepareFrames: output image must be exactly " + std::to_string(fs.outputWidth) +
+		                            "x" + std::to_string(fs.outputHeight));
+	}
+	if (!directEligible(in, out) || !m_UseGraph || !m_DirectGraph) return 0;  // staged frames: graphs exist already
+	const DirectKey pair{in.ptr, in.stride, out.ptr, out.stride, 0};
+	if (!m_RegisteredPairs.count(pair)) {
+		if (m_RegisteredPairs.size() >= kMaxRegisteredPairs) {
+			throw std::invalid_argument("prepareFrames: more than " + std::to_string(kMaxRegisteredPairs) +
+			                            " frame-buffer pairs registered");
+		}
+		m_RegisteredPairs.insert(pair);
+	}
+	std::unique_lock<std::mutex> chain = chainBegin();  // (no capture while another engine's constructor drains the device)
+	const FrameIO keep = m_IO;
+	m_IO.in = static_cast<const std::uint8_t *>(in.ptr);
+	m_IO.inStride = in.stride;
+	m_IO.out = static_cast<std::uint8_t *>(out.ptr);
+	m_IO.outStride = out.stride;
+	int captured = 0;
+	try {
+		for (int idx = 0; idx < 2; ++idx) {
+			DirectKey key = pair;
+			key.idx = idx;
+			DirectEntry &e = directEntry(key);
+			e.lastUse = ++m_DirectClock;
+			if (!e.graph.valid()) {
+				captureDirect(&e, idx);
+				++captured;
+				++m_PreparedCaptures;
+			}
+		}
+	} catch (...) {
+		m_IO = keep;
+		throw;
+	}
+	m_IO = keep;
+	return captured;
+}
+
 void Engine::runProgram() {
 	if (m_UseGraph && !m_DirectIO && m_Graph[m_Idx].valid()) {
 		m_Graph[m_Idx].launch(m_Stream);
@@ -1200,24 +1303,18 @@ void Engine::runProgram() {
 	}
 	if (m_UseGraph && m_DirectIO && m_DirectGraph) {
 		const DirectKey key{m_IO.in, m_IO.inStride, m_IO.out, m_IO.outStride, m_Idx};
-		auto it = m_DirectGraphs.find(key);
-		if (it == m_DirectGraphs.end()) {
-			if (m_DirectGraphs.size() >= kMaxDirectGraphs) {  // evict the least recently used tuple
-				auto victim = m_DirectGraphs.begin();
-				for (auto j = m_DirectGraphs.begin(); j != m_DirectGraphs.end(); ++j) {
-					if (j->second.lastUse < victim->second.lastUse) victim = j;
-				}
-				m_DirectGraphs.erase(victim);
-			}
-			it = m_DirectGraphs.emplace(key, DirectEntry{}).first;
-		}
-		DirectEntry &e = it->second;
+		DirectEntry &e = directEntry(key);
 		e.lastUse = ++m_DirectClock;
-		if (!e.graph.valid() && ++e.seen >= 2) {
-			// second sighting of this tuple: record the launches (nothing executes here) ...
-			e.graph = GraphExec::capture(m_Stream, [&] {
-				for (const Step &st : m_Program[m_Idx]) st.run(m_Stream);
-			});
+		if (!e.graph.valid()) {
+			DirectKey pair = key;
+			pair.idx = 0;
+			// a registered pair whose graph was dropped (fallback / return to the resident
+			// kernel) is captured again at once; an unknown tuple at its second sighting --
+			// a caller that hands over a fresh pointer every frame never pays a capture
+			if (++e.seen >= 2 || m_RegisteredPairs.count(pair)) {
+				captureDirect(&e, m_Idx);  // records the launches (nothing executes here) ...
+				++m_InlineCaptures;
+			}
 		}
 		if (e.graph.valid()) {  // ... and replay
 			e.graph.launch(m_Stream);
@@ -1231,19 +1328,10 @@ void Engine::runProgram() {
 
 void Engine::submit(const Frame &in, const Frame &out) {
 	const FrameSize fs = frameSize();
-	// Device-resident frames + eager launches: the kernels read the caller's input and
-	// write the caller's output directly (any signed stride), no staging copies.
-	m_DirectIO = m_PreferDirect && in.location == Location::Device &&
-	             out.location == Location::Device && in.ptr != nullptr && out.ptr != nullptr &&
-	             in.width == fs.inputWidth && in.height == fs.inputHeight &&
-	             out.width == fs.outputWidth && out.height == fs.outputHeight &&
-	             (in.stride >= static_cast<std::ptrdiff_t>(fs.inputWidth * 4) ||
-	                 -in.stride >= static_cast<std::ptrdiff_t>(fs.inputWidth * 4)) &&
-	             (out.stride >= static_cast<std::ptrdiff_t>(fs.outputWidth * 4) ||
-	                 -out.stride >= static_cast<std::ptrdiff_t>(fs.outputWidth * 4)) &&
-	             (reinterpret_cast<std::uintptr_t>(in.ptr) % 4 == 0) && in.stride % 4 == 0 &&
-	             (reinterpret_cast<std::uintptr_t>(out.ptr) % 8 == 0) && out.stride % 8 == 0;
-	chainBefore();
+	// Device-resident frames: the kernels read the caller's input and write the caller's
+	// output directly (any signed stride), no staging copies.
+	m_DirectIO = directEligible(in, out);
+	std::unique_lock<std::mutex> chain = chainBegin();
 	if (m_DirectIO) {
 		m_IO.in = static_cast<const std::uint8_t *>(in.ptr);
 		m_IO.inStride = in.stride;
@@ -1259,7 +1347,7 @@ void Engine::submit(const Frame &in, const Frame &out) {
 		runProgram();
 		stageOut(out);
 	}
-	chainAfter();
+	chainEnd(chain);
 	m_Idx ^= 1;  // state ping-pong (tensorrt_backend.cc:277)
 }
 
@@ -1396,6 +1484,7 @@ double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
 	m_IO.inStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 4;
 	m_IO.out = m_OutStage.as<std::uint8_t>();
 	m_IO.outStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 16;
+	std::unique_lock<std::mutex> chain = chainBegin();  // (the timed launches may be resident towers)
 	for (const Step *s : steps) s->run(m_Stream);  // warm
 	Event t0, t1;
 	t0.record(m_Stream);
@@ -1403,6 +1492,7 @@ double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
 		for (const Step *s : steps) s->run(m_Stream);
 	}
 	t1.record(m_Stream);
+	chainEnd(chain);
 	t1.synchronize();
 	const double ms = static_cast<double>(Event::elapsedMs(t0, t1)) / (static_cast<double>(iters) * steps.size());
 	// The timed launches ran outside the frame sequence: scratch tensors, the output
@@ -1410,6 +1500,7 @@ double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
 	// the stream from a clean state again, and do not leave a bounded-wait failure of the
 	// resident tower behind for the next process() to trip over.
 	const unsigned code = takeResidentError();
+	if (code) fallbackToLayers(code);  // (also zeroes the mailboxes: the aborted launch left the slot epochs out of step)
 	reset();
 	if (code) {
 		std::ostringstream ss;
@@ -1423,6 +1514,9 @@ double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
 double Engine::stat(const std::string &key) const {
 	if (key == "graph_replays") return static_cast<double>(m_GraphReplays);
 	if (key == "eager_runs") return static_cast<double>(m_EagerRuns);
+	if (key == "graph_captures") return static_cast<double>(m_InlineCaptures);
+	if (key == "prepared_captures") return static_cast<double>(m_PreparedCaptures);
+	if (key == "registered_pairs") return static_cast<double>(m_RegisteredPairs.size());
 	if (key == "resident_tower") return m_Resident ? 1.0 : 0.0;
 	if (key == "resident_flow") return m_ResidentFlow ? 1.0 : 0.0;
 	if (key == "fallbacks") return static_cast<double>(m_Fallbacks);

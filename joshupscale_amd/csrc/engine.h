@@ -15,6 +15,8 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -55,6 +57,15 @@ public:
 	// Asynchronous variant for device-resident frames: enqueue only.
 	void enqueue(const Frame &in, const Frame &out);
 	void synchronize();
+	// Registers a pair of device-resident frame buffers the caller is going to hand to
+	// process() / enqueue(): the per-frame graphs of the pair (one per binding set) are
+	// captured NOW, so that no later call pays a capture -- the reference captures its graphs
+	// in the constructor too, never inside process (tensorrt_backend.cc:257-263).  Nothing
+	// executes and the buffers are not touched.  Pairs that cannot take the direct path
+	// (host frames, graphics resources, odd alignment) need nothing: their frames go through
+	// the staging buffers, whose graphs the constructor captured.  Returns the number of
+	// graphs captured by this call (0 when the pair was registered before).
+	int prepareFrames(const Frame &in, const Frame &out);
 	// Zero the recurrent state (what destroying and recreating the runtime does
 	// in the reference: obs_plugin/src/filter.cc:146-151).
 	void reset();
@@ -217,8 +228,8 @@ private:
 	// device therefore chain their frames through events when more than one of them uses the
 	// resident kernel; a single runtime pays nothing.
 	Event m_FrameDone;
-	void chainBefore();
-	void chainAfter();
+	std::unique_lock<std::mutex> chainBegin();
+	void chainEnd(std::unique_lock<std::mutex> &lock);
 	PinnedWords m_ResError;              // pinned, device-visible: word 0 = the tower's error report
 	unsigned *m_ResErrorDev = nullptr;
 	unsigned takeResidentError();        // 0 = none; clears it
@@ -249,10 +260,19 @@ private:
 		std::uint64_t lastUse = 0;
 	};
 	std::map<DirectKey, DirectEntry> m_DirectGraphs;
+	// pairs registered through prepareFrames (idx = 0 in the key): captured at their FIRST
+	// sighting also after the cache was dropped (fallback to / return from the per-block path)
+	std::set<DirectKey> m_RegisteredPairs;
+	bool directEligible(const Frame &in, const Frame &out) const;
+	DirectEntry &directEntry(const DirectKey &key);
+	void captureDirect(DirectEntry *e, int idx);
 	std::uint64_t m_DirectClock = 0;
 	bool m_DirectGraph = true;  // JU_DIRECT_GRAPH=0: device frames always launch eagerly
-	static constexpr std::size_t kMaxDirectGraphs = 64;
-	std::uint64_t m_GraphReplays = 0, m_EagerRuns = 0;  // introspection ("graph_replays" / "eager_runs")
+	static constexpr std::size_t kMaxDirectGraphs = 64;     // unregistered tuples (LRU)
+	static constexpr std::size_t kMaxRegisteredPairs = 256;
+	// introspection ("graph_replays" / "eager_runs" / "graph_captures": captures of device-frame
+	// graphs made inside process / enqueue, i.e. not by prepareFrames or the constructor)
+	std::uint64_t m_GraphReplays = 0, m_EagerRuns = 0, m_InlineCaptures = 0, m_PreparedCaptures = 0;
 
 public:
 	std::uint64_t fallbacks() const { return m_Fallbacks; }

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	// convolution's zero padding.
 	const bool border = y0 - 2 < 0 || y0 + TH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
 	constexpr int LPP = G::PBX / 16;  // lanes (16-byte chunks) per pixel
-	if (p.skip & 1) {
+	if (JU_SKIP(p) & 1) {
 	} else if constexpr (!UPS) {
 		if (border) {  // interior tiles are overwritten completely
 			for (int i = tid; i < G::NPL * G::XPLANE / 16; i += NT) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 				}
 			}
 		};
-		if (p.skip & 2) {
+		if (JU_SKIP(p) & 2) {
 		} else if constexpr (G::NPL == 1) {
 			for (int pair = pstart; pair < NPAIR; pair += PSTEP) {
 				initAcc(acc[0]);
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	}
 	unsigned char *stage = smem + G::OFF_STAGE + wave * G::STAGE_WAVE;
 	constexpr int NCH = G::RBW / 16;  // 16-byte chunks per staged pixel
-	for (int pair = pstart; pair < ((p.skip & 4) ? 0 : TH / 2); pair += PSTEP) {
+	for (int pair = pstart; pair < ((JU_SKIP(p) & 4) ? 0 : TH / 2); pair += PSTEP) {
 		f32x16 acc[2];
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 				const unsigned slot = static_cast<unsigned>(lane % NCH);
 				const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & (NCH - 1));
 				const uint4 val = *reinterpret_cast<const uint4 *>(stage + pi * G::RBW + (slot << 4));
-				if (p.skip & 8) {
+				if (JU_SKIP(p) & 8) {
 				} else if constexpr (POOL) {
 					const int oy = (y0 >> 1) + pair, ox = (x0 >> 1) + pi;
 					if (pi < kFbOutW / 2 && oy < (p.H >> 1) && ox < (p.W >> 1)) {
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
 	};
 
 	int tile = blockIdx.x;
-	if (tile < p.numTiles && !(p.skip & 1)) stageX(tile);
+	if (tile < p.numTiles && !(JU_SKIP(p) & 1)) stageX(tile);
 	for (; tile < p.numTiles; tile += gridDim.x) {
 		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
 		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
@@ -642,8 +642,8 @@ __global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
 					for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = biasA[g][i];
 				}
 			}
-			if (!(p.skip & 2)) FbPair<T, 4, 128>::run(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, acc);
-			if (p.skip & 32) continue;
+			if (!(JU_SKIP(p) & 2)) FbPair<T, 4, 128>::run(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, acc);
+			if (JU_SKIP(p) & 32) continue;
 			const int gx = x0 - 1 + px;
 			const bool colIn = gx >= 0 && gx < p.W;
 #pragma unroll
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
 		}
 		__syncthreads();  // T complete, X dead
 		// ---- the next tile's X travels while conv B computes ----
-		if (tile + static_cast<int>(gridDim.x) < p.numTiles && !(p.skip & 1)) stageX(tile + gridDim.x);
+		if (tile + static_cast<int>(gridDim.x) < p.numTiles && !(JU_SKIP(p) & 1)) stageX(tile + gridDim.x);
 		// ---- conv B: 14 rows x 32 columns (30 valid) + skip -> activation -> global ----
 		for (int pair = pl; pair < kRbTH / 2; pair += 2) {
 			f32x16 acc[2];
@@ -681,12 +681,12 @@ __global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
 				const T *rp = in + ((size_t)gy * p.inPitch + gx) * 64 + cb * 32 + 4 * hh;
 #pragma unroll
 				for (int g = 0; g < 4; ++g) {
-					if (p.skip & 8) resv[r][g] = Vec4<T>{};
+					if (JU_SKIP(p) & 8) resv[r][g] = Vec4<T>{};
 					else resv[r][g] = *reinterpret_cast<const Vec4<T> *>(rp + 8 * g);
 				}
 			}
-			if (!(p.skip & 4)) FbPair<T, 4, 128>::run(ldsBase + kRbX + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wb, acc);
-			if (p.skip & 64) continue;
+			if (!(JU_SKIP(p) & 4)) FbPair<T, 4, 128>::run(ldsBase + kRbX + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wb, acc);
+			if (JU_SKIP(p) & 64) continue;
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
 					const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & 3u);
 					const uint4 val = *reinterpret_cast<const uint4 *>(stage + pi * 64 + (slot << 4));
 					const int gx = x0 + pi;
-					if (pi < kFbOutW && gy < p.H && gx < p.W && !(p.skip & 16)) {
+					if (pi < kFbOutW && gy < p.H && gx < p.W && !(JU_SKIP(p) & 16)) {
 						*reinterpret_cast<uint4 *>(outp + (((size_t)gy * p.outPitch + gx) * 64 + cb * 32) * 2 + chunk * 16) = val;
 					}
 				}
@@ -726,11 +726,7 @@ void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
 	auto kern = res_block_kernel<T>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), kRbLds, &ldsDone, "res block");
-	static const int cus = [] {
-		int dev = 0, n = 256;
-		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-		return n;
-	}();
+	const int cus = currentDeviceCUs();
 	ResBlockParams p{};
 	p.in = q.in;
 	p.out = q.out;
@@ -746,11 +742,7 @@ void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.numTiles = p.tilesX * ((q.H + kRbTH - 1) / kRbTH);
 	p.s1 = q.act1 == 1 ? 0.0f : (q.act1 == 2 ? q.slope : 1.0f);
 	p.s2 = q.act2 == 1 ? 0.0f : (q.act2 == 2 ? q.slope : 1.0f);
-	static const int skipEnv = [] {
-		const char *e = std::getenv("JU_FB_SKIP");
-		return e ? std::atoi(e) : 0;
-	}();
-	p.skip = skipEnv;
+	p.skip = ablationSkipBits();
 	const int grid = p.numTiles < cus ? p.numTiles : cus;
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kRbLds, stream, p);
 	hipCheckLaunch("res_block");
@@ -837,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 		for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
 			for (int ks = 0; ks < KS; ++ks) {
-				if (!(p.skip & 1)) w[b][tap * KS + ks] = *reinterpret_cast<const Vec8<T> *>(wsrc + (size_t)(tap * 4 + ks) * 1024);
+				if (!(JU_SKIP(p) & 1)) w[b][tap * KS + ks] = *reinterpret_cast<const Vec8<T> *>(wsrc + (size_t)(tap * 4 + ks) * 1024);
 				else w[b][tap * KS + ks] = Vec8<T>{};
 			}
 		}
@@ -845,7 +837,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 	// ---- tile rows [t0, t0 + nr) -> ring slots (t mod 4), all planes ----
 	// tile row t = image row y0 - 1 + t, tile column k = image column x0 - 1 + k
 	auto stageRows = [&](int t0, int nr) {
-		if (p.skip & 2) return;
+		if (JU_SKIP(p) & 2) return;
 		const int nPix = nr * kFbW;
 		const int nInstr = (nPix + 7) >> 3;  // 8 pixels of one plane per wave-instruction
 		const int slot0 = t0 & 3;            // (t0 is even: the rows of a stage never wrap)
@@ -895,7 +887,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 			}
 		}
 #pragma unroll
-		for (int b = 0; b < (p.skip & 4 ? 0 : CB); ++b) {
+		for (int b = 0; b < (JU_SKIP(p) & 4 ? 0 : CB); ++b) {
 			if (pr & 1) FbPair<T, KS, 128>::template run<2>(xBase, colOff, colSwz, hhx, w[b], acc[b]);
 			else FbPair<T, KS, 128>::template run<0>(xBase, colOff, colSwz, hhx, w[b], acc[b]);
 		}
@@ -903,7 +895,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 		if (pr + 1 < nPairs) stageRows(2 * pr + 4, 2);
 		// ---- pieces to their owners ----
 #pragma unroll
-		for (int b = 0; b < (p.skip & 8 ? 0 : CB); ++b) {
+		for (int b = 0; b < (JU_SKIP(p) & 8 ? 0 : CB); ++b) {
 #pragma unroll
 			for (int o = 0; o < 8; ++o) {
 				if (o != wave) {
@@ -920,7 +912,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 		for (int b = 0; b < CB; ++b) {
 			f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-			for (int src = 0; src < (p.skip & 8 ? 0 : 8); ++src) {
+			for (int src = 0; src < (JU_SKIP(p) & 8 ? 0 : 8); ++src) {
 				f32x4 v;
 				if (src == wave) {
 					// (this wave's own piece: select by the uniform owner index)
@@ -953,7 +945,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 			if (tid < CB * 256) {
 				const int q = tid & 3, cx = (tid >> 2) & 31, r = (tid >> 7) & 1, b = tid >> 8;
 				const int gy = y0 + 2 * pr + r, gx = x0 + cx;
-				if (gy < p.H && gx < p.W && !(p.skip & 16)) {
+				if (gy < p.H && gx < p.W && !(JU_SKIP(p) & 16)) {
 					const uint4 v = *reinterpret_cast<const uint4 *>(smem + G::OFF_S + ((b * 2 + r) * 32 + cx) * 64 +
 					    ((static_cast<unsigned>(q) ^ ((cx >> 2) & 3u)) << 4));
 					*reinterpret_cast<uint4 *>(out + ((size_t)gy * p.outPitch + gx) * p.cout + (cog0 + b) * 32 + q * 8) = v;
@@ -1051,16 +1043,8 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.act1 = q.act1;
 	p.act2 = q.act2;
 	p.slope = q.slope;
-	static const int skipEnv = [] {
-		const char *e = std::getenv("JU_FB_SKIP");
-		return e ? std::atoi(e) : 0;
-	}();
-	p.skip = skipEnv;
-	static const int cus = [] {
-		int dev = 0, n = 256;
-		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-		return n;
-	}();
+	p.skip = ablationSkipBits();
+	const int cus = currentDeviceCUs();
 	if (q.upsample && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused upsampling needs even H and W");
 	if (q.pool && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused max-pool needs even H and W");
 	// the shapes of the flow auto-encoder's fusable blocks (flowBlockSupported)
@@ -1112,11 +1096,7 @@ bool convSplitKSupported(const ConvParams &p) {
 
 void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStream_t stream) {
 	if (!convSplitKSupported(q) || !zeros) throw std::invalid_argument("split-K conv: unsupported layer");
-	static const int cus = [] {
-		int dev = 0, n = 256;
-		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-		return n;
-	}();
+	const int cus = currentDeviceCUs();
 	SplitKParams p{};
 	p.in = q.in;
 	p.wgt = q.wgt;
@@ -1130,11 +1110,7 @@ void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStrea
 	p.outPitch = q.outPitch ? q.outPitch : (q.pool ? q.W / 2 : q.W);
 	p.act = q.relu;
 	p.slope = q.slope;
-	static const int skipEnv = [] {
-		const char *e = std::getenv("JU_FB_SKIP");
-		return e ? std::atoi(e) : 0;
-	}();
-	p.skip = skipEnv;
+	p.skip = ablationSkipBits();
 	p.tilesX = (q.W + 31) / 32;
 	// Tile height and cout blocks per workgroup: every workgroup pulls its cout blocks'
 	// whole weights (147 KB per block at 256 channels), so the fewest workgroups that still

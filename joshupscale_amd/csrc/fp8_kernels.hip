@@ -461,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 	};
 
 	int tile = blockIdx.x;
-	if (tile < p.numTiles && !(p.skip & 1)) stageX(tile);
+	if (tile < p.numTiles && !(JU_SKIP(p) & 1)) stageX(tile);
 	for (; tile < p.numTiles; tile += gridDim.x) {
 		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
 		const int y0 = ty * TH, x0 = tx * 30;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 			}
 			// the next tap's fragments travel behind the current tap's 6 instructions
 			i32x8 f0[4], f1[4];
-			if (p.skip & 2) goto epiA;
+			if (JU_SKIP(p) & 2) goto epiA;
 			loadFrags(smX, pair, 0, f0);
 			loadFrags(smX, pair, 1, f1);
 			// (tap order 1, 0, 2: see tower8_kernels.hip)
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 2], f1[r + dy], acc[r], 0, 0, 0, scA1, 0, p.scaleB1);
 			}
 		epiA:
-			if (p.skip & 32) continue;
+			if (JU_SKIP(p) & 32) continue;
 			const int gx = x0 - 1 + px;
 			const bool colIn = gx >= 0 && gx < p.W;
 			const int sw = (px >> 2) & 3;
@@ -522,13 +522,13 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 			}
 		}
 		__syncthreads();  // T8 complete, X8 dead
-		if (tile + static_cast<int>(gridDim.x) < p.numTiles && !(p.skip & 1)) stageX(tile + gridDim.x);
+		if (tile + static_cast<int>(gridDim.x) < p.numTiles && !(JU_SKIP(p) & 1)) stageX(tile + gridDim.x);
 		// ---- conv B: TH rows x 32 columns (30 valid) + skip -> ReLU -> stream, e4m3 copy ----
 		for (int pair = pl; pair < TH / 2; pair += 4) {
 			// the pair's skip records (this wave's half: channels 32 cb ..) by LDS-DMA into the
 			// staging slice, pixel pi = r * 32 + px at pi * 64, chunk c at c ^ (pi & 3); they land
 			// during the K loop, and the results go back into the same places
-			if (!(p.skip & 8)) {
+			if (!(JU_SKIP(p) & 8)) {
 				const unsigned char *src = static_cast<const unsigned char *>(p.stream);
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
@@ -549,12 +549,12 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				}
 			}
 			i32x8 f0[4], f1[4];
-			if (!(p.skip & 4)) {
+			if (!(JU_SKIP(p) & 4)) {
 			loadFrags(smT, pair, 0, f0);
 			loadFrags(smT, pair, 1, f1);
 			}
 #pragma unroll
-			for (int t = 0; t < ((p.skip & 4) ? 0 : 3); ++t) {
+			for (int t = 0; t < ((JU_SKIP(p) & 4) ? 0 : 3); ++t) {
 				const int dx = t == 0 ? 1 : (t == 1 ? 0 : 2);
 				if (t == 1) loadFrags(smT, pair, 2, f1);
 #pragma unroll
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				}
 			}
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the skip records have landed (this wave's own DMA)
-			if (p.skip & 64) continue;
+			if (JU_SKIP(p) & 64) continue;
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
 				const int pi = r * 32 + px;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & 3u);
 				const i32x4 val = *reinterpret_cast<const i32x4 *>(stage + pi * 64 + (slot << 4));
 				const int gy = y0 + 2 * pair + (pi >> 5), gx = x0 + (pi & 31);
-				if ((pi & 31) < 30 && gy < p.H && gx < p.W && !(p.skip & 16)) {
+				if ((pi & 31) < 30 && gy < p.H && gx < p.W && !(JU_SKIP(p) & 16)) {
 					*reinterpret_cast<i32x4 *>(static_cast<unsigned char *>(p.stream) +
 					    (((size_t)(gy + 1) * p.pitch + gx + 1) * 64 + cb * 32) * 2 + chunk * 16) = val;
 				}
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				const i32x2 a = *reinterpret_cast<const i32x2 *>(stage8 + ((2 * c) * 64 + pxo * 2) * 4);
 				const i32x2 b = *reinterpret_cast<const i32x2 *>(stage8 + ((2 * c + 1) * 64 + pxo * 2) * 4);
 				const int gy = y0 + 2 * pair + r, gx = x0 + pxo;
-				if (pxo < 30 && gy < p.H && gx < p.W && !(p.skip & 16)) {
+				if (pxo < 30 && gy < p.H && gx < p.W && !(JU_SKIP(p) & 16)) {
 					*reinterpret_cast<i32x4 *>(p.out8 + ((size_t)(gy + 1) * p.pitch + gx + 1) * 64 + cb * 32 + c * 16) =
 					    i32x4{a[0], a[1], b[0], b[1]};
 				}
@@ -748,16 +748,8 @@ void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 	k.H = q.H;
 	k.W = q.W;
 	k.pitch = towerPitch(q.W);
-	static const int skipEnv = [] {
-		const char *e = std::getenv("JU_FB_SKIP");
-		return e ? std::atoi(e) : 0;
-	}();
-	k.skip = skipEnv;
-	static const int cus = [] {
-		int dev = 0, n = 256;
-		if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-		return n;
-	}();
+	k.skip = ablationSkipBits();
+	const int cus = currentDeviceCUs();
 	// Tile height: a CU works through ceil(tiles / CUs) tiles one after the other, each
 	// costing about (rows + 5) row-times (recompute ring + per-tile fixed work): take the
 	// height with the shortest makespan (480x270: 18 rows, 240 tiles, one each; 640x448: 14

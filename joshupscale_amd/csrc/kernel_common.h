@@ -91,6 +91,39 @@ __device__ __forceinline__ Vec4<T> pack4(float a, float b, float c, float d) {
 	return __builtin_bit_cast(Vec4<T>, u32x2p{l, h});
 }
 
+// Timing-ablation bits (JU_FB_SKIP: drop staging / MFMAs / stores inside a kernel to see what
+// the phase costs).  They exist in PROBE builds only (make KERNELFLAGS+=-DJU_ABLATE, as
+// tools/*_ablate.sh do): the product library neither reads the variable nor carries the
+// branches in its hot loops -- a stray environment variable cannot corrupt frames.
+#ifdef JU_ABLATE
+#define JU_SKIP(p) ((p).skip)
+inline int ablationSkipBits() {
+	static const int bits = [] {
+		const char *e = std::getenv("JU_FB_SKIP");
+		return e ? std::atoi(e) : 0;
+	}();
+	return bits;
+}
+#else
+#define JU_SKIP(p) 0
+inline int ablationSkipBits() { return 0; }
+#endif
+
+// CU count of the CURRENT device (a process may drive several GPUs: not a function-local
+// static of whichever device launched first).
+inline int currentDeviceCUs() {
+	static std::atomic<int> cached[64] = {};
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+	int n = cached[dev].load(std::memory_order_relaxed);
+	if (n == 0) {
+		n = 256;
+		(void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+		cached[dev].store(n, std::memory_order_relaxed);
+	}
+	return n;
+}
+
 inline void hipCheckLaunch(const char *what) {
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess) {

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			// 402 / 378 against 363 us per tower with / without the reading epilogues included:
 			// LDS operations return in order.)
 			i32x8 f0[4], f1[4];
-			if (!(p.skip & 2)) {
+			if (!(JU_SKIP(p) & 2)) {
 			loadFrags(inOff, u, 0, f0);
 			loadFrags(inOff, u, 1, f1);
 			}
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 #pragma unroll
 			// taps in the order dx = 1, 0, 2 (all three 8-bit kernels: the fp32 summation order is
 			// part of their byte equality): the middle tap reads no halo column
-			for (int t = 0; t < ((p.skip & 2) ? 0 : 3); ++t) {
+			for (int t = 0; t < ((JU_SKIP(p) & 2) ? 0 : 3); ++t) {
 				const int dx = t == 0 ? 1 : (t == 1 ? 0 : 2);
 				if (t == 1) {
 					loadFrags(inOff, u, 2, f1);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 				}
 			}
 			// ---- epilogue ----
-			if (!(p.skip & 4)) {
+			if (!(JU_SKIP(p) & 4)) {
 #pragma unroll
 				for (int r = 0; r < 2; ++r) {
 					const int row = 2 * u + r;  // region row; buffer row index row + 1
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			ldsBias[((i + 1) & 1) * 64 + lane] = biasNext;
 			ldsScale[((i + 1) & 1) * 64 + lane] = scaleNext;
 		}
-		if (more && !(p.skip & 1)) publish(std::integral_constant<int, SECOND ? kT8OffX : kT8OffT>{}, i);
+		if (more && !(JU_SKIP(p) & 1)) publish(std::integral_constant<int, SECOND ? kT8OffX : kT8OffT>{}, i);
 		// this layer's weight registers are free: refill them for layer i+2 while the
 		// neighbours' stores travel, THEN sweep (tower_kernels.hip, same order)
 		if (i + 2 < L) {
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			}
 		}
 		// the halo of the next layer's INPUT: this layer's output ring
-		if (more && !(p.skip & 1)) {
+		if (more && !(JU_SKIP(p) & 1)) {
 			if (!fillHalo(std::integral_constant<int, SECOND ? kT8OffX : kT8OffT>{}, i)) return false;
 		} else {
 			__syncthreads();
@@ -521,11 +521,7 @@ void launchResidentTower8(DType dt, const ResidentTower8Params &q, hipStream_t s
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
 	p.fault = residentFaultForTests();
-	static const int skipEnv = [] {
-		const char *e = std::getenv("JU_FB_SKIP");
-		return e ? std::atoi(e) : 0;
-	}();
-	p.skip = skipEnv;
+	p.skip = ablationSkipBits();
 	if (p.nLayers < 2 || (p.nLayers & 1)) throw std::invalid_argument("fp8 resident tower: layer count must be 2 x blocks");
 	if (dt == kF16) launchTower8T<f16>(p, stream);
 	else launchTower8T<bf16>(p, stream);

@@ -56,6 +56,8 @@ def broadcast_model_native(blob: Optional[bytes], device: torch.device, src: int
     dist.broadcast_object_list(meta, src=src)
     comm = R.Comm(meta[0], rank, world, device.index if device.index is not None else 0)
     out = comm.broadcast(blob if rank == src else None, int(meta[1]), root=src)
+    if _COMM is not None:  # a repeated broadcast: the previous communicator is not leaked
+        _COMM.close()
     _COMM = comm
     LAST_BROADCAST.update(how="rccl (ju_comm_broadcast, C layer)", ranks_seen=comm.count(), bytes=int(meta[1]))
     return out
@@ -104,6 +106,16 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value: float, device: torch.device) -> list:
+    """One float per rank, in rank order, on every rank (the bench's per-rank frame rates:
+    outside the timed region, so the launcher's process group carries it)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, float(value))
+    return [float(v) for v in out]
 
 
 def barrier() -> None:

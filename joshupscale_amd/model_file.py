@@ -272,6 +272,13 @@ def deserialize(blob: bytes) -> Tuple[ModelConfig, Dict[str, np.ndarray]]:
     eps, cdt, nt, ts, tt, acts, fslope, gslope = vals[22:30]
     if scale != 4:
         raise ValueError("scale must be 4")
+    # (as csrc/model.cpp: unknown codes and non-zero upper bits are errors, not KeyErrors)
+    if acts >> 16:
+        raise ValueError("Invalid model: unknown activation field")
+    if (acts & 0xff) not in ACTIVATION_INV:
+        raise ValueError(f"Invalid model: unknown flow activation {acts & 0xff}")
+    if ((acts >> 8) & 0xff) not in ACTIVATION_INV:
+        raise ValueError(f"Invalid model: unknown generator activation {(acts >> 8) & 0xff}")
     fact, gact = ACTIVATION_INV[acts & 0xff], ACTIVATION_INV[(acts >> 8) & 0xff]
     cfg = ModelConfig(fh, fw, nfi, FLOW_ARCH_INV[arch], tuple(ff[:nff]), frf,
                       frb, pad, gf, gb, bool(nb), eps, cdt, ts,
@@ -280,6 +287,8 @@ def deserialize(blob: bytes) -> Tuple[ModelConfig, Dict[str, np.ndarray]]:
                       gslope if gact == "lrelu" else DEFAULT_NEGATIVE_SLOPE)
     if header_bytes >= 160:
         win, gain, flags = struct.unpack_from("<IfI", blob, 128)
+        if flags >> 3:
+            raise ValueError("Invalid model: unknown temporal filter flags")
         cfg.temporal_window, cfg.temporal_gain = win, gain
         cfg.temporal_norm = "L2" if flags & 1 else "L1"
         cfg.temporal_limit, cfg.temporal_luma = bool(flags & 2), bool(flags & 4)

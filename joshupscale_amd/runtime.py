@@ -81,6 +81,7 @@ def load_library() -> C.CDLL:
         "ju_process": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage)]),
         "ju_enqueue": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage)]),
         "ju_synchronize": (C.c_int, [C.c_void_p]),
+        "ju_prepare_frames": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage), P(C.c_int)]),
         "ju_get_size": (C.c_int, [C.c_void_p] + [P(C.c_size_t)] * 4),
         "ju_reset": (C.c_int, [C.c_void_p]),
         "ju_last_error": (C.c_char_p, []),
@@ -186,6 +187,13 @@ class Runtime:
 
     def synchronize(self) -> None:
         _check(self._lib, self._lib.ju_synchronize(self._h))
+
+    def prepare_frames(self, inp: JuImage, out: JuImage) -> int:
+        """``ju_prepare_frames``: capture the graphs of a device frame-buffer pair now
+        (the reference captures in its constructor); returns the graphs captured."""
+        n = C.c_int()
+        _check(self._lib, self._lib.ju_prepare_frames(self._h, C.byref(inp), C.byref(out), C.byref(n)))
+        return n.value
 
     def reset(self) -> None:
         _check(self._lib, self._lib.ju_reset(self._h))

@@ -48,6 +48,12 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
     mb = res["config"]["model_broadcast"]
     assert mb["how"].startswith("rccl") and mb["ranks_seen"] == 1 and mb["bytes"] > 1 << 20
     assert res["config"]["submission"]["graph_replays"] > 0
+    # the driver's command line (--steps 20 --warmup 5) measures the steady state: every timed
+    # frame replays a graph captured in set-up (ju_prepare_frames)
+    assert res["config"]["timed_region"] == {"replays": 20, "eager": 0, "captures": 0}
+    assert res["config"]["submission"]["prepared_captures"] == 32 and res["config"]["submission"]["inline_captures"] == 0
+    assert len(res["config"]["per_rank_fps"]["values"]) == 1
+    assert "how" in res["config"]["affinity"] and res["config"]["model_broadcast"]["seconds"] > 0
     # launched the wrong way, the bench refuses instead of measuring one GPU
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT)

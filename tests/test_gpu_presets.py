@@ -193,6 +193,109 @@ def test_device_frame_graphs_equal_eager_launches(monkeypatch):
     rt.close()
 
 
+def test_prepare_frames_captures_in_setup_and_the_loop_only_replays():
+    """ju_prepare_frames: the graphs of a registered device frame-buffer pair are captured at
+    registration (both binding sets), as the reference captures its graphs in the constructor
+    (tensorrt_backend.cc:257-263); the frame loop then replays from its first frame on -- no
+    eager first sighting, no capture inside ju_process -- and produces the bytes of an
+    unregistered runtime.  A dropped cache (fallback to the per-block path) re-captures a
+    registered pair at its first use."""
+    import torch
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames = M.synthetic_frames(5, h, w, seed=35, kind="noise")
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(frames).to(dev)
+    d_out = torch.empty((4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    plain = R.Runtime(blob, 0, R.DTYPE_BF16)
+    want = []
+    for i in range(10):
+        plain.process(plain.device_image(d_in[i % 5].data_ptr(), w, h), plain.device_image(d_out.data_ptr(), 4 * w, 4 * h))
+        want.append(d_out.cpu().numpy())
+    assert plain.stat("graph_captures") > 0 and plain.stat("eager_runs") > 0     # second-sighting policy
+    plain.close()
+    rt = R.Runtime(blob, 0, R.DTYPE_BF16)
+    ins = [rt.device_image(d_in[t].data_ptr(), w, h) for t in range(5)]
+    out = rt.device_image(d_out.data_ptr(), 4 * w, 4 * h)
+    assert [rt.prepare_frames(i, out) for i in ins] == [2] * 5                   # one graph per binding set
+    assert rt.prepare_frames(ins[0], out) == 0                                    # registered already
+    assert rt.prepare_frames(R.host_image(frames[0]), R.host_image(np.empty((4 * h, 4 * w, 4), np.uint8))) == 0
+    with pytest.raises(R.JoshUpscaleError):
+        rt.prepare_frames(rt.device_image(d_in[0].data_ptr(), w - 1, h), out)
+    assert rt.stat("prepared_captures") == 10 and rt.stat("registered_pairs") == 5
+    for i in range(10):
+        rt.process(ins[i % 5], out)
+        assert np.array_equal(d_out.cpu().numpy(), want[i]), i
+    assert rt.stat("graph_replays") == 10 and rt.stat("eager_runs") == 0 and rt.stat("graph_captures") == 0
+    # the cache is dropped when the engine leaves the resident kernel; a registered pair is
+    # captured again at its FIRST use afterwards (one inline capture, no eager run)
+    lib = R.load_library()
+    rt.reset()
+    lib.ju_debug_set(b"resident_fault", 1)
+    try:
+        rt.process_image(frames[0])                   # host frame: times out, falls back, re-runs
+    finally:
+        lib.ju_debug_set(b"resident_fault", 0)
+    assert rt.stat("resident_tower") == 0 and rt.stat("direct_graphs") == 0
+    rt.process(ins[1], out)
+    assert rt.stat("graph_captures") == 1 and rt.stat("eager_runs") == 0
+    rt.close()
+
+
+def test_second_runtime_is_created_while_the_first_has_frames_in_flight():
+    """Advisor finding: a runtime created while another resident runtime has enqueued frames
+    must not run its constructor's tower launches beside them, and two threads calling the
+    synchronous ju_process on two resident runtimes must serialise wait + launches + record
+    per device.  Both streams produce their solo frames; neither falls back."""
+    import threading
+    import torch
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    n = 20
+    clips = [M.synthetic_frames(n, h, w, seed=91 + k, kind="smooth") for k in range(2)]
+    dev = torch.device("cuda", 0)
+    d_in = [torch.from_numpy(c).to(dev) for c in clips]
+    solo = []
+    for k in range(2):
+        rt = R.Runtime(blob, 0, R.DTYPE_F16)
+        d_out = torch.empty((n, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for t in range(n):
+            rt.process(rt.device_image(d_in[k][t].data_ptr(), w, h), rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h))
+        solo.append(d_out.cpu())
+        rt.close()
+    outs = [torch.empty((n, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    first = R.Runtime(blob, 0, R.DTYPE_F16)
+    for t in range(n // 2):                                  # in flight, not waited for
+        first.enqueue(first.device_image(d_in[0][t].data_ptr(), w, h), first.device_image(outs[0][t].data_ptr(), 4 * w, 4 * h))
+    second = R.Runtime(blob, 0, R.DTYPE_F16)                 # constructor runs both programs eagerly
+    rts = [first, second]
+    errors = []
+
+    def worker(k, start):
+        try:
+            for t in range(start, n):
+                rts[k].process(rts[k].device_image(d_in[k][t].data_ptr(), w, h),
+                               rts[k].device_image(outs[k][t].data_ptr(), 4 * w, 4 * h))
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, e))
+
+    threads = [threading.Thread(target=worker, args=(0, n // 2)), threading.Thread(target=worker, args=(1, 0))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not errors, errors
+    for k in range(2):
+        assert rts[k].stat("resident_tower") == 1 and rts[k].stat("fallbacks") == 0, k
+        assert torch.equal(outs[k].cpu(), solo[k]), k
+        rts[k].close()
+
+
 def test_resident_failure_recovers_with_graphs_enabled():
     """The default configuration (graphs on): a bounded wait of the resident tower expires
     on an eagerly launched device frame; the engine runs the per-layer programs once

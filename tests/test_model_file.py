@@ -93,6 +93,25 @@ def test_rejects_foreign_files():
         M.deserialize(b"JUPWGT")
 
 
+def test_python_twin_rejects_what_the_cpp_loader_rejects():
+    """csrc/model.cpp refuses unknown activation codes, non-zero upper bits of the activations
+    word and unknown temporal flag bits with 'Invalid model: ...'; so does the Python twin, with
+    ValueError like every other malformed field (not a bare KeyError)."""
+    cfg = M.ModelConfig(frame_height=30, frame_width=48, gen_blocks=1, temporal_strength=0.5,
+                        temporal_window=16)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+
+    def patched(offset, fmt, *vals):
+        b = bytearray(blob)
+        struct.pack_into(fmt, b, offset, *vals)
+        return bytes(b)
+    for bad, match in [(patched(116, "<I", 2), "flow activation"), (patched(116, "<I", 0x0300), "generator activation"),
+                       (patched(116, "<I", 0x10000), "activation field"), (patched(136, "<I", 8), "temporal filter flags")]:
+        with pytest.raises(ValueError, match=match):
+            M.deserialize(bad)
+    M.deserialize(patched(136, "<I", 7))     # every known flag bit set: accepted
+
+
 def test_seeded_weights_are_deterministic_and_named_like_keras():
     cfg = M.ModelConfig(gen_blocks=2)
     a = M.make_seeded_weights(cfg, seed=42)

@@ -1,5 +1,7 @@
 #!/bin/bash
 # developer tool: timing ablation of tower8_resident_kernel (JU_FB_SKIP bits: 1 halo exchange, 2 K loop, 4 epilogue)
+# needs the probe build: `make ablate` (the product library ignores JU_FB_SKIP)
+export JU_LIBRARY=${JU_LIBRARY:-$PWD/build/ablate/libJoshUpscale.so}
 for s in 0 1 2 4 3 6 7; do
   JU_FB_SKIP=$s python3 - <<PY
 import os, sys
