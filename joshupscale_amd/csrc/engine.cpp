@@ -487,6 +487,8 @@ void Engine::buildProgram(int set) {
 		rp.GY = m_FlowGY;
 		rp.RH = m_FlowRH;
 		rp.nLayers = 1 + 2 * c.flowResBlocks;
+		rp.leaky = c.flowActivation == 1 ? 1 : 0;
+		rp.slope = c.flowNegativeSlope;
 		prog.push_back({"flow",
 		    2.0 * PH * PW * 9.0 * (3.0 * c.numFlowInputs * 64 + 64.0 * 64 * 2 * c.flowResBlocks),
 		    [=](hipStream_t s) { launchResidentTower(dt, rp, s); }});
@@ -522,9 +524,26 @@ void Engine::buildProgram(int set) {
 		                }});
 	}
 	// ---- generator ----
+	// calibration mode (JU_CALIBRATE=1, tools/calibrate.py): one launch per convolution, and
+	// after each the largest |output| of the layer folded into tower_profile[layer] -- works
+	// for every geometry and activation, unlike the resident kernel's in-kernel maxima
+	auto addCalib = [&](int layer, const std::string &tensor) {
+		if (!m_Calibrate) return;
+		const Tensor &t = m_Tensors.at(tensor);
+		const void *src = t.buf.get();
+		const std::size_t n = t.count;
+		unsigned *dst = m_Tensors.at("tower_profile").buf.as<unsigned>() + layer;
+		prog.push_back({"calib", 0.0, [=](hipStream_t s) { launchAbsMax(dt, src, n, dst, s); }});
+	};
+	if (m_Calibrate) {
+		void *profile = m_Tensors.at("tower_profile").buf.get();
+		const std::size_t bytes = (1 + 2 * static_cast<std::size_t>(c.genBlocks)) * 4;
+		prog.push_back({"calib", 0.0, [=](hipStream_t s) { JU_HIP(hipMemsetAsync(profile, 0, bytes, s)); }});
+	}
 	if (!m_Resident || m_Fp8Tower) {  // (the 16-bit resident tower runs conv_1 as its layer 0)
 		addConvStep(&prog, "gen_head", "generator/conv_1", Op("gen_in"), none, Op("trunk_a"), H, W,
 		    true, false);
+		addCalib(0, "trunk_a");
 	}
 	const char *xs[2] = {"trunk_a", "trunk_b"};
 	int a = 0;
@@ -570,7 +589,9 @@ void Engine::buildProgram(int set) {
 		rp.GY = m_ResGY;
 		rp.RH = m_ResRH;
 		rp.nLayers = 1 + 2 * c.genBlocks;
-		tailInTower = m_FusedTail && m_TailInTower && c.genFilters == 64;
+		rp.leaky = c.genActivation == 1 ? 1 : 0;
+		rp.slope = c.genNegativeSlope;
+		tailInTower = m_FusedTail && m_TailInTower && c.genFilters == 64 && c.genActivation == 0;
 		if (tailInTower) {  // the tail runs on the tower's LDS-resident last layer
 			rp.tailW1 = m_Convs.at("generator/conv_trans_1").w.get();
 			rp.tailB1 = m_Convs.at("generator/conv_trans_1").bias.as<float>();
@@ -654,8 +675,10 @@ void Engine::buildProgram(int set) {
 			}
 			addConvStep(&prog, "tower", n + "/conv_1", Op(xs[a]), none, Op("trunk_t"), H, W, true,
 			    false, true);
+			addCalib(2 * i + 1, "trunk_t");
 			addConvStep(&prog, "tower", n + "/conv_2", Op("trunk_t"), Op(xs[a]), Op(xs[a ^ 1]), H, W,
 			    true, false, true);
+			addCalib(2 * i + 2, xs[a ^ 1]);
 			a ^= 1;
 		}
 	}
@@ -764,13 +787,12 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		JU_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
 		bool wanted = !(mode && (std::string(mode) == "layers" || std::string(mode) == "convs"));
 		m_BlockFused = !(mode && std::string(mode) == "convs");
-		if (wanted && c.genActivation != 0) {
-			// the resident kernel's halo slots carry their epoch tag in the sign bits of
-			// post-ReLU values; a LeakyReLU model has no free bits there
-			logMessage(LogLevel::Info, "Engine",
-			    "generator activation is lrelu: the residual tower runs on the per-layer kernels "
-			    "(the resident tower kernel needs ReLU outputs)");
+		const char *calib = std::getenv("JU_CALIBRATE");
+		m_Calibrate = calib && calib[0] == '1';
+		if (m_Calibrate) {
+			if (m_Fp8Tower) throw std::invalid_argument("JU_CALIBRATE: calibrate the fp16 / bf16 engine, not the 8-bit one");
 			wanted = false;
+			m_BlockFused = false;
 		}
 		if (wanted && c.genFilters == 64 && c.genBlocks >= 1 &&
 		    residentTowerGeometry(c.frameHeight, c.frameWidth, cus, &m_ResGX, &m_ResGY, &m_ResRH)) {
@@ -779,8 +801,9 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 			m_TowerW.upload(m_TowerHostW.data(), m_TowerHostW.size() * 2);
 			m_TowerB = DeviceBuffer(m_TowerHostB.size() * 4);
 			m_TowerB.upload(m_TowerHostB.data(), m_TowerHostB.size() * 4);
+			// (`activation: lrelu`: twice the slots -- the epoch travels beside the values)
 			m_ResMail = DeviceBuffer(m_Fp8Tower ? residentMailboxBytes8(m_ResGX, m_ResGY)
-			                                    : residentMailboxBytes(m_ResGX, m_ResGY));
+			                                    : residentMailboxBytes(m_ResGX, m_ResGY, c.genActivation == 1));
 			m_ResFlags = DeviceBuffer(residentCounterBytes(m_ResGX, m_ResGY));  // publish counts per region
 			m_ResError = PinnedWords(64);
 			m_ResErrorDev = m_ResError.device();
@@ -791,7 +814,6 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		if (flowMode && std::string(flowMode) == "convs") m_BlockFused = false;
 		if (m_Resident && !(flowMode && (std::string(flowMode) == "layers" || std::string(flowMode) == "convs")) &&
 		    c.flowArch == 1 &&
-		    c.flowActivation == 0 &&
 		    c.flowResFilters == 64 && c.flowResBlocks >= 1 && 3 * c.numFlowInputs <= 64 &&
 		    residentTowerGeometry(PH, PW, cus, &m_FlowGX, &m_FlowGY, &m_FlowRH)) {
 			m_ResidentFlow = m_ResidentFlowCapable = true;
@@ -799,7 +821,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 			m_FlowTowerW.upload(m_FlowTowerHostW.data(), m_FlowTowerHostW.size() * 2);
 			m_FlowTowerB = DeviceBuffer(m_FlowTowerHostB.size() * 4);
 			m_FlowTowerB.upload(m_FlowTowerHostB.data(), m_FlowTowerHostB.size() * 4);
-			m_FlowMail = DeviceBuffer(residentMailboxBytes(m_FlowGX, m_FlowGY));
+			m_FlowMail = DeviceBuffer(residentMailboxBytes(m_FlowGX, m_FlowGY, c.flowActivation == 1));
 			m_FlowFlags = DeviceBuffer(residentCounterBytes(m_FlowGX, m_FlowGY));
 		}
 		m_FlowTowerHostW.clear();

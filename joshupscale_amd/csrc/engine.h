@@ -193,6 +193,9 @@ private:
 	// after a fallback): one launch per BLOCK (flow_block_kernel, intermediate tensor in LDS);
 	// JU_TOWER=convs keeps one launch per convolution
 	bool m_BlockFused = true;
+	// JU_CALIBRATE=1 (tools/calibrate.py): per-convolution launches + max |output| of every
+	// tower layer per frame into "tower_profile" (as float bit patterns)
+	bool m_Calibrate = false;
 	void planFlowUnits();
 	bool flowConvIsFused(const std::string &name) const;
 	bool m_FusedUpsample = true;  // flow decoder: bilinear x2 folded into the next conv's staging

@@ -12,6 +12,8 @@
 //                       core/src/cuda_convert.cc.cu:95-108); tail = two-kernel form
 //  * temporal_*         moving-average output filter (frame_moving_avg.py)
 //  * copy_rows/to_float staging and introspection helpers
+#include <algorithm>
+
 #include "kernel_common.h"
 
 namespace ju {
@@ -623,7 +625,30 @@ __global__ __launch_bounds__(256) void to_float_kernel(
 	if (idx < n) out[idx] = static_cast<float>(in[idx]);
 }
 
+// max |x| of a 16-bit tensor -> atomic max into *out (bit pattern of a non-negative float:
+// integer order = float order).  Calibration mode only (Engine, JU_CALIBRATE=1).
+template <typename T>
+__global__ __launch_bounds__(256) void abs_max_kernel(const T *__restrict__ in, size_t n8, unsigned *__restrict__ out) {
+	float m = 0.f;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+		const Vec8<T> v = reinterpret_cast<const Vec8<T> *>(in)[i];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(static_cast<float>(v[k])));
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+	if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 }  // namespace
+
+void launchAbsMax(DType dt, const void *in, std::size_t n, unsigned *out, hipStream_t stream) {
+	const std::size_t n8 = n / 8;  // (every tensor of the engine is a multiple of 8 elements)
+	const unsigned nb = static_cast<unsigned>(std::min<std::size_t>(blocksFor(n8), 2048));
+	if (dt == kF16) hipLaunchKernelGGL(abs_max_kernel<f16>, dim3(nb), dim3(256), 0, stream, static_cast<const f16 *>(in), n8, out);
+	else hipLaunchKernelGGL(abs_max_kernel<bf16>, dim3(nb), dim3(256), 0, stream, static_cast<const bf16 *>(in), n8, out);
+	hipCheckLaunch("abs_max");
+}
 
 void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameStride,
     const void *prevPacked, void *curPacked, int H, int W, int PH, int PW, int padTop,

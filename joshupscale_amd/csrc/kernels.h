@@ -200,6 +200,11 @@ struct ResidentTowerParams {
 	int H, W;
 	int GX, GY, RH;
 	int nLayers;
+	// `activation: lrelu` models (models.py:24-27): LeakyReLU(slope) instead of ReLU after every
+	// layer; the mailbox must then be residentMailboxBytes(GX, GY, true) (twice the slots: a
+	// LeakyReLU output has no free sign bit for the slot epoch)
+	int leaky;
+	float slope;
 	// Optional fused generator tail (tailW1 != nullptr): instead of writing the last
 	// layer to `out`, every workgroup runs the tail (launchTailFused's arithmetic) on
 	// its LDS-resident region and writes the HR state and the BGRX frame directly.
@@ -215,7 +220,7 @@ struct ResidentTowerParams {
 	const unsigned *sums;     // normalize_brightness channel sums or nullptr
 };
 bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH);
-std::size_t residentMailboxBytes(int GX, int GY);
+std::size_t residentMailboxBytes(int GX, int GY, bool leaky = false);
 inline std::size_t residentCounterBytes(int GX, int GY) {
 	return (static_cast<std::size_t>(GX) * GY * 2 * sizeof(unsigned) + 63) / 64 * 64;
 }
@@ -340,6 +345,10 @@ void launchTailFused(DType dt, const TailFusedLaunch &p, hipStream_t stream);
 // Row-wise device copy with signed strides (bottom-up frames).
 void launchCopyRows(const std::uint8_t *src, std::ptrdiff_t srcStride, std::uint8_t *dst,
     std::ptrdiff_t dstStride, std::size_t rowBytes, std::size_t rows, hipStream_t stream);
+
+// max |x| over n 16-bit elements, atomically folded into *out as the bit pattern of a
+// non-negative float (the caller zeroes it per frame).  Calibration mode only.
+void launchAbsMax(DType dt, const void *in, std::size_t n, unsigned *out, hipStream_t stream);
 
 // 16-bit tensor -> f32 (debug read-back).
 void launchToFloat(DType dt, const void *in, float *out, std::size_t n, hipStream_t stream);

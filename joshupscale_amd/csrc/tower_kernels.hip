@@ -409,6 +409,7 @@ struct ResidentParams {
 	int H, W, pitch;
 	int GX, GY, RH;
 	int nLayers;
+	float slope;              // LEAKY instantiations: the LeakyReLU negative slope, in [0, 1]
 	// fused generator tail (tailW1 != nullptr), see ResidentTowerParams
 	const void *tailW1;
 	const float *tailB1;
@@ -430,7 +431,11 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // HEAD: layer 0 is the generator's conv_1 (plain conv + ReLU), residual blocks follow
 // TAIL: the generator tail runs on the LDS-resident last layer (JU_TAIL=tower); a
 // separate instantiation so that the default kernel carries none of its code
-template <typename T, int VARIANT, bool HEAD, bool TAIL = false>
+// LEAKY: `activation: lrelu` models (models.py:24-27, 36-60): the epilogue applies
+// x < 0 ? slope * x : x in f32, and -- the outputs having no free sign bit -- the halo slots
+// carry their epoch beside the values instead of inside them (see publish / fillHalo).  A
+// separate instantiation: the ReLU kernel is byte for byte what it was.
+template <typename T, int VARIANT, bool HEAD, bool TAIL = false, bool LEAKY = false>
 __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr bool xchg = !(VARIANT & 1);
@@ -763,12 +768,24 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #pragma unroll
 							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[r][g][i]);
 						}
-						if constexpr (VARIANT == 5) {  // calibration build: range of the layer's output
+						if constexpr (VARIANT == 5 && !LEAKY) {  // calibration build: range of the layer's output
 #pragma unroll
-							for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, v[i]);
+							for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, v[i]);  // (= max of the ReLU'd values)
 						}
-						*reinterpret_cast<Vec4<T> *>(smem + outOff + (ra + r) * kResRowBytes + outsw[g]) =
-						    reluPacked<T>(pack4<T>(v[0], v[1], v[2], v[3]));
+						if constexpr (LEAKY) {
+							// slope in [0, 1] (model.cpp): max(x, slope * x) IS x < 0 ? slope * x : x
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * p.slope);
+							if constexpr (VARIANT == 5) {
+#pragma unroll
+								for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, fabsf(v[i]));
+							}
+							*reinterpret_cast<Vec4<T> *>(smem + outOff + (ra + r) * kResRowBytes + outsw[g]) =
+							    pack4<T>(v[0], v[1], v[2], v[3]);
+						} else {
+							*reinterpret_cast<Vec4<T> *>(smem + outOff + (ra + r) * kResRowBytes + outsw[g]) =
+							    reluPacked<T>(pack4<T>(v[0], v[1], v[2], v[3]));
+						}
 					}
 				}
 			}
@@ -833,7 +850,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// ------------------------------------------------------------------------
 	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
-	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * kResMailSlots * 16), 0x00020000);
+	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * (LEAKY ? 2 : 1) * kResMailSlots * 16), 0x00020000);
 	constexpr int kSc1 = 16;  // cache-policy bit of sc1 (write-through store / L2-bypassing load)
 	// Self-validating slots: every tower output is post-ReLU (>= 0), so the sign bit
 	// of each of the 8 values in a 16-byte slot is free.  EVERY dword carries the same
@@ -854,35 +871,43 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// buffer (A / B) enters as the LDS instructions' immediate offset and the slot parity as
 	// the buffer instructions' scalar offset, so publish and sweep are loads, stores and the
 	// tag arithmetic, nothing else -- in this kernel every other instruction is serial time.
-	constexpr int NP = kResMailSlots / 256;  // publish: 4 strips x 32 entries x 8 chunks
-	constexpr int NS = NP + 1;               // sweep: 4 sides x 32 entries x 8 chunks, + the 4 corners
-	unsigned pubLds[NP];                     // LDS byte offset inside a buffer of the chunk to publish
+	// LEAKY: a LeakyReLU output has no free bit, so a 16-byte slot carries FOUR values, each
+	// dword = value16 | epoch16 << 16 with epoch = (writes to this slot so far) & 0xffff --
+	// every dword still validates itself, the mailbox holds twice the slots (16 per pixel
+	// record instead of 8) and publish / sweep move 8-byte half chunks on the LDS side.
+	constexpr int kSlots = LEAKY ? 2 * kResMailSlots : kResMailSlots;  // per region and parity
+	constexpr int CPP = LEAKY ? 16 : 8;      // slots per pixel record
+	constexpr int CSH = LEAKY ? 4 : 3;
+	constexpr int NP = kSlots / 256;         // publish: 4 strips x 32 entries x CPP slots
+	constexpr int NS = NP + 1;               // sweep: 4 sides x 32 entries x CPP slots, + the 4 corners
+	unsigned pubLds[NP];                     // LDS byte offset inside a buffer of the (half) chunk to publish
 	unsigned pubValid = 0;
 #pragma unroll
 	for (int it = 0; it < NP; ++it) {
 		const int idx = it * 256 + tid;
-		const int strip = idx >> 8, e = (idx >> 3) & 31, c = idx & 7;
+		const int strip = idx >> (5 + CSH), e = (idx >> CSH) & 31, cs = idx & (CPP - 1);
+		const int c = LEAKY ? cs >> 1 : cs, half = LEAKY ? (cs & 1) * 8 : 0;
 		int rr, cc;
 		bool valid;
 		if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
 		else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
 		else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
 		else { rr = e + 1; cc = rwv; valid = e < rhv; }
-		pubLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
+		pubLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4) + half);
 		if (valid) pubValid |= 1u << it;
 	}
-	const unsigned pubBase = (unsigned)(region * 2 * kResMailSlots) * 16u + (unsigned)tid * 16u;
+	const unsigned pubBase = (unsigned)(region * 2 * kSlots) * 16u + (unsigned)tid * 16u;
 	unsigned sweepSrc[NS];  // mailbox byte offset of the neighbour's slot, parity 0
-	unsigned sweepLds[NS];  // LDS byte offset inside a buffer of the halo chunk it fills
+	unsigned sweepLds[NS];  // LDS byte offset inside a buffer of the halo (half) chunk it fills
 	unsigned sweepValid = 0;
 #pragma unroll
 	for (int it = 0; it < NS; ++it) {
-		int nx = gxr, ny = gyr, strip, se, rr, cc, c;
+		int nx = gxr, ny = gyr, strip, se, rr, cc, cs;
 		bool valid;
 		if (it < NS - 1) {
 			const int idx = it * 256 + tid;
-			const int hp = idx >> 3;
-			c = idx & 7;
+			const int hp = idx >> CSH;
+			cs = idx & (CPP - 1);
 			const int side = hp >> 5, e = hp & 31;
 			// side 0: row above, 1: row below, 2: column left, 3: column right
 			if (side < 2) {
@@ -901,10 +926,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				valid = e < rhv;
 			}
 		} else {
-			// corners: threads 0..31 = 4 corners x 8 chunks; the diagonal neighbour's
+			// corners: threads 0 .. 4 * CPP - 1 = 4 corners x CPP slots; the diagonal neighbour's
 			// bottom/top row strip, last/first entry (interior columns are 32 wide)
-			const int k = tid >> 3;
-			c = tid & 7;
+			const int k = tid >> CSH;
+			cs = tid & (CPP - 1);
 			const bool up = k < 2, left = (k & 1) == 0;
 			ny += up ? -1 : 1;
 			nx += left ? -1 : 1;
@@ -912,31 +937,48 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			se = left ? kResRW - 1 : 0;
 			rr = up ? 0 : rhv + 1;
 			cc = left ? 0 : rwv + 1;
-			valid = tid < 32;
+			valid = tid < 4 * CPP;
 		}
+		const int c = LEAKY ? cs >> 1 : cs, half = LEAKY ? (cs & 1) * 8 : 0;
 		valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
 		const int nreg = valid ? ny * p.GX + nx : region;
-		sweepSrc[it] = (unsigned)((nreg * 2) * kResMailSlots + (strip * 32 + se) * 8 + c) * 16u;
-		sweepLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4));
+		sweepSrc[it] = (unsigned)((nreg * 2) * kSlots + (strip * 32 + se) * CPP + cs) * 16u;
+		sweepLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4) + half);
 		if (valid) sweepValid |= 1u << it;
 	}
-	constexpr unsigned kParityBytes = kResMailSlots * 16u;
+	constexpr unsigned kParityBytes = kSlots * 16u;
 	// `layer`: the layer whose output (in buffer `off`) is published
 	auto publish = [&](auto offTag, int layer) __attribute__((always_inline)) {
 		constexpr int off = decltype(offTag)::value;
 		// (the caller has just passed the workgroup barrier: the region's output is in LDS)
 		const int ppar = (layer + 1) & 1;
 		pubCount[ppar] += 1u;
-		const unsigned tm = epochMask(ppar);
 		const unsigned soff = ppar ? kParityBytes : 0u;
-		u32x4 v[NP];
+		if constexpr (LEAKY) {
+			typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+			const unsigned tg = pubCount[ppar] << 16;
+			u32x2 v[NP];
 #pragma unroll
-		for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4 *>(smem + off + pubLds[it]);
+			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x2 *>(smem + off + pubLds[it]);
 #pragma unroll
-		for (int it = 0; it < NP; ++it) {
-			if (pubValid >> it & 1u) {
-				__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7fff7fffu) | tm, mailRsrc,
-				    pubBase + it * 4096, soff, kSc1);
+			for (int it = 0; it < NP; ++it) {
+				if (pubValid >> it & 1u) {
+					const u32x4 d = {(v[it][0] & 0xffffu) | tg, (v[it][0] >> 16) | tg, (v[it][1] & 0xffffu) | tg,
+					    (v[it][1] >> 16) | tg};
+					__builtin_amdgcn_raw_buffer_store_b128(d, mailRsrc, pubBase + it * 4096, soff, kSc1);
+				}
+			}
+		} else {
+			const unsigned tm = epochMask(ppar);
+			u32x4 v[NP];
+#pragma unroll
+			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4 *>(smem + off + pubLds[it]);
+#pragma unroll
+			for (int it = 0; it < NP; ++it) {
+				if (pubValid >> it & 1u) {
+					__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7fff7fffu) | tm, mailRsrc,
+					    pubBase + it * 4096, soff, kSc1);
+				}
 			}
 		}
 	};
@@ -947,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		u64 t0 = 0;  // (the clock is read only once a pass has failed: a scalar-memory round trip)
 		const int par = (layer + 1) & 1;
 		// (this region published the same layer a moment ago: its count is the neighbours')
-		const unsigned tm = epochMask(par);
+		const unsigned tm = LEAKY ? (pubCount[par] & 0xffffu) : epochMask(par);
 		const unsigned soff = par ? kParityBytes : 0u;
 		unsigned pending = sweepValid;
 		// sweep: all loads of a pass in flight together, sc1 (never a stale L1/L2 line);
@@ -962,11 +1004,22 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		auto checkPass = [&]() __attribute__((always_inline)) {
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
-				const u32x4 tg = hv[it] & 0x80008000u;
-				const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
-				if ((pending >> it & 1u) && ok) {
-					*reinterpret_cast<u32x4 *>(smem + off + sweepLds[it]) = hv[it] & 0x7fff7fffu;
-					pending &= ~(1u << it);
+				if constexpr (LEAKY) {
+					typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+					const u32x4 tg = hv[it] >> 16;
+					const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
+					if ((pending >> it & 1u) && ok) {
+						*reinterpret_cast<u32x2 *>(smem + off + sweepLds[it]) =
+						    u32x2{(hv[it][0] & 0xffffu) | (hv[it][1] << 16), (hv[it][2] & 0xffffu) | (hv[it][3] << 16)};
+						pending &= ~(1u << it);
+					}
+				} else {
+					const u32x4 tg = hv[it] & 0x80008000u;
+					const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
+					if ((pending >> it & 1u) && ok) {
+						*reinterpret_cast<u32x4 *>(smem + off + sweepLds[it]) = hv[it] & 0x7fff7fffu;
+						pending &= ~(1u << it);
+					}
 				}
 			}
 		};
@@ -1158,9 +1211,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	}
 }
 
-template <typename T, int VARIANT, bool HEAD, bool TAIL = false>
+template <typename T, int VARIANT, bool HEAD, bool TAIL = false, bool LEAKY = false>
 void launchResidentT(const ResidentParams &p, hipStream_t stream) {
-	auto kern = tower_resident_kernel<T, VARIANT, HEAD, TAIL>;
+	auto kern = tower_resident_kernel<T, VARIANT, HEAD, TAIL, LEAKY>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), kResLds, &ldsDone, "resident tower");
 	// (g_ResidentFault > 0, tests only: some regions are never computed, their neighbours'
@@ -1209,8 +1262,8 @@ bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH) 
 	return true;
 }
 
-std::size_t residentMailboxBytes(int GX, int GY) {
-	return static_cast<std::size_t>(GX) * GY * 2 * kResMailSlots * 16;
+std::size_t residentMailboxBytes(int GX, int GY, bool leaky) {
+	return static_cast<std::size_t>(GX) * GY * 2 * kResMailSlots * 16 * (leaky ? 2 : 1);
 }
 
 void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t stream) {
@@ -1233,6 +1286,7 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.GY = q.GY;
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
+	p.slope = q.slope;
 	p.tailW1 = q.tailW1;
 	p.tailB1 = q.tailB1;
 	p.tailW2 = q.tailW2;
@@ -1245,6 +1299,26 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	p.sums = q.sums;
 	if ((p.nLayers & 1) != (p.hasHead ? 1 : 0)) {
 		throw std::invalid_argument("resident tower: layer count must be 2*blocks (+1 with a head)");
+	}
+	if (q.leaky) {
+		// `activation: lrelu` models: own instantiations (epoch beside the values, f32 LeakyReLU);
+		// variant 8 = the plain schedule (tests), 5 = calibration maxima
+		if (!(q.slope >= 0.0f && q.slope <= 1.0f)) throw std::invalid_argument("resident tower: negative slope outside [0, 1]");
+		if (p.tailW1 != nullptr) throw std::invalid_argument("resident tower: the fused tail is built for ReLU models");
+		if (!p.hasHead) {
+			if (dt == kF16) launchResidentT<f16, 0, false, false, true>(p, stream);
+			else launchResidentT<bf16, 0, false, false, true>(p, stream);
+		} else if (g_TowerVariant == 8) {
+			if (dt == kF16) launchResidentT<f16, 8, true, false, true>(p, stream);
+			else launchResidentT<bf16, 8, true, false, true>(p, stream);
+		} else if (g_TowerVariant == 5 && dt == kBF16) {
+			(void)hipMemsetAsync(p.debug, 0, static_cast<std::size_t>(p.nLayers) * sizeof(unsigned), stream);
+			launchResidentT<bf16, 5, true, false, true>(p, stream);
+		} else {
+			if (dt == kF16) launchResidentT<f16, 0, true, false, true>(p, stream);
+			else launchResidentT<bf16, 0, true, false, true>(p, stream);
+		}
+		return;
 	}
 	if (!p.hasHead) {
 		if (dt == kF16) launchResidentT<f16, 0, false>(p, stream);

@@ -126,6 +126,9 @@ PRESETS: Dict[str, ModelConfig] = {
     "psp-fast": ModelConfig(gen_blocks=8, compute_dtype=DTYPE_F16),
     "ps2-quality": ModelConfig(frame_height=448, frame_width=640),  # BASELINE config 5 runs it with dtype fp8
     "psp-quality-flowres": ModelConfig(flow_arch="resnet", flow_pad_factor=0),
+    # `activation: lrelu` in both sub-models (reference models.py:24-27; the INT8 quantiser of the
+    # deployed graphs lists LeakyRelu, quantize_int8.py:177-178), keras' default slope
+    "psp-quality-lrelu": ModelConfig(flow_activation="lrelu", gen_activation="lrelu"),
 }
 
 

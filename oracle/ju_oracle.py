@@ -298,11 +298,22 @@ def _conv_bn_act(x, wts: Weights, conv: str, bn: str, eps: float, act=relu) -> n
     return act(y)
 
 
-def res_block(x, wts: Weights, name: str, eps: float, act=relu) -> np.ndarray:
+def res_block(x, wts: Weights, name: str, eps: float, act=relu, amax: Optional[list] = None) -> np.ndarray:
     """``res_block`` (models.py:193-254):
     ``act(BN2(conv2(act(BN1(conv1(x))))) + x)``; FadeIn is the identity at
-    inference once its counter has saturated (keras_layers.py:321-323)."""
+    inference once its counter has saturated (keras_layers.py:321-323).
+    ``amax``: receives max |.| of the two post-activation tensors (what a symmetric
+    per-tensor activation calibration records, generate_calibration.py:93-234)."""
     y = _conv_bn_act(x, wts, name + "/conv_1", name + "/bn_1", eps, act)
+    if amax is not None:
+        amax.append(float(np.abs(y).max()))
+    out = _res_block_tail(x, y, wts, name, eps, act)
+    if amax is not None:
+        amax.append(float(np.abs(out).max()))
+    return out
+
+
+def _res_block_tail(x, y, wts: Weights, name: str, eps: float, act) -> np.ndarray:
     y = conv2d_same(y, wts[name + "/conv_2/kernel"])
     b = name + "/bn_2"
     y = batch_norm(y, wts[b + "/gamma"], wts[b + "/beta"],
@@ -335,11 +346,18 @@ def fp8_activation_exponent(amax: float) -> int:
 
 
 def _fold_bn(wts: Weights, conv: str, bn: str, eps: float):
-    """BN folded into the convolution, in float32 like the engine's loader."""
-    k = np.asarray(wts[conv + "/kernel"], np.float32)
-    g = np.asarray(wts[bn + "/gamma"], np.float32)
-    scale = g / np.sqrt(np.asarray(wts[bn + "/moving_variance"], np.float32) + np.float32(eps))
-    bias = np.asarray(wts[bn + "/beta"], np.float32) - np.asarray(wts[bn + "/moving_mean"], np.float32) * scale
+    """BN folded into the convolution the way the engine's loader does it
+    (csrc/model.cpp bnScaleShift / foldConv): scale and shift in float64 from the float32
+    variables, the products rounded ONCE to float32.  Every operation is a correctly rounded
+    IEEE one, so any implementation of this recipe gives the same float32 kernel -- which
+    matters here because the e4m3 quantiser that follows is discontinuous."""
+    f8 = np.float64
+    k = np.asarray(wts[conv + "/kernel"], np.float32).astype(f8)
+    g = np.asarray(wts[bn + "/gamma"], np.float32).astype(f8)
+    var = np.asarray(wts[bn + "/moving_variance"], np.float32).astype(f8)
+    scale = g / np.sqrt(var + f8(np.float32(eps)))
+    bias = np.asarray(wts[bn + "/beta"], np.float32).astype(f8) - \
+        np.asarray(wts[bn + "/moving_mean"], np.float32).astype(f8) * scale
     return (k * scale).astype(np.float32), bias.astype(np.float32)
 
 
@@ -423,6 +441,9 @@ def generator(images: np.ndarray, pre_warp: np.ndarray, wts: Weights,
     _rec(trace, "gen_in_ref", x)  # reference channel order, 51 channels
     x = _conv_bn_act(x, wts, "generator/conv_1", "generator/bn_1", eps, act)
     _rec(trace, "gen_head", x)
+    # max |output| of generator/conv_1 and of the two activations of every residual block, in
+    # execution order: the tensors an activation calibration ranges over
+    amax = [float(np.abs(x).max())] if trace is not None and not cfg.fp8_tower else None
     if cfg.fp8_tower:
         amax = wts.get("generator/fp8_amax")
         exps = [fp8_activation_exponent(FP8_DEFAULT_AMAX if amax is None else float(np.float32(amax[j])))
@@ -431,7 +452,9 @@ def generator(images: np.ndarray, pre_warp: np.ndarray, wts: Weights,
         if cfg.fp8_tower:
             x = res_block_fp8(x, wts, f"generator/block_{i + 1}", eps, exps[2 * i], exps[2 * i + 1])
         else:
-            x = res_block(x, wts, f"generator/block_{i + 1}", eps, act)
+            x = res_block(x, wts, f"generator/block_{i + 1}", eps, act, amax)
+    if amax is not None:
+        trace["tower_amax"] = np.asarray(amax)
     _rec(trace, "trunk", x)
     x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_1/kernel"])
     b = "generator/bn_2"

@@ -10,6 +10,7 @@ travel to the GPU box as plain data.
     python tests/golden/make_golden.py            # small fixtures (seconds)
     python tests/golden/make_golden.py --full     # + the four full-size presets (~15 min)
     python tests/golden/make_golden.py --preset psp-fast   # one full-size preset only
+    python tests/golden/make_golden.py --preset psp-quality --fp8   # its 8-bit-tower fixture
 """
 
 import argparse
@@ -60,18 +61,23 @@ def crops_for(h: int, w: int):
             (H * 5 // 18 // 4 * 4, W * 5 // 8 // 4 * 4)]
 
 
-def full(preset: str = "psp-quality") -> None:
+# the 8-bit tower (BASELINE.json config 5) at the sizes it is quoted on: same clip, same crops
+FULL_FP8 = {"psp-quality": ("full_psp_quality_fp8", 2), "ps2-quality": ("full_ps2_quality_fp8", 2)}
+
+
+def full(preset: str = "psp-quality", fp8_tower: bool = False) -> None:
     """Full-size fixture of one preset, generated TWICE: by the numpy float64 oracle and
     by the independent PyTorch restatement (tests/torch_restatement.py).  Both whole-frame
     SHA-256 digests are stored (the only independent anchor available: the reference ships
-    no vectors and cannot run here); the crops and means come from the numpy oracle."""
+    no vectors and cannot run here); the crops and means come from the numpy oracle.
+    fp8_tower: the restatements of the 8-bit tower scheme (csrc/fp8.h) instead."""
     from torch_restatement import TorchSession
-    name, n = FULL_PRESETS[preset]
+    name, n = (FULL_FP8 if fp8_tower else FULL_PRESETS)[preset]
     cfg = M.PRESETS[preset]
     h, w = cfg.frame_height, cfg.frame_width
     wts = M.make_seeded_weights(cfg, seed=42)
-    sess = O.Session(wts, oracle_config(cfg))
-    tsess = TorchSession(wts, oracle_config(cfg))
+    sess = O.Session(wts, oracle_config(cfg, fp8_tower=fp8_tower))
+    tsess = TorchSession(wts, oracle_config(cfg, fp8_tower=fp8_tower))
     frames = M.synthetic_frames(n, h, w, seed=777, kind="smooth")
     crops = crops_for(h, w)
     assert preset != "psp-quality" or crops == CROPS
@@ -110,10 +116,11 @@ if __name__ == "__main__":
     ap.add_argument("--preset", action="append", choices=sorted(FULL_PRESETS),
                     help="only this full-size preset (repeatable); skips the small fixtures")
     ap.add_argument("--only", action="append", help="only this small fixture (repeatable)")
+    ap.add_argument("--fp8", action="store_true", help="with --preset / --full: the 8-bit tower fixtures")
     a = ap.parse_args()
     if a.preset:
         for p in a.preset:
-            full(p)
+            full(p, fp8_tower=a.fp8)
         sys.exit(0)
     smalls = {
         "small_autoencoder": (small_config(), 4, "smooth", 11, False),
@@ -132,3 +139,5 @@ if __name__ == "__main__":
     if a.full:
         for p in FULL_PRESETS:
             full(p)
+        for p in FULL_FP8:
+            full(p, fp8_tower=True)

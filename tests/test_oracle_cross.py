@@ -30,6 +30,25 @@ def test_numpy_oracle_vs_torch_restatement(arch, pad, h, w, extra):
         assert (a[..., 3] == 0).all()
 
 
+def test_numpy_oracle_vs_torch_restatement_8bit_tower():
+    """The 8-bit tower scheme (csrc/fp8.h) restated twice: the oracle's frexp-based e4m3
+    rounding against PyTorch's own float8_e4m3fn conversion, scales derived independently.
+    Both fold BatchNorm the way the loader does (float64, one rounding to float32), so the
+    discontinuous quantiser sees identical inputs and the frames are EQUAL."""
+    cfg = small_config(gen_blocks=4)
+    wts = M.make_seeded_weights(cfg)
+    amax = np.linspace(0.8, 9.0, 8).astype(np.float32)          # a calibration tensor too
+    for extra in ({}, {"generator/fp8_amax": amax}):
+        w = dict(wts, **extra)
+        s = O.Session(w, oracle_config(cfg, fp8_tower=True))
+        ts = TorchSession(w, oracle_config(cfg, fp8_tower=True))
+        for f in M.synthetic_frames(3, 30, 48, seed=14, kind="smooth"):
+            a, b = s.run(f), ts.run(f)
+            raw = ts.output_raw[0].permute(1, 2, 0).numpy()
+            assert np.abs(raw - s.last.output_raw).max() <= 1e-9
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("arch,pad,extra", [("autoencoder", 8, {}), ("resnet", 0, {}),
                                             ("autoencoder", 8, LRELU), ("resnet", 0, LRELU)])
 def test_c_restatement_vs_numpy_oracle(arch, pad, extra):

@@ -55,6 +55,62 @@ def _res(x, w, n, eps, act=F.relu):
     return act(y + x)
 
 
+# ---- 8-bit tower (the BUILD's scheme, joshupscale_amd/csrc/fp8.h), restated a second time ----
+# e4m3 rounding is PyTorch's own float8_e4m3fn conversion (round to nearest even), not the
+# oracle's frexp arithmetic; scales are derived with torch ops.
+def _e4m3(x):
+    """Nearest e4m3 value, ties to even, of float64 data through PyTorch's float8_e4m3fn cast.
+    The cast takes float32, and float64 -> float32 -> e4m3 with two nearest roundings goes
+    wrong for values within 2^-24 of an e4m3 tie (a few per 10^7: enough to flip a handful of
+    activations per full-size tensor), so the first step rounds TO ODD (truncate, set the last
+    bit when inexact), after which the second rounding is the correct one."""
+    x = x.clamp(-448.0, 448.0)
+    f = x.to(torch.float32)
+    back = f.to(DT)
+    f = torch.where(back.abs() > x.abs(), torch.nextafter(f, torch.zeros_like(f)), f)  # toward zero
+    bits = f.view(torch.int32)
+    f = torch.where(back != x, bits | 1, bits).view(torch.float32)
+    return f.to(torch.float8_e4m3fn).to(DT)
+
+
+def _fold32(w, conv, bn, eps):
+    """BN folded into the kernel as the engine's loader stores it (csrc/model.cpp): float64
+    arithmetic on the float32 variables, rounded once to float32.  OIHW kernel, bias."""
+    k = torch.from_numpy(np.asarray(w[conv + "/kernel"], np.float32)).to(DT).permute(3, 2, 0, 1)
+    g = torch.from_numpy(np.asarray(w[bn + "/gamma"], np.float32)).to(DT)
+    var = torch.from_numpy(np.asarray(w[bn + "/moving_variance"], np.float32)).to(DT)
+    scale = g / torch.sqrt(var + float(np.float32(eps)))
+    bias = torch.from_numpy(np.asarray(w[bn + "/beta"], np.float32)).to(DT) - \
+        torch.from_numpy(np.asarray(w[bn + "/moving_mean"], np.float32)).to(DT) * scale
+    return (k * scale.view(-1, 1, 1, 1)).to(torch.float32), bias.to(torch.float32)
+
+
+def _q_weights(k):
+    """Per output channel 2^ew with max|w| 2^ew in (224, 448], then e4m3, scaled back."""
+    amax = k.abs().amax(dim=(1, 2, 3)).to(DT)
+    ew = torch.where(amax > 0, torch.floor(torch.log2(448.0 / amax.clamp(min=1e-300))), torch.zeros_like(amax))
+    ew = ew.clamp(-32, 32).view(-1, 1, 1, 1)
+    return _e4m3(k.to(DT) * torch.exp2(ew)) * torch.exp2(-ew)
+
+
+def _q_act(x, e):
+    return _e4m3(torch.minimum(x * 2.0 ** e, torch.tensor(448.0, dtype=DT))) * 2.0 ** -e
+
+
+def _act_exponent(amax):
+    if not (amax > 0 and np.isfinite(amax)):
+        return 0
+    return int(min(max(np.floor(np.log2(224.0 / amax)), -16), 16))
+
+
+def _res_fp8(x, w, n, eps, ex, et):
+    k1, b1 = _fold32(w, n + "/conv_1", n + "/bn_1", eps)
+    k2, b2 = _fold32(w, n + "/conv_2", n + "/bn_2", eps)
+    t = F.relu(F.conv2d(_q_act(x, ex), _q_weights(k1), b1.to(DT), padding=1))
+    y = F.conv2d(_q_act(t, et), _q_weights(k2), b2.to(DT), padding=1)
+    return F.relu(y + x)
+
+
 def _up_tf1(x, s):
     # tf.compat.v1 resize_bilinear(align_corners=False, half_pixel_centers=False)
     n, c, h, w = x.shape
@@ -145,8 +201,16 @@ class TorchSession:
         x = torch.cat([cur, _s2d(pre_warp, 4)], dim=1)
         act = _act(cfg, "gen")
         x = _cba(x, w, "generator/conv_1", "generator/bn_1", eps, act)
+        fp8 = getattr(cfg, "fp8_tower", False)
+        if fp8:
+            amax = w.get("generator/fp8_amax")
+            exps = [_act_exponent(7.0 if amax is None else float(np.float32(amax[j])))
+                    for j in range(2 * cfg.gen_blocks)]
         for i in range(cfg.gen_blocks):
-            x = _res(x, w, f"generator/block_{i + 1}", eps, act)
+            if fp8:
+                x = _res_fp8(x, w, f"generator/block_{i + 1}", eps, exps[2 * i], exps[2 * i + 1])
+            else:
+                x = _res(x, w, f"generator/block_{i + 1}", eps, act)
         k1 = _t(w["generator/conv_trans_1/kernel"]).permute(3, 2, 0, 1)
         x = act(_bn(F.conv_transpose2d(x, k1, stride=2), w, "generator/bn_2", eps))
         k2 = _t(w["generator/conv_trans_2/kernel"]).permute(3, 2, 0, 1)
