@@ -567,6 +567,8 @@ void Engine::buildProgram(int set) {
 		rp.GY = m_ResGY;
 		rp.RH = m_ResRH;
 		rp.nLayers = 2 * c.genBlocks;
+		rp.leaky = c.genActivation == 1 ? 1 : 0;
+		rp.slope = c.genNegativeSlope;
 		prog.push_back({"tower", 2.0 * H * W * 9.0 * 64.0 * 64 * 2 * c.genBlocks,
 		    [=](hipStream_t s) { launchResidentTower8(dt, rp, s); }});
 		a = 1;
@@ -619,8 +621,9 @@ void Engine::buildProgram(int set) {
 		void *streamBuf = m_Tensors.at("trunk_a").buf.get();
 		void *x8 = m_Fp8X.get(), *t8 = m_Fp8T.get();
 		const int e0 = m_Fp8Exp[0];
+		const bool leaky8 = c.genActivation == 1;
 		prog.push_back({"tower", 0.0,
-		    [=](hipStream_t s) { launchQuantizeTower(dt, streamBuf, x8, H, W, e0, s); }});
+		    [=](hipStream_t s) { launchQuantizeTower(dt, streamBuf, x8, H, W, e0, leaky8, s); }});
 		for (int i = 0; i < c.genBlocks && m_BlockFused; ++i) {
 			// one launch per block: the e4m3 stream copy ping-pongs between the two tensors
 			const std::string n = "generator/block_" + std::to_string(i + 1);
@@ -640,6 +643,8 @@ void Engine::buildProgram(int set) {
 			fb.outExp = (i + 1 < c.genBlocks) ? m_Fp8Exp[2 * i + 2] : 0;  // (the last copy has no reader)
 			fb.H = H;
 			fb.W = W;
+			fb.leaky = leaky8 ? 1 : 0;
+			fb.slope = c.genNegativeSlope;
 			prog.push_back({"tower", 2.0 * H * W * 9.0 * 64 * 64 * 2,
 			    [=](hipStream_t s) { launchResBlockFp8(dt, fb, s); }});
 		}
@@ -660,6 +665,8 @@ void Engine::buildProgram(int set) {
 				fp.outExp = (2 * i + j + 1 < 2 * c.genBlocks) ? m_Fp8Exp[2 * i + j + 1] : 0;
 				fp.H = H;
 				fp.W = W;
+				fp.leaky = leaky8 ? 1 : 0;
+				fp.slope = c.genNegativeSlope;
 				prog.push_back({"tower", 2.0 * H * W * 9.0 * 64 * 64,
 				    [=](hipStream_t s) { launchConvTowerFp8(dt, fp, s); }});
 			}
@@ -750,10 +757,6 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		if (c.genFilters != 64 || c.genBlocks < 1) {
 			throw std::invalid_argument("fp8 tower needs a 64-filter generator with at least one residual block");
 		}
-		if (c.genActivation != 0) {
-			throw std::invalid_argument("fp8 tower: the 8-bit scheme is defined for ReLU generators only "
-			                            "(its conv inputs are non-negative tensors); run this model in fp16 or bf16");
-		}
 		m_Fp8Tower = true;
 		dt = kF16;
 	}
@@ -802,7 +805,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 			m_TowerB = DeviceBuffer(m_TowerHostB.size() * 4);
 			m_TowerB.upload(m_TowerHostB.data(), m_TowerHostB.size() * 4);
 			// (`activation: lrelu`: twice the slots -- the epoch travels beside the values)
-			m_ResMail = DeviceBuffer(m_Fp8Tower ? residentMailboxBytes8(m_ResGX, m_ResGY)
+			m_ResMail = DeviceBuffer(m_Fp8Tower ? residentMailboxBytes8(m_ResGX, m_ResGY, c.genActivation == 1)
 			                                    : residentMailboxBytes(m_ResGX, m_ResGY, c.genActivation == 1));
 			m_ResFlags = DeviceBuffer(residentCounterBytes(m_ResGX, m_ResGY));  // publish counts per region
 			m_ResError = PinnedWords(64);

@@ -80,13 +80,22 @@ __device__ __forceinline__ void store16(unsigned char *base, unsigned uniformOff
 #define JU_F8_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
-// e4m3 of four non-negative values, saturating (the hardware conversion returns NaN
-// above 448: tools/probes/fp8_mfma_probe.hip), packed into one dword
+// e4m3 of four values, saturating (the hardware conversion returns NaN above 448:
+// tools/probes/fp8_mfma_probe.hip), packed into one dword.  ReLU models: the values are
+// non-negative, one min each; LEAKY (`activation: lrelu`): clamped on both sides.
+template <bool LEAKY = false>
 __device__ __forceinline__ int quantize4(float a, float b, float c, float d, float mul) {
-	a = fminf(a * mul, 448.0f);
-	b = fminf(b * mul, 448.0f);
-	c = fminf(c * mul, 448.0f);
-	d = fminf(d * mul, 448.0f);
+	if constexpr (LEAKY) {
+		a = __builtin_amdgcn_fmed3f(a * mul, -448.0f, 448.0f);
+		b = __builtin_amdgcn_fmed3f(b * mul, -448.0f, 448.0f);
+		c = __builtin_amdgcn_fmed3f(c * mul, -448.0f, 448.0f);
+		d = __builtin_amdgcn_fmed3f(d * mul, -448.0f, 448.0f);
+	} else {
+		a = fminf(a * mul, 448.0f);
+		b = fminf(b * mul, 448.0f);
+		c = fminf(c * mul, 448.0f);
+		d = fminf(d * mul, 448.0f);
+	}
 	int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
 	return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
 }
@@ -101,12 +110,13 @@ struct Fp8KernelParams {
 	unsigned char *out8;       // e4m3 out, allocation start
 	int scaleB;                // E8M0 code of the input tensor's scale 2^-ea
 	float outMul;              // 2^ea of the output tensor
+	float slope;               // LEAKY instantiations: LeakyReLU negative slope
 	int H, W, pitch;           // pitch in pixels
 	int tilesX, numTiles;
 };
 
 // STREAM: second conv of a block: + skip connection, writes the 16-bit stream too
-template <typename T, bool STREAM>
+template <typename T, bool STREAM, bool LEAKY = false>
 __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8KernelParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	unsigned char *smT = smem;
@@ -278,7 +288,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 				for (int g = 0; g < 4; ++g) {
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
-						acc[rw][4 * g + i] = fmaxf(acc[rw][4 * g + i] + static_cast<float>(rv[g][i]), 0.0f);
+						acc[rw][4 * g + i] = act8<LEAKY>(acc[rw][4 * g + i] + static_cast<float>(rv[g][i]), p.slope);
 					}
 					*reinterpret_cast<Vec4<T> *>(rec + ((g ^ sw) << 4)) =
 					    pack4<T>(acc[rw][4 * g], acc[rw][4 * g + 1], acc[rw][4 * g + 2], acc[rw][4 * g + 3]);
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 #pragma unroll
 			for (int rw = 0; rw < 4; ++rw) {
 #pragma unroll
-				for (int i = 0; i < 16; ++i) acc[rw][i] = fmaxf(acc[rw][i], 0.0f);
+				for (int i = 0; i < 16; ++i) acc[rw][i] = act8<LEAKY>(acc[rw][i], p.slope);
 			}
 		}
 		// e4m3 copy through the slice: [rw][g][px][hh] dwords (every write instruction covers
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
 				*reinterpret_cast<int *>(slice + ((rw * 4 + g) * 64 + px * 2 + hh) * 4) =
-				    quantize4(acc[rw][4 * g], acc[rw][4 * g + 1], acc[rw][4 * g + 2], acc[rw][4 * g + 3], p.outMul);
+				    quantize4<LEAKY>(acc[rw][4 * g], acc[rw][4 * g + 1], acc[rw][4 * g + 2], acc[rw][4 * g + 3], p.outMul);
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -366,6 +376,7 @@ struct Fp8BlockParams {
 	const float *b1, *b2;
 	int scaleB1, scaleB2;       // E8M0 codes of the input / intermediate tensor scales
 	float mulT, mulOut;         // 2^e of the intermediate / output e4m3 tensors
+	float slope;                // LEAKY instantiations: LeakyReLU negative slope
 	int H, W, pitch;
 	int tilesX, numTiles;
 	int skip;                   // timing ablation (JU_FB_SKIP, developer only)
@@ -389,7 +400,7 @@ struct Fp8BlockGeom {
 	static_assert(LDS <= 160 * 1024, "fp8 block tile");
 };
 
-template <typename T, int TH>
+template <typename T, int TH, bool LEAKY = false>
 __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p) {
 	using G = Fp8BlockGeom<TH>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -513,8 +524,8 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				unsigned char *rec = smT + (tr * 34 + px) * 64;
 #pragma unroll
 				for (int g = 0; g < 4; ++g) {
-					int q = quantize4(fmaxf(acc[r][4 * g], 0.0f), fmaxf(acc[r][4 * g + 1], 0.0f),
-					    fmaxf(acc[r][4 * g + 2], 0.0f), fmaxf(acc[r][4 * g + 3], 0.0f), p.mulT);
+					int q = quantize4<LEAKY>(act8<LEAKY>(acc[r][4 * g], p.slope), act8<LEAKY>(acc[r][4 * g + 1], p.slope),
+					    act8<LEAKY>(acc[r][4 * g + 2], p.slope), act8<LEAKY>(acc[r][4 * g + 3], p.slope), p.mulT);
 					if (!inside) q = 0;
 					// bytes 32 cb + 8 g + 4 hh .. + 3 of the record: chunk 2 cb + (g >> 1)
 					*reinterpret_cast<int *>(rec + (((2 * cb + (g >> 1)) ^ sw) << 4) + (g & 1) * 8 + hh * 4) = q;
@@ -582,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				for (int g = 0; g < 4; ++g) {
 					float v[4];
 #pragma unroll
-					for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[r][4 * g + i] + static_cast<float>(rv[g][i]), 0.0f);
+					for (int i = 0; i < 4; ++i) v[i] = act8<LEAKY>(acc[r][4 * g + i] + static_cast<float>(rv[g][i]), p.slope);
 					*reinterpret_cast<Vec4<T> *>(rec + ((static_cast<unsigned>(g) ^ sw) << 4)) = pack4<T>(v[0], v[1], v[2], v[3]);
 					acc[r][4 * g] = v[0];
 					acc[r][4 * g + 1] = v[1];
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 #pragma unroll
 				for (int g = 0; g < 4; ++g) {
 					*reinterpret_cast<int *>(stage8 + (g * 64 + px * 2 + hh) * 4) =
-					    quantize4(acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3], p.mulOut);
+					    quantize4<LEAKY>(acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3], p.mulOut);
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
@@ -640,10 +651,10 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 	}
 }
 
-template <typename T, int TH>
+template <typename T, int TH, bool LEAKY>
 void launchFp8BlockT(Fp8BlockParams k, int cus, hipStream_t stream) {
 	using G = Fp8BlockGeom<TH>;
-	auto kern = res_block_fp8_kernel<T, TH>;
+	auto kern = res_block_fp8_kernel<T, TH, LEAKY>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "fp8 block");
 	k.tilesX = (k.W + 29) / 30;
@@ -654,7 +665,7 @@ void launchFp8BlockT(Fp8BlockParams k, int cus, hipStream_t stream) {
 }
 
 // 16-bit tower tensor -> e4m3 copy (interior pixels only: the border stays zero)
-template <typename T>
+template <typename T, bool LEAKY>
 __global__ __launch_bounds__(256) void quantize_tower_kernel(const T *__restrict__ in,
     unsigned char *__restrict__ out, int H, int W, int pitch, float mul) {
 	const int i = blockIdx.x * 256 + threadIdx.x;  // one 16-channel chunk per thread
@@ -668,18 +679,20 @@ __global__ __launch_bounds__(256) void quantize_tower_kernel(const T *__restrict
 	float v[16];
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
-		v[k] = fmaxf(static_cast<float>(a[k]), 0.0f);
-		v[8 + k] = fmaxf(static_cast<float>(b[k]), 0.0f);
+		// (the tensor is a layer's OUTPUT: the activation has been applied; ReLU models clamp
+		// at 0 all the same -- a no-op that keeps -0.0 out of the e4m3 copy)
+		v[k] = LEAKY ? static_cast<float>(a[k]) : fmaxf(static_cast<float>(a[k]), 0.0f);
+		v[8 + k] = LEAKY ? static_cast<float>(b[k]) : fmaxf(static_cast<float>(b[k]), 0.0f);
 	}
 	i32x4 o;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) o[k] = quantize4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], mul);
+	for (int k = 0; k < 4; ++k) o[k] = quantize4<LEAKY>(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], mul);
 	*reinterpret_cast<i32x4 *>(out + rec * 64 + chunk * 16) = o;
 }
 
-template <typename T, bool STREAM>
+template <typename T, bool STREAM, bool LEAKY>
 void launchFp8T(const Fp8KernelParams &k, int grid, hipStream_t stream) {
-	auto kern = conv_tower_fp8_kernel<T, STREAM>;
+	auto kern = conv_tower_fp8_kernel<T, STREAM, LEAKY>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), kF8Lds, &ldsDone, "fp8 tower");
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(kF8Threads), kF8Lds, stream, k);
@@ -699,6 +712,7 @@ void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
 	k.out8 = static_cast<unsigned char *>(q.out8);
 	k.scaleB = 127 - q.inExp;
 	k.outMul = std::ldexp(1.0f, q.outExp);
+	k.slope = q.slope;
 	k.H = q.H;
 	k.W = q.W;
 	k.pitch = towerPitch(q.W);
@@ -721,12 +735,22 @@ void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
 	if (grid > 8) grid = k.numTiles <= 2 * cus ? (grid + 7) / 8 * 8 : grid - grid % 8;
 	// JU_FP8_GRID=n (tests): any grid computes the same bytes, a race would not
 	if (const char *g = std::getenv("JU_FP8_GRID")) grid = std::atoi(g) > 0 ? std::atoi(g) : grid;
+	if (q.leaky) {  // `activation: lrelu` models: own instantiations, the ReLU kernels are unchanged
+		if (q.stream != nullptr) {
+			if (dt == kF16) launchFp8T<f16, true, true>(k, grid, stream);
+			else launchFp8T<bf16, true, true>(k, grid, stream);
+		} else {
+			if (dt == kF16) launchFp8T<f16, false, true>(k, grid, stream);
+			else launchFp8T<bf16, false, true>(k, grid, stream);
+		}
+		return;
+	}
 	if (q.stream != nullptr) {
-		if (dt == kF16) launchFp8T<f16, true>(k, grid, stream);
-		else launchFp8T<bf16, true>(k, grid, stream);
+		if (dt == kF16) launchFp8T<f16, true, false>(k, grid, stream);
+		else launchFp8T<bf16, true, false>(k, grid, stream);
 	} else {
-		if (dt == kF16) launchFp8T<f16, false>(k, grid, stream);
-		else launchFp8T<bf16, false>(k, grid, stream);
+		if (dt == kF16) launchFp8T<f16, false, false>(k, grid, stream);
+		else launchFp8T<bf16, false, false>(k, grid, stream);
 	}
 }
 
@@ -745,6 +769,7 @@ void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 	k.scaleB2 = 127 - q.midExp;
 	k.mulT = std::ldexp(1.0f, q.midExp);
 	k.mulOut = std::ldexp(1.0f, q.outExp);
+	k.slope = q.slope;
 	k.H = q.H;
 	k.W = q.W;
 	k.pitch = towerPitch(q.W);
@@ -765,11 +790,16 @@ void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 			best = th;
 		}
 	}
-#define JU_F8B(TH_)                                        \
-	if (best == TH_) {                                     \
-		if (dt == kF16) launchFp8BlockT<f16, TH_>(k, cus, stream); \
-		else launchFp8BlockT<bf16, TH_>(k, cus, stream);   \
-		return;                                            \
+#define JU_F8B(TH_)                                                       \
+	if (best == TH_) {                                                    \
+		if (q.leaky) {                                                    \
+			if (dt == kF16) launchFp8BlockT<f16, TH_, true>(k, cus, stream);  \
+			else launchFp8BlockT<bf16, TH_, true>(k, cus, stream);        \
+		} else {                                                          \
+			if (dt == kF16) launchFp8BlockT<f16, TH_, false>(k, cus, stream); \
+			else launchFp8BlockT<bf16, TH_, false>(k, cus, stream);       \
+		}                                                                 \
+		return;                                                           \
 	}
 	JU_F8B(18)
 	JU_F8B(14)
@@ -778,17 +808,21 @@ void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 #undef JU_F8B
 }
 
-void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int exponent,
+void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int exponent, bool leaky,
     hipStream_t stream) {
 	const int n = H * W * 4;
 	const float mul = std::ldexp(1.0f, exponent);
 	const int pitch = towerPitch(W);
+	const dim3 grid((n + 255) / 256), block(256);
+	auto *dst = static_cast<unsigned char *>(out8);
 	if (dt == kF16) {
-		hipLaunchKernelGGL(quantize_tower_kernel<f16>, dim3((n + 255) / 256), dim3(256), 0, stream,
-		    static_cast<const f16 *>(in), static_cast<unsigned char *>(out8), H, W, pitch, mul);
+		const auto *src = static_cast<const f16 *>(in);
+		if (leaky) hipLaunchKernelGGL((quantize_tower_kernel<f16, true>), grid, block, 0, stream, src, dst, H, W, pitch, mul);
+		else hipLaunchKernelGGL((quantize_tower_kernel<f16, false>), grid, block, 0, stream, src, dst, H, W, pitch, mul);
 	} else {
-		hipLaunchKernelGGL(quantize_tower_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, stream,
-		    static_cast<const bf16 *>(in), static_cast<unsigned char *>(out8), H, W, pitch, mul);
+		const auto *src = static_cast<const bf16 *>(in);
+		if (leaky) hipLaunchKernelGGL((quantize_tower_kernel<bf16, true>), grid, block, 0, stream, src, dst, H, W, pitch, mul);
+		else hipLaunchKernelGGL((quantize_tower_kernel<bf16, false>), grid, block, 0, stream, src, dst, H, W, pitch, mul);
 	}
 	hipCheckLaunch("quantize_tower");
 }

@@ -91,6 +91,13 @@ __device__ __forceinline__ Vec4<T> pack4(float a, float b, float c, float d) {
 	return __builtin_bit_cast(Vec4<T>, u32x2p{l, h});
 }
 
+// Activation of the 8-bit tower's layers in f32 (csrc/fp8.h): ReLU, or (LEAKY) LeakyReLU --
+// slope in [0, 1] (model.cpp), so max(x, slope * x) IS x < 0 ? slope * x : x.
+template <bool LEAKY>
+__device__ __forceinline__ float act8(float v, float slope) {
+	return LEAKY ? fmaxf(v, v * slope) : fmaxf(v, 0.0f);
+}
+
 // Timing-ablation bits (JU_FB_SKIP: drop staging / MFMAs / stores inside a kernel to see what
 // the phase costs).  They exist in PROBE builds only (make KERNELFLAGS+=-DJU_ABLATE, as
 // tools/*_ablate.sh do): the product library neither reads the variable nor carries the

@@ -155,6 +155,8 @@ struct Fp8TowerParams {
 	int inExp;            // the input tensor holds e4m3(x * 2^inExp)
 	int outExp;           // the output copy holds e4m3(y * 2^outExp)
 	int H, W;
+	int leaky;            // `activation: lrelu` models: LeakyReLU(slope) instead of ReLU
+	float slope;
 };
 void launchConvTowerFp8(DType dt, const Fp8TowerParams &p, hipStream_t stream);
 // One residual block of the 8-bit tower per launch (the intermediate e4m3 tensor stays in
@@ -169,10 +171,13 @@ struct Fp8BlockLaunch {
 	const float *b1, *b2;
 	int inExp, midExp, outExp;
 	int H, W;
+	int leaky;            // `activation: lrelu` models
+	float slope;
 };
 void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream);
-// e4m3(max(x, 0) * 2^exponent) of a 16-bit tower tensor (allocation starts)
-void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int exponent,
+// e4m3(max(x, 0) * 2^exponent) of a 16-bit tower tensor (allocation starts); leaky: the tensor
+// is a LeakyReLU output, e4m3(clamp(x * 2^exponent, +-448))
+void launchQuantizeTower(DType dt, const void *in, void *out8, int H, int W, int exponent, bool leaky,
     hipStream_t stream);
 
 // ---- resident tower: every residual-block convolution in one launch --------
@@ -254,8 +259,10 @@ struct ResidentTower8Params {
 	int H, W;
 	int GX, GY, RH;
 	int nLayers;
+	int leaky;           // `activation: lrelu` models; the mailbox is then residentMailboxBytes8(GX, GY, true)
+	float slope;
 };
-std::size_t residentMailboxBytes8(int GX, int GY);
+std::size_t residentMailboxBytes8(int GX, int GY, bool leaky = false);
 void launchResidentTower8(DType dt, const ResidentTower8Params &p, hipStream_t stream);
 
 // ---- flow-net helpers -------------------------------------------------------

@@ -58,14 +58,17 @@ __device__ __forceinline__ void t8Glds16(const void *g, void *l) {
 // value as min(max(x, 0) * mul, 448) of the other 8-bit kernels: mul is a positive power
 // of two.  (371 -> 361 us per tower against separate max / min.)
 // (the multiplies as two packed v_pk_mul_f32: same values, half the instructions)
+// LEAKY (`activation: lrelu`): the caller has applied the LeakyReLU; clamp on both sides.
 typedef float t8f32x2 __attribute__((ext_vector_type(2)));
+template <bool LEAKY = false>
 __device__ __forceinline__ int t8Quantize4(float a, float b, float c, float d, float mul) {
 	const t8f32x2 m = {mul, mul};
 	const t8f32x2 ab = t8f32x2{a, b} * m, cd = t8f32x2{c, d} * m;
-	a = __builtin_amdgcn_fmed3f(ab[0], 0.0f, 448.0f);
-	b = __builtin_amdgcn_fmed3f(ab[1], 0.0f, 448.0f);
-	c = __builtin_amdgcn_fmed3f(cd[0], 0.0f, 448.0f);
-	d = __builtin_amdgcn_fmed3f(cd[1], 0.0f, 448.0f);
+	constexpr float lo = LEAKY ? -448.0f : 0.0f;
+	a = __builtin_amdgcn_fmed3f(ab[0], lo, 448.0f);
+	b = __builtin_amdgcn_fmed3f(ab[1], lo, 448.0f);
+	c = __builtin_amdgcn_fmed3f(cd[0], lo, 448.0f);
+	d = __builtin_amdgcn_fmed3f(cd[1], lo, 448.0f);
 	int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
 	return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
 }
@@ -84,11 +87,15 @@ struct Tower8Params {
 	int H, W, pitch;
 	int GX, GY, RH;
 	int nLayers;               // 2 x blocks
+	float slope;               // LEAKY instantiations: LeakyReLU negative slope
 	int fault;                 // test hook: workgroups launched short (they never publish)
 	int skip;                  // timing ablation (JU_FB_SKIP, developer only): 1 exchange, 2 K loop, 4 epilogue
 };
 
-template <typename T>
+// LEAKY: `activation: lrelu` generators (models.py:24-27): LeakyReLU in f32, two-sided e4m3
+// clamp, and -- e4m3 bytes of such tensors having no free sign bit -- halo slots that carry a
+// 16-bit epoch beside every two value bytes (twice the slots; tower_resident_kernel's LEAKY form)
+template <typename T, bool LEAKY = false>
 __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
@@ -168,12 +175,12 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			float v[16];
 #pragma unroll
 			for (int k = 0; k < 8; ++k) {
-				v[k] = fmaxf(static_cast<float>(a[k]), 0.0f);
-				v[8 + k] = fmaxf(static_cast<float>(b[k]), 0.0f);
+				v[k] = LEAKY ? static_cast<float>(a[k]) : fmaxf(static_cast<float>(a[k]), 0.0f);
+				v[8 + k] = LEAKY ? static_cast<float>(b[k]) : fmaxf(static_cast<float>(b[k]), 0.0f);
 			}
 			i32x4 o;
 #pragma unroll
-			for (int k = 0; k < 4; ++k) o[k] = t8Quantize4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], mul0);
+			for (int k = 0; k < 4; ++k) o[k] = t8Quantize4<LEAKY>(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3], mul0);
 			*reinterpret_cast<i32x4 *>(smem + kT8OffX + rr * kT8QRow + cc * 64 + ((c ^ ((cc >> 2) & 3)) << 4)) = o;
 		}
 	}
@@ -275,9 +282,13 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 							                    t8f32x2{static_cast<float>(rv[r][g][0]), static_cast<float>(rv[r][g][1])};
 							const t8f32x2 s23 = t8f32x2{acc[r][4 * g + 2], acc[r][4 * g + 3]} +
 							                    t8f32x2{static_cast<float>(rv[r][g][2]), static_cast<float>(rv[r][g][3])};
-							const float v[4] = {fmaxf(s01[0], 0.0f), fmaxf(s01[1], 0.0f), fmaxf(s23[0], 0.0f), fmaxf(s23[1], 0.0f)};
+							const float v[4] = {act8<LEAKY>(s01[0], p.slope), act8<LEAKY>(s01[1], p.slope), act8<LEAKY>(s23[0], p.slope),
+							    act8<LEAKY>(s23[1], p.slope)};
 							o16[g] = pack4<T>(v[0], v[1], v[2], v[3]);
-							o8[g] = t8Quantize4(v[0], v[1], v[2], v[3], mul);
+							o8[g] = t8Quantize4<LEAKY>(v[0], v[1], v[2], v[3], mul);
+						} else if constexpr (LEAKY) {
+							o8[g] = t8Quantize4<true>(act8<true>(acc[r][4 * g], p.slope), act8<true>(acc[r][4 * g + 1], p.slope),
+							    act8<true>(acc[r][4 * g + 2], p.slope), act8<true>(acc[r][4 * g + 3], p.slope), mul);
 						} else {
 							o8[g] = t8Quantize4(acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3], mul);
 						}
@@ -297,8 +308,12 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	};
 
 	// ---- edge ring -> mailbox, neighbours' mailboxes -> halo ring (64-byte records: 4 chunks) ----
+	// LEAKY: dword = 2 value bytes | epoch16 << 16, so a 16-byte slot carries 8 value bytes and a
+	// 64-byte record takes 8 slots instead of 4
+	constexpr int kSlots = LEAKY ? 2 * kT8MailSlots : kT8MailSlots;
+	constexpr int CPP = LEAKY ? 8 : 4, CSH = LEAKY ? 3 : 2;
 	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
-	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * kT8MailSlots * 16), 0x00020000);
+	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * kSlots * 16), 0x00020000);
 	constexpr int kSc1 = 16;
 	// 2-bit epoch (writes to the slot so far & 3) in the sign bits of every byte pair: each
 	// dword carries it twice (bits 7, 23 = e & 1; bits 15, 31 = e >> 1)
@@ -308,17 +323,19 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	};
 	// slot descriptors, computed once (tower_kernels.hip): the buffer enters as the LDS
 	// instructions' immediate offset, the slot parity as the buffer instructions' scalar offset
-	auto chunkOff = [&](int rr, int cc, int c) -> unsigned {
-		return (unsigned)(rr * kT8QRow + cc * 64 + ((c ^ ((cc >> 2) & 3)) << 4));
+	// (cs: slot index inside the pixel record; LEAKY: chunk cs >> 1, 8-byte half cs & 1)
+	auto chunkOff = [&](int rr, int cc, int cs) -> unsigned {
+		const int c = LEAKY ? cs >> 1 : cs;
+		return (unsigned)(rr * kT8QRow + cc * 64 + ((c ^ ((cc >> 2) & 3)) << 4) + (LEAKY ? (cs & 1) * 8 : 0));
 	};
-	constexpr int NP = kT8MailSlots / 256;  // 4 strips x 32 entries x 4 chunks
-	constexpr int NS = NP + 1;              // 4 sides x 32 entries x 4 chunks, + the 4 corners
+	constexpr int NP = kSlots / 256;  // 4 strips x 32 entries x CPP slots
+	constexpr int NS = NP + 1;        // 4 sides x 32 entries x CPP slots, + the 4 corners
 	unsigned pubLds[NP];
 	unsigned pubValid = 0;
 #pragma unroll
 	for (int it = 0; it < NP; ++it) {
 		const int idx = it * 256 + tid;
-		const int strip = idx >> 7, e = (idx >> 2) & 31, c = idx & 3;
+		const int strip = idx >> (5 + CSH), e = (idx >> CSH) & 31, c = idx & (CPP - 1);
 		int rr, cc;
 		bool valid;
 		if (strip == 0) { rr = 1; cc = e + 1; valid = e < rwv; }
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		pubLds[it] = chunkOff(rr, cc, c);
 		if (valid) pubValid |= 1u << it;
 	}
-	const unsigned pubBase = (unsigned)(region * 2 * kT8MailSlots) * 16u + (unsigned)tid * 16u;
+	const unsigned pubBase = (unsigned)(region * 2 * kSlots) * 16u + (unsigned)tid * 16u;
 	unsigned sweepSrc[NS], sweepLds[NS];
 	unsigned sweepValid = 0;
 #pragma unroll
@@ -337,8 +354,8 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		bool valid;
 		if (it < NS - 1) {
 			const int idx = it * 256 + tid;
-			const int hp = idx >> 2;
-			c = idx & 3;
+			const int hp = idx >> CSH;
+			c = idx & (CPP - 1);
 			const int side = hp >> 5, e = hp & 31;
 			if (side < 2) {  // row above / below: their bottom / top row strip
 				ny += side == 0 ? -1 : 1;
@@ -355,9 +372,9 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 				cc = side == 2 ? 0 : rwv + 1;
 				valid = e < rhv;
 			}
-		} else {  // corners: threads 0..15 = 4 corners x 4 chunks, from the diagonal neighbour's row strips
-			const int k = tid >> 2;
-			c = tid & 3;
+		} else {  // corners: threads 0 .. 4 CPP - 1 = 4 corners x CPP slots, from the diagonal neighbour's row strips
+			const int k = tid >> CSH;
+			c = tid & (CPP - 1);
 			const bool up = k < 2, left = (k & 1) == 0;
 			ny += up ? -1 : 1;
 			nx += left ? -1 : 1;
@@ -365,28 +382,44 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			se = left ? kT8RW - 1 : 0;
 			rr = up ? 0 : rhv + 1;
 			cc = left ? 0 : rwv + 1;
-			valid = tid < 16;
+			valid = tid < 4 * CPP;
 		}
 		valid = valid && nx >= 0 && nx < p.GX && ny >= 0 && ny < p.GY;
 		const int nreg = valid ? ny * p.GX + nx : region;
-		sweepSrc[it] = (unsigned)((nreg * 2) * kT8MailSlots + (strip * 32 + se) * 4 + c) * 16u;
+		sweepSrc[it] = (unsigned)((nreg * 2) * kSlots + (strip * 32 + se) * CPP + c) * 16u;
 		sweepLds[it] = chunkOff(rr, cc, c);
 		if (valid) sweepValid |= 1u << it;
 	}
-	constexpr unsigned kParityBytes = kT8MailSlots * 16u;
+	constexpr unsigned kParityBytes = kSlots * 16u;
 	auto publish = [&](auto offTag, int layer) {
 		constexpr int off = decltype(offTag)::value;
 		const int ppar = (layer + 1) & 1;
 		pubCount[ppar] += 1u;
-		const unsigned tm = epochMask(ppar);
 		const unsigned soff = ppar ? kParityBytes : 0u;
-		u32x4w v[NP];
+		if constexpr (LEAKY) {
+			typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+			const unsigned tg = pubCount[ppar] << 16;
+			u32x2w v[NP];
 #pragma unroll
-		for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4w *>(smem + off + pubLds[it]);
+			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x2w *>(smem + off + pubLds[it]);
 #pragma unroll
-		for (int it = 0; it < NP; ++it) {
-			if (pubValid >> it & 1u) {
-				__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7f7f7f7fu) | tm, mailRsrc, pubBase + it * 4096, soff, kSc1);
+			for (int it = 0; it < NP; ++it) {
+				if (pubValid >> it & 1u) {
+					const u32x4w d = {(v[it][0] & 0xffffu) | tg, (v[it][0] >> 16) | tg, (v[it][1] & 0xffffu) | tg,
+					    (v[it][1] >> 16) | tg};
+					__builtin_amdgcn_raw_buffer_store_b128(d, mailRsrc, pubBase + it * 4096, soff, kSc1);
+				}
+			}
+		} else {
+			const unsigned tm = epochMask(ppar);
+			u32x4w v[NP];
+#pragma unroll
+			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4w *>(smem + off + pubLds[it]);
+#pragma unroll
+			for (int it = 0; it < NP; ++it) {
+				if (pubValid >> it & 1u) {
+					__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7f7f7f7fu) | tm, mailRsrc, pubBase + it * 4096, soff, kSc1);
+				}
 			}
 		}
 	};
@@ -394,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		constexpr int off = decltype(offTag)::value;
 		u64 t0 = 0;  // (the clock is read only once a pass has failed: a scalar-memory round trip)
 		const int par = (layer + 1) & 1;
-		const unsigned tm = epochMask(par);
+		const unsigned tm = LEAKY ? (pubCount[par] & 0xffffu) : epochMask(par);
 		const unsigned soff = par ? kParityBytes : 0u;
 		unsigned pending = sweepValid;
 		while (__any(pending != 0)) {
@@ -403,11 +436,22 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			for (int it = 0; it < NS; ++it) hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, sweepSrc[it], soff, kSc1);
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
-				const u32x4w tg = hv[it] & 0x80808080u;
-				const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
-				if ((pending >> it & 1u) && ok) {
-					*reinterpret_cast<u32x4w *>(smem + off + sweepLds[it]) = hv[it] & 0x7f7f7f7fu;
-					pending &= ~(1u << it);
+				if constexpr (LEAKY) {
+					typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+					const u32x4w tg = hv[it] >> 16;
+					const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
+					if ((pending >> it & 1u) && ok) {
+						*reinterpret_cast<u32x2w *>(smem + off + sweepLds[it]) =
+						    u32x2w{(hv[it][0] & 0xffffu) | (hv[it][1] << 16), (hv[it][2] & 0xffffu) | (hv[it][3] << 16)};
+						pending &= ~(1u << it);
+					}
+				} else {
+					const u32x4w tg = hv[it] & 0x80808080u;
+					const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
+					if ((pending >> it & 1u) && ok) {
+						*reinterpret_cast<u32x4w *>(smem + off + sweepLds[it]) = hv[it] & 0x7f7f7f7fu;
+						pending &= ~(1u << it);
+					}
 				}
 			}
 			if (pending != 0) {
@@ -485,9 +529,9 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	}
 }
 
-template <typename T>
+template <typename T, bool LEAKY>
 void launchTower8T(const Tower8Params &p, hipStream_t stream) {
-	auto kern = tower8_resident_kernel<T>;
+	auto kern = tower8_resident_kernel<T, LEAKY>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), kT8Lds, &ldsDone, "fp8 resident tower");
 	const int grid = p.GX * p.GY - (p.fault < p.GX * p.GY ? p.fault : 0);
@@ -497,8 +541,8 @@ void launchTower8T(const Tower8Params &p, hipStream_t stream) {
 
 }  // namespace
 
-std::size_t residentMailboxBytes8(int GX, int GY) {
-	return static_cast<std::size_t>(GX) * GY * 2 * kT8MailSlots * 16;
+std::size_t residentMailboxBytes8(int GX, int GY, bool leaky) {
+	return static_cast<std::size_t>(GX) * GY * 2 * kT8MailSlots * 16 * (leaky ? 2 : 1);
 }
 
 void launchResidentTower8(DType dt, const ResidentTower8Params &q, hipStream_t stream) {
@@ -520,11 +564,17 @@ void launchResidentTower8(DType dt, const ResidentTower8Params &q, hipStream_t s
 	p.GY = q.GY;
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
+	p.slope = q.slope;
 	p.fault = residentFaultForTests();
 	p.skip = ablationSkipBits();
 	if (p.nLayers < 2 || (p.nLayers & 1)) throw std::invalid_argument("fp8 resident tower: layer count must be 2 x blocks");
-	if (dt == kF16) launchTower8T<f16>(p, stream);
-	else launchTower8T<bf16>(p, stream);
+	if (q.leaky) {
+		if (dt == kF16) launchTower8T<f16, true>(p, stream);
+		else launchTower8T<bf16, true>(p, stream);
+		return;
+	}
+	if (dt == kF16) launchTower8T<f16, false>(p, stream);
+	else launchTower8T<bf16, false>(p, stream);
 }
 
 }  // namespace ju

@@ -438,7 +438,10 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 template <typename T, int VARIANT, bool HEAD, bool TAIL = false, bool LEAKY = false>
 __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr bool xchg = !(VARIANT & 1);
+	// (variants 1 .. 3 are bit masks; 4, 5, 8 are NOT -- round 2 tested `VARIANT & 1` and ran the
+	// calibration build, variant 5, without the halo exchange: its maxima drifted by up to 10 %)
+	constexpr bool kNoMfma = VARIANT == 2 || VARIANT == 3;
+	constexpr bool xchg = !(VARIANT == 1 || VARIANT == 3);
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6;
 	const int lane = tid & 63;
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		return v < np2 ? v : -1;
 	};
 	const int firstWhole = isPre(rp) ? (preEnd < np2 ? preEnd : -1) : (rp < np2 ? rp : -1);
-	const bool streamsInUnit = (firstWhole >= 0 || mySingle) && !(VARIANT & 2) && !kPlain;  // the next layer's weights stream behind the last unit
+	const bool streamsInUnit = (firstWhole >= 0 || mySingle) && !kNoMfma && !kPlain;  // the next layer's weights stream behind the last unit
 
 	// KIND 0: pre-run (accumulator init + positions 0..3); 1: finish (positions 4..11 +
 	// epilogue); 2: whole unit.  `primed`: the first step's fragments are already in flight
@@ -659,12 +662,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		constexpr int NR = ROWS + 2;      // input rows / fragment reads per macro-step
 		constexpr int NM = 3 * ROWS;      // MFMAs per macro-step
 		const int ra = 1 + 2 * unit;      // first output row (buffer row index)
-		if constexpr (KIND != 1 && (VARIANT & 2)) {
+		if constexpr (KIND != 1 && kNoMfma) {
 #pragma unroll
 			for (int r = 0; r < ROWS; ++r) acc[r] = biasVec;
 		}
 		const unsigned rowAddr = ldsBase + inOff + (2 * unit) * kResRowBytes;
-		if (!(VARIANT & 2)) {
+		if (!kNoMfma) {
 			if (!primed) {
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				__builtin_amdgcn_sched_barrier(0);
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			if (k < nPre) {
 				const int nu = (k + 1 < nPre) ? preFirst + 2 * (k + 1) : -1;
 				unitSeg(R2{}, KPre{}, std::false_type{}, inTag, outTag, acc, layer, preFirst + 2 * k,
-				    (k > 0 || primedFirst) && !(VARIANT & 2), nu, false, std::false_type{});
+				    (k > 0 || primedFirst) && !kNoMfma, nu, false, std::false_type{});
 			}
 		};
 		if constexpr (LO <= 0 && 0 < HI) slot(accPre0, 0);
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			if (k < nPre) {
 				const bool nextIsPre = k + 1 < nPre;
 				const int nu = nextIsPre ? preFirst + 2 * (k + 1) : afterPre;
-				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, acc, layer, preFirst + 2 * k, k > 0 && !(VARIANT & 2), nu, nextIsPre,
+				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, acc, layer, preFirst + 2 * k, k > 0 && !kNoMfma, nu, nextIsPre,
 				    std::false_type{});
 			}
 		};
@@ -829,14 +832,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		if constexpr (kPreRun > 1) slot(accPre1, 1);
 		if constexpr (kPreRun > 2) slot(accPre2, 2);
 		// (every finish segment primes its successor when there is one)
-		bool primed = nPre > 0 && afterPre >= 0 && !(VARIANT & 2);
+		bool primed = nPre > 0 && afterPre >= 0 && !kNoMfma;
 		f32x16 acc[2];
 		for (int u = firstWhole; u >= 0;) {
 			const int nw = nextWhole(u);
 			const int nu = nw >= 0 ? nw : (mySingle ? np2 : -1);
 			if (streamW && nu < 0) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, std::true_type{});
 			else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, std::false_type{});
-			primed = nu >= 0 && !(VARIANT & 2);
+			primed = nu >= 0 && !kNoMfma;
 			u = nw;
 		}
 		if (mySingle) {
@@ -1081,7 +1084,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		if (more && xchg) publish(OutT{}, i);
 		// the pre-run's first fragments (interior rows of this layer's output) travel
 		// while the weight stream is issued
-		const bool primePre = more && nPre > 0 && !(VARIANT & 2);
+		const bool primePre = more && nPre > 0 && !kNoMfma;
 		if (primePre) {
 			const unsigned na = ldsBase + OutT::value + (2 * preFirst) * kResRowBytes;
 #pragma unroll

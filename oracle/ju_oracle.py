@@ -370,17 +370,19 @@ def fp8_quantize_weights(k: np.ndarray) -> np.ndarray:
 
 
 def fp8_quantize_activation(x: np.ndarray, exponent: int) -> np.ndarray:
-    return e4m3_round(np.minimum(x * 2.0 ** exponent, 448.0)) * 2.0 ** -exponent
+    """e4m3(clamp(x * 2^e, +-448)) * 2^-e.  Post-ReLU tensors only use the upper clamp; a
+    LeakyReLU tensor (`activation: lrelu`) has negative values too."""
+    return e4m3_round(np.clip(x * 2.0 ** exponent, -448.0, 448.0)) * 2.0 ** -exponent
 
 
-def res_block_fp8(x, wts: Weights, name: str, eps: float, ex: int, et: int) -> np.ndarray:
-    """res_block with both convolutions on e4m3 operands; bias, ReLU and the skip
+def res_block_fp8(x, wts: Weights, name: str, eps: float, ex: int, et: int, act=relu) -> np.ndarray:
+    """res_block with both convolutions on e4m3 operands; bias, activation and the skip
     connection in full precision (the stream ``x`` itself is never quantised)."""
     k1, b1 = _fold_bn(wts, name + "/conv_1", name + "/bn_1", eps)
     k2, b2 = _fold_bn(wts, name + "/conv_2", name + "/bn_2", eps)
-    t = relu(conv2d_same(fp8_quantize_activation(x, ex), fp8_quantize_weights(k1)) + b1)
+    t = act(conv2d_same(fp8_quantize_activation(x, ex), fp8_quantize_weights(k1)) + b1)
     y = conv2d_same(fp8_quantize_activation(t, et), fp8_quantize_weights(k2)) + b2
-    return relu(y + x)
+    return act(y + x)
 
 
 def flow_autoencoder(frames: Sequence[np.ndarray], wts: Weights,
@@ -435,26 +437,24 @@ def generator(images: np.ndarray, pre_warp: np.ndarray, wts: Weights,
     """``get_generator_resnet`` (models.py:484-595)."""
     eps = cfg.bn_eps
     act = cfg.act("generator")
-    if cfg.fp8_tower and cfg.gen_activation != "relu":
-        raise ValueError("the 8-bit tower scheme is defined for ReLU generators only")
     x = np.concatenate([images, space_to_depth(pre_warp, 4)], axis=2)  # :523-530
     _rec(trace, "gen_in_ref", x)  # reference channel order, 51 channels
     x = _conv_bn_act(x, wts, "generator/conv_1", "generator/bn_1", eps, act)
     _rec(trace, "gen_head", x)
     # max |output| of generator/conv_1 and of the two activations of every residual block, in
     # execution order: the tensors an activation calibration ranges over
-    amax = [float(np.abs(x).max())] if trace is not None and not cfg.fp8_tower else None
+    layer_amax = [float(np.abs(x).max())] if trace is not None and not cfg.fp8_tower else None
     if cfg.fp8_tower:
         amax = wts.get("generator/fp8_amax")
         exps = [fp8_activation_exponent(FP8_DEFAULT_AMAX if amax is None else float(np.float32(amax[j])))
                 for j in range(2 * cfg.gen_blocks)]
     for i in range(cfg.gen_blocks):
         if cfg.fp8_tower:
-            x = res_block_fp8(x, wts, f"generator/block_{i + 1}", eps, exps[2 * i], exps[2 * i + 1])
+            x = res_block_fp8(x, wts, f"generator/block_{i + 1}", eps, exps[2 * i], exps[2 * i + 1], act)
         else:
-            x = res_block(x, wts, f"generator/block_{i + 1}", eps, act, amax)
-    if amax is not None:
-        trace["tower_amax"] = np.asarray(amax)
+            x = res_block(x, wts, f"generator/block_{i + 1}", eps, act, layer_amax)
+    if layer_amax is not None:
+        trace["tower_amax"] = np.asarray(layer_amax)
     _rec(trace, "trunk", x)
     x = conv2d_transpose_k2s2(x, wts["generator/conv_trans_1/kernel"])
     b = "generator/bn_2"

@@ -62,7 +62,7 @@ def crops_for(h: int, w: int):
 
 
 # the 8-bit tower (BASELINE.json config 5) at the sizes it is quoted on: same clip, same crops
-FULL_FP8 = {"psp-quality": ("full_psp_quality_fp8", 2), "ps2-quality": ("full_ps2_quality_fp8", 2)}
+FULL_FP8 = {"psp-quality": ("full_psp_quality_fp8", 3), "ps2-quality": ("full_ps2_quality_fp8", 2)}  # (frame counts of the float fixtures: the smooth clip depends on it)
 
 
 def full(preset: str = "psp-quality", fp8_tower: bool = False) -> None:

@@ -84,6 +84,28 @@ def test_full_size_goldens_were_generated_twice_and_agree(preset):
     assert all(0 <= y <= H - 64 and 0 <= x <= W - 64 for y, x in g["crops"])
 
 
+FULL_FP8 = {"psp-quality": "full_psp_quality_fp8", "ps2-quality": "full_ps2_quality_fp8"}
+
+
+@pytest.mark.parametrize("preset", sorted(FULL_FP8))
+def test_full_size_8bit_goldens_were_generated_twice_and_agree(preset):
+    """The 8-bit tower (BASELINE.json config 5) at the sizes it is quoted on, 480x270 and
+    640x448: whole-frame digests of the numpy oracle's restatement of the scheme and of the
+    PyTorch one (its own float8_e4m3fn rounding) agree byte for byte; same clip and crops as
+    the float fixtures, and it IS a different model (the crops differ from the float ones)."""
+    g = load(FULL_FP8[preset])
+    gf = load(FULL[preset])
+    n = int(g["n_frames"])
+    assert n == int(gf["n_frames"]) and str(g["model_sha256"]) == str(gf["model_sha256"])
+    assert str(g["frames_sha256"]) == str(gf["frames_sha256"])       # the SAME clip as the float fixture
+    assert [str(x) for x in g["out_sha256_numpy"]] == [str(x) for x in g["out_sha256_torch"]]
+    assert not g["bytes_differing"].any() and g["raw_max_diff"].max() < 1e-9
+    assert np.array_equal(g["crops"], gf["crops"]) and int(g["seed"]) == int(gf["seed"])
+    d = g["crops_u8"].astype(int) - gf["crops_u8"][:n].astype(int)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean(d.astype(float) ** 2))
+    assert 40.0 < psnr < 60.0, psnr          # quantisation noise of 48 e4m3 convolutions, not a broken model
+
+
 @pytest.mark.parametrize("preset", ["psp-quality", "psp-fast"])
 def test_c_restatement_matches_full_size_golden_first_frame(preset):
     """One 480x270 frame of the BASELINE.json configurations (a few seconds each)."""

@@ -54,6 +54,15 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
     assert res["config"]["submission"]["prepared_captures"] == 32 and res["config"]["submission"]["inline_captures"] == 0
     assert len(res["config"]["per_rank_fps"]["values"]) == 1
     assert "how" in res["config"]["affinity"] and res["config"]["model_broadcast"]["seconds"] > 0
+    # N = 1 under the launcher measures what a bare N = 1 run measures (the driver computes
+    # scaling efficiency from the per-N values: the launcher itself must not cost frames)
+    bare = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                           "--no-cpu-baseline", "--preset", "psp-fast", "--dtype", "fp16"],
+                          capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert bare.returncode == 0, bare.stderr[-2000:]
+    res1 = json.loads([ln for ln in bare.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res1["config"]["timed_region"] == {"replays": 20, "eager": 0, "captures": 0}
+    assert abs(res["value"] / res1["value"] - 1.0) < 0.06, (res["value"], res1["value"])
     # launched the wrong way, the bench refuses instead of measuring one GPU
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT)

@@ -740,6 +740,19 @@ def test_fp8_tower_matches_its_oracle(h, w, blocks):
     _fp8_case(cfg, M.make_seeded_weights(cfg), M.synthetic_frames(3, h, w, seed=5, kind="smooth"))
 
 
+@pytest.mark.parametrize("h,w,blocks,mode", [(30, 48, 3, "resident"), (34, 50, 2, "resident"), (64, 96, 5, "layers"),
+                                             (40, 70, 4, "convs")])
+def test_fp8_tower_of_a_leaky_generator_matches_its_oracle(h, w, blocks, mode, monkeypatch):
+    """`activation: lrelu` generators on the 8-bit tower (round 2 rejected them): LeakyReLU in
+    f32, e4m3 clamped on both sides, halo slots with the epoch beside the values -- against the
+    oracle's restatement of the same scheme, in each of the three forms."""
+    if mode != "resident":
+        monkeypatch.setenv("JU_TOWER", mode)
+    cfg = small_config(frame_height=h, frame_width=w, gen_blocks=blocks, gen_activation="lrelu",
+                       gen_negative_slope=0.2, flow_activation="lrelu")
+    _fp8_case(cfg, M.make_seeded_weights(cfg), M.synthetic_frames(3, h, w, seed=5, kind="smooth"))
+
+
 def test_fp8_tower_multi_round_tiles():
     """More 8x32 tiles than resident workgroups (2 per CU): full rounds in XCD order plus
     the spread-out remainder round, at about the benchmark's pixel count."""
@@ -778,9 +791,9 @@ def test_calibration_producer_matches_the_oracle_layer_maxima(h, w, blocks, extr
       * from the engine's calibration mode (JU_CALIBRATE=1: per-conv launches + abs-max), and
       * from the resident tower's in-kernel maxima (tower_variant 5, bf16),
     against the oracle's per-layer post-activation maxima (trace["tower_amax"]) within the
-    16-bit tolerance: a maximum is ONE value of a tensor that went through up to 7 16-bit layers
-    and 3 recurrent frames, so it moves by a few units of the last place (measured: bf16 up to
-    3.7 %, fp16 0.3 %); what consumes it is a power-of-two scale with one bit of headroom."""
+    16-bit tolerance (measured: bf16 0.5 %, fp16 0.08 %; bounds 2 % / 0.4 %).  This test found
+    that round 2's resident calibration build ran WITHOUT the halo exchange (variant 5 was
+    matched by a `VARIANT & 1` ablation test): its maxima were off by up to 10 %."""
     cfg = small_config(frame_height=h, frame_width=w, gen_blocks=blocks, **extra)
     wts = M.make_seeded_weights(cfg)
     blob = M.serialize(cfg, wts)
@@ -824,7 +837,7 @@ def test_calibration_producer_matches_the_oracle_layer_maxima(h, w, blocks, extr
         assert want.shape == (n_layers,) and (want > 0).all()
         for key, vals in got.items():
             rel = np.abs(vals[t] - want) / want
-            tol = 0.06 if key[1] == R.DTYPE_BF16 else 0.008
+            tol = 0.02 if key[1] == R.DTYPE_BF16 else 0.004
             record(("calibration", key[0], h, w, sorted(extra), t), key[1], {"rel_max": float(rel.max())})
             assert rel.max() <= tol, (key, t, rel)
 
@@ -919,9 +932,13 @@ def test_fp8_resident_block_and_per_conv_kernels_give_the_same_bytes(monkeypatch
     (JU_TOWER=convs).  Per output element all three execute the same instruction sequence,
     so the bytes are equal -- at a ragged small size, at the benchmark size, and at the PS2
     size (no resident form there: several tiles per CU)."""
+    leaky = dict(gen_activation="lrelu", gen_negative_slope=0.2)
     for cfg, n, resident in [(small_config(frame_height=34, frame_width=70, gen_blocks=3), 3, True),
                              (small_config(frame_height=30, frame_width=48, gen_blocks=1), 2, True),
-                             (M.PRESETS["psp-quality"], 2, True), (M.PRESETS["ps2-quality"], 2, False)]:
+                             (M.PRESETS["psp-quality"], 2, True), (M.PRESETS["ps2-quality"], 2, False),
+                             # `activation: lrelu`: the LEAKY instantiations of all three forms
+                             (small_config(frame_height=34, frame_width=70, gen_blocks=3, **leaky), 3, True),
+                             (M.PRESETS["psp-quality-lrelu"], 2, True)]:
         blob = M.serialize(cfg, M.make_seeded_weights(cfg))
         frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=1234, kind="noise")
         runs = {}
@@ -943,6 +960,58 @@ def test_fp8_resident_block_and_per_conv_kernels_give_the_same_bytes(monkeypatch
             assert np.array_equal(runs[mode][1], runs["convs"][1]), mode
             for x, y in zip(runs[mode][0], runs["convs"][0]):
                 assert np.array_equal(x, y), mode
+
+
+FULL_FP8 = {"psp-quality": ("full_psp_quality_fp8", "full_psp_quality"),
+            "ps2-quality": ("full_ps2_quality_fp8", "full_ps2_quality")}
+
+
+@pytest.mark.parametrize("preset", sorted(FULL_FP8))
+def test_fp8_full_size_against_the_8bit_oracle_and_the_bf16_engine(preset):
+    """BASELINE.json config 5 at ITS sizes (480x270: resident 8-bit tower; 640x448: one launch
+    per block), not only at the small geometries the float64 oracle steps through in seconds:
+      * against the committed crops of the 8-bit oracle (generated twice, tests/test_golden.py)
+        the same three relations as _fp8_case: the engine is as far from the float oracle as the
+        8-bit oracle is, and closer to the 8-bit oracle than that is to the float one -- it
+        reproduces THE quantisation, not merely a similar amount of noise;
+      * "PSNR-vs-bf16 reported": the 8-bit engine against the bf16 engine on the same frames, on
+        the golden (smooth) clip and on the benchmark's noise clip, held 1 dB under the measured
+        values (profiles/r02_quality_*.json: smooth 47.2-47.3 dB, max 7-8 LSB; noise 45.3 dB,
+        max 9-10 LSB) -- a quantiser regression of a decibel or a single wild byte fails."""
+    name8, namef = FULL_FP8[preset]
+    g8, gf = np.load(os.path.join(GOLD, name8 + ".npz")), np.load(os.path.join(GOLD, namef + ".npz"))
+    cfg = M.PRESETS[preset]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    assert hashlib.sha256(blob).hexdigest() == str(g8["model_sha256"])
+    n = int(g8["n_frames"])
+    smooth = M.synthetic_frames(n, h, w, seed=int(g8["seed"]), kind="smooth")
+    assert hashlib.sha256(smooth.tobytes()).hexdigest() == str(g8["frames_sha256"])
+    noise = M.synthetic_frames(16, h, w, seed=1234, kind="noise")[:3]
+    outs = {}
+    for name, dt in (("fp8", R.DTYPE_FP8), ("bf16", R.DTYPE_BF16)):
+        rt = R.Runtime(blob, 0, dt)
+        if name == "fp8":
+            assert rt.dtype == R.DTYPE_FP8 and rt.stat("resident_tower") == (1 if preset == "psp-quality" else 0)
+        outs[name, "smooth"] = [rt.process_image(f).copy() for f in smooth]
+        rt.reset()
+        outs[name, "noise"] = [rt.process_image(f).copy() for f in noise]
+        rt.close()
+
+    def crops(img):
+        return np.stack([img[y:y + 64, x:x + 64, :3] for y, x in g8["crops"]])
+    for t in range(n):
+        eng, o8, of = crops(outs["fp8", "smooth"][t]), g8["crops_u8"][t], gf["crops_u8"][t]
+        p_eng_f, p_orc_f, p_eng_orc = _psnr(eng, of), _psnr(o8, of), _psnr(eng, o8)
+        record(("fp8-full-crops", preset, t), R.DTYPE_FP8, {"eng_float": p_eng_f, "orc_float": p_orc_f, "eng_orc": p_eng_orc})
+        assert abs(p_eng_f - p_orc_f) <= 0.5, (t, p_eng_f, p_orc_f)
+        assert p_eng_orc >= p_orc_f + 0.5, (t, p_eng_orc, p_orc_f)
+        assert np.abs(eng.astype(int) - o8.astype(int)).max() <= 8, t
+    for kind, floor, cap in (("smooth", 46.1, 10), ("noise", 44.2, 13)):
+        for t, (a, b) in enumerate(zip(outs["fp8", kind], outs["bf16", kind])):
+            st = u8_stats(a, b)
+            record(("fp8-vs-bf16-engine", preset, kind, t), R.DTYPE_FP8, st)
+            assert st["psnr"] >= floor and st["max"] <= cap, (kind, t, st)
 
 
 def test_fp8_rejects_a_calibration_tensor_of_the_wrong_length():

@@ -35,10 +35,11 @@ def test_numpy_oracle_vs_torch_restatement_8bit_tower():
     rounding against PyTorch's own float8_e4m3fn conversion, scales derived independently.
     Both fold BatchNorm the way the loader does (float64, one rounding to float32), so the
     discontinuous quantiser sees identical inputs and the frames are EQUAL."""
-    cfg = small_config(gen_blocks=4)
-    wts = M.make_seeded_weights(cfg)
     amax = np.linspace(0.8, 9.0, 8).astype(np.float32)          # a calibration tensor too
-    for extra in ({}, {"generator/fp8_amax": amax}):
+    for extra, leaky in (({}, {}), ({"generator/fp8_amax": amax}, {}),
+                         ({}, dict(gen_activation="lrelu", gen_negative_slope=0.2))):   # + a LeakyReLU generator
+        cfg = small_config(gen_blocks=4, **leaky)
+        wts = M.make_seeded_weights(cfg)
         w = dict(wts, **extra)
         s = O.Session(w, oracle_config(cfg, fp8_tower=True))
         ts = TorchSession(w, oracle_config(cfg, fp8_tower=True))

@@ -94,7 +94,7 @@ def _q_weights(k):
 
 
 def _q_act(x, e):
-    return _e4m3(torch.minimum(x * 2.0 ** e, torch.tensor(448.0, dtype=DT))) * 2.0 ** -e
+    return _e4m3(x * 2.0 ** e) * 2.0 ** -e      # (_e4m3 clamps to +-448)
 
 
 def _act_exponent(amax):
@@ -103,12 +103,12 @@ def _act_exponent(amax):
     return int(min(max(np.floor(np.log2(224.0 / amax)), -16), 16))
 
 
-def _res_fp8(x, w, n, eps, ex, et):
+def _res_fp8(x, w, n, eps, ex, et, act=F.relu):
     k1, b1 = _fold32(w, n + "/conv_1", n + "/bn_1", eps)
     k2, b2 = _fold32(w, n + "/conv_2", n + "/bn_2", eps)
-    t = F.relu(F.conv2d(_q_act(x, ex), _q_weights(k1), b1.to(DT), padding=1))
+    t = act(F.conv2d(_q_act(x, ex), _q_weights(k1), b1.to(DT), padding=1))
     y = F.conv2d(_q_act(t, et), _q_weights(k2), b2.to(DT), padding=1)
-    return F.relu(y + x)
+    return act(y + x)
 
 
 def _up_tf1(x, s):
@@ -208,7 +208,7 @@ class TorchSession:
                     for j in range(2 * cfg.gen_blocks)]
         for i in range(cfg.gen_blocks):
             if fp8:
-                x = _res_fp8(x, w, f"generator/block_{i + 1}", eps, exps[2 * i], exps[2 * i + 1])
+                x = _res_fp8(x, w, f"generator/block_{i + 1}", eps, exps[2 * i], exps[2 * i + 1], act)
             else:
                 x = _res(x, w, f"generator/block_{i + 1}", eps, act)
         k1 = _t(w["generator/conv_trans_1/kernel"]).permute(3, 2, 0, 1)
