@@ -314,10 +314,15 @@ void Engine::buildProgram(int set) {
 		prog.push_back({"pack", 0.0,
 		    [=](hipStream_t s) { launchFrameSums(io->in, io->inStride, H, W, sumsOut, s); }});
 	}
-	prog.push_back({"pack", 0.0, [=](hipStream_t s) {
-		                launchPackFrames(dt, io->in, io->inStride, packedIn, packedOut, H, W, PH, PW,
-		                    padTop, padLeft, nIn, sums, s);
-	                }});
+	// (the flow net's first block builds the packed tensor itself when it runs as one launch)
+	const bool packInBlock = m_PackInBlock && c.flowArch == 0 && !m_FlowUnits.empty() && m_FlowUnits[0].fused &&
+	                         3 * nIn <= 16 && !c.flowFilters.empty() && c.flowFilters[0] == 32;
+	if (!packInBlock) {
+		prog.push_back({"pack", 0.0, [=](hipStream_t s) {
+			                launchPackFrames(dt, io->in, io->inStride, packedIn, packedOut, H, W, PH, PW,
+			                    padTop, padLeft, nIn, sums, s);
+		                }});
+	}
 	// one launch for a 64-filter residual block outside the resident tower
 	auto addResBlockStep = [&](const std::string &tag, const std::string &block, Operand in, Operand out,
 	                           int bh, int bw, int act, float slope) {
@@ -377,8 +382,25 @@ void Engine::buildProgram(int set) {
 			fb.act1 = flowAct;
 			fb.act2 = act2;
 			fb.slope = c.flowNegativeSlope;
-			prog.push_back({"flow", 2.0 * bh * bw * 9.0 * (double(wa.cinReal) * wa.cout + double(wb.cinReal) * wb.cout),
-			    [dt, fb](hipStream_t s) { launchFlowBlock(dt, fb, s); }});
+			const double flops = 2.0 * bh * bw * 9.0 * (double(wa.cinReal) * wa.cout + double(wb.cinReal) * wb.cout);
+			if (packInBlock && convA == "flow/block_1/conv_1") {
+				fb.packPrev = packedIn;
+				fb.packOut = packedOut;
+				fb.frameH = H;
+				fb.frameW = W;
+				fb.padTop = padTop;
+				fb.padLeft = padLeft;
+				fb.numInputs = nIn;
+				fb.sums = sums;
+				prog.push_back({"flow", flops, [dt, fb, io](hipStream_t s) {
+					                FlowBlockLaunch f = fb;  // the caller's frame is known at launch time only
+					                f.packFrame = io->in;
+					                f.packFrameStride = io->inStride;
+					                launchFlowBlock(dt, f, s);
+				                }});
+				return;
+			}
+			prog.push_back({"flow", flops, [dt, fb](hipStream_t s) { launchFlowBlock(dt, fb, s); }});
 		};
 		auto unitUpsIn = [&](int k) { return k < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[k].fused && m_FlowUnits[k].upsIn; };
 		bool upsampleNext = false;  // `cur` is half resolution: the next conv upsamples it
@@ -773,6 +795,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	// carries the tail's HBM-bound work (its MFMA fraction reads 1.5 points lower), so
 	// the separate launch stays the default.
 	m_TailInTower = tailMode && std::string(tailMode) == "tower";
+	const char *packMode = std::getenv("JU_PACK");
+	m_PackInBlock = !(packMode && std::string(packMode) == "split");  // JU_PACK=split: pack_frames_kernel as its own launch
 	const char *poolMode = std::getenv("JU_POOL");
 	m_FusedPool = !(poolMode && std::string(poolMode) == "split");
 	const char *upMode = std::getenv("JU_UPSAMPLE");

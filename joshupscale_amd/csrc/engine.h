@@ -200,6 +200,7 @@ private:
 	bool flowConvIsFused(const std::string &name) const;
 	bool m_FusedUpsample = true;  // flow decoder: bilinear x2 folded into the next conv's staging
 	bool m_FusedPool = true;  // max-pool folded into the flow encoder's conv epilogues
+	bool m_PackInBlock = true;  // the flow net's first block builds the packed input itself (JU_PACK=split: own launch)
 	bool m_FusedTail = true;  // JU_TAIL=split: convT1 as a conv launch + the VALU tail kernel
 	bool m_TailInTower = false;  // JU_TAIL=tower: the fused tail runs inside the resident tower launch
 	DeviceBuffer m_InStage, m_OutStage, m_RawStage;

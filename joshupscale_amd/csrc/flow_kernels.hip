@@ -140,6 +140,15 @@ struct FlowBlockParams {
 	int act1, act2;   // 0 none, 1 ReLU, 2 LeakyReLU(slope)
 	float slope;
 	int skip;         // timing ablation (JU_FB_SKIP, developer only): 1 staging/expansion, 2 conv A, 4 conv B, 8 stores
+	// PACK instantiation (the flow net's first block): the 16-channel input records are built
+	// here from the u8 frame and the previous packed tensor (launchPackFrames' arithmetic) and
+	// written to `packOut` by the tile that owns the pixel; `in` is unused
+	const std::uint8_t *frame;
+	std::ptrdiff_t frameStride;
+	const void *packPrev;
+	void *packOut;
+	int frameH, frameW, padTop, padLeft, numInputs;
+	const unsigned *sums;
 };
 
 // Activation as ONE multiplier: x < 0 ? x * s : x with s = 0 (ReLU), the negative slope
@@ -194,8 +203,9 @@ struct FbGeom {
 // NW waves per workgroup: 8 (two per SIMD) wherever the kernel fits 256 registers -- the
 // staging, expansion and epilogue phases are VALU work that one wave per SIMD issues at
 // half rate, and a partner wave's epilogue runs beside the other's MFMAs.
-template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK, int NW>
+template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK, int NW, bool PACK = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockParams p) {
+	static_assert(!PACK || (CIN == 16 && !UPS), "PACK: the 16-channel flow input");
 	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, NW>;
 	constexpr int NT = NW * 64;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -237,6 +247,62 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	const bool border = y0 - 2 < 0 || y0 + TH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
 	constexpr int LPP = G::PBX / 16;  // lanes (16-byte chunks) per pixel
 	if (JU_SKIP(p) & 1) {
+	} else if constexpr (PACK) {
+		// The flow input is born here (pack_frames_kernel's arithmetic, one launch less): ch 0-2 =
+		// the current frame (x / 255 - 0.5 - brightness, exact 0 in the pad border), ch 3 .. = the
+		// previous tensor's ch 0 .., the rest zero.  One thread per tile pixel; the tile that OWNS
+		// a pixel (its 30 x TH output area) also writes the record to the new packed tensor, the
+		// next frame's history.  Pixels outside the padded image are the convolution's zeros.
+		const float bright = brightnessOf(p.sums, 1.0f / static_cast<float>(p.frameH * p.frameW));
+		const T *__restrict__ prev = static_cast<const T *>(p.packPrev);
+		T *__restrict__ cur = static_cast<T *>(p.packOut);
+		const int nch = 3 * p.numInputs;
+		constexpr int NPIX = G::XR * kFbW;
+		for (int q = tid; q < NPIX; q += NT) {
+			const int r = q / kFbW, k = q - r * kFbW;
+			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
+			const T zero = static_cast<T>(0.f);
+			Vec8<T> o0 = {zero, zero, zero, zero, zero, zero, zero, zero}, o1 = o0;
+			const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+			if (inside) {
+				const int y = gy - p.padTop, x = gx - p.padLeft;
+				float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+				if (y >= 0 && y < p.frameH && x >= 0 && x < p.frameW) {
+					const unsigned v = *reinterpret_cast<const unsigned *>(p.frame + y * p.frameStride + x * 4);
+					c0 = preprocessU8(v & 0xff) - bright;
+					c1 = preprocessU8((v >> 8) & 0xff) - bright;
+					c2 = preprocessU8((v >> 16) & 0xff) - bright;
+				}
+				const size_t idx = (size_t)gy * p.W + gx;
+				const Vec8<T> p0 = *reinterpret_cast<const Vec8<T> *>(prev + idx * 16);
+				const Vec8<T> p1 = *reinterpret_cast<const Vec8<T> *>(prev + idx * 16 + 8);
+				T pv[16], o[16];
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					pv[i] = p0[i];
+					pv[8 + i] = p1[i];
+				}
+				o[0] = static_cast<T>(c0);
+				o[1] = static_cast<T>(c1);
+				o[2] = static_cast<T>(c2);
+#pragma unroll
+				for (int j = 3; j < 16; ++j) o[j] = (j < nch) ? pv[j - 3] : zero;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					o0[i] = o[i];
+					o1[i] = o[8 + i];
+				}
+				if (r >= 2 && r < 2 + TH && k >= 2 && k < 2 + kFbOutW) {
+					*reinterpret_cast<Vec8<T> *>(cur + idx * 16) = o0;
+					*reinterpret_cast<Vec8<T> *>(cur + idx * 16 + 8) = o1;
+				}
+			}
+			unsigned char *xb = smem + G::OFF_X + (r * kFbW + k) * G::PBX;
+			const unsigned sw = fbSwz<G::PBX>(k);
+			*reinterpret_cast<Vec8<T> *>(xb + ((0u ^ sw) << 4)) = o0;
+			*reinterpret_cast<Vec8<T> *>(xb + ((1u ^ sw) << 4)) = o1;
+		}
+		__syncthreads();
 	} else if constexpr (!UPS) {
 		if (border) {  // interior tiles are overwritten completely
 			for (int i = tid; i < G::NPL * G::XPLANE / 16; i += NT) {
@@ -994,12 +1060,12 @@ constexpr int fbWaves() {
 	return CIN > 64 ? 4 : 8;
 }
 
-template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK>
+template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK, bool PACK = false>
 void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
 	constexpr int NW = fbWaves<CIN>();
 	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, NW>;
 	static_assert(G::FITS, "tile does not fit LDS");
-	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTK, NW>;
+	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTK, NW, PACK>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "flow block");
 	dim3 grid((p.W + kFbOutW - 1) / kFbOutW, (p.H + TH - 1) / TH);
@@ -1011,10 +1077,15 @@ void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
 // fills the chip, the short one (6 rows) for small tensors.
 constexpr int kFbTall = 18, kFbMid = 14, kFbShort = 6;
 
-template <typename T, int CIN, int CMID, bool UPS, bool POOL, int OUTK>
+template <typename T, int CIN, int CMID, bool UPS, bool POOL, int OUTK, bool PACK = false>
 void launchFlowBlockT(const FlowBlockParams &p, int numCUs, hipStream_t stream) {
 	const long tilesX = (p.W + kFbOutW - 1) / kFbOutW;
-	if constexpr (FbGeom<CIN, CMID, kFbTall, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS) {
+	if constexpr (PACK) {
+		if (tilesX * ((p.H + kFbTall - 1) / kFbTall) * 10 >= 7L * numCUs) {
+			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTK, true>(p, stream);
+		}
+		return launchFlowBlockInst<T, CIN, CMID, kFbShort, UPS, POOL, OUTK, true>(p, stream);
+	} else if constexpr (FbGeom<CIN, CMID, kFbTall, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS) {
 		if (tilesX * ((p.H + kFbTall - 1) / kFbTall) * 10 >= 7L * numCUs) {
 			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTK>(p, stream);
 		}
@@ -1044,7 +1115,23 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.act2 = q.act2;
 	p.slope = q.slope;
 	p.skip = ablationSkipBits();
+	p.frame = q.packFrame;
+	p.frameStride = q.packFrameStride;
+	p.packPrev = q.packPrev;
+	p.packOut = q.packOut;
+	p.frameH = q.frameH;
+	p.frameW = q.frameW;
+	p.padTop = q.padTop;
+	p.padLeft = q.padLeft;
+	p.numInputs = q.numInputs;
+	p.sums = q.sums;
 	const int cus = currentDeviceCUs();
+	if (q.packOut != nullptr) {
+		if (!(q.cin == 16 && q.cmid == 32 && !q.upsample && q.pool && !q.outHead && !q.residual && q.packFrame && q.packPrev)) {
+			throw std::invalid_argument("flow block: input packing is built for the first block (16 -> 32 -> 32, pool)");
+		}
+		return launchFlowBlockT<T, 16, 32, false, true, 0, true>(p, cus, stream);
+	}
 	if (q.upsample && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused upsampling needs even H and W");
 	if (q.pool && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused max-pool needs even H and W");
 	// the shapes of the flow auto-encoder's fusable blocks (flowBlockSupported)

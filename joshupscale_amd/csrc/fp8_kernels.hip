@@ -38,11 +38,15 @@ constexpr int kF8Lds = 2 * kF8TileBytes + 4 * kF8Slice;  // 77824: two workgroup
 
 // Addresses are "uniform base + uniform offset + 32-bit lane offset": the loop-invariant
 // lane offsets cost one VGPR each.  (Buffer instructions -- descriptor + voffset + soffset
-// -- would save the 64-bit adds, and were tried: with BOTH the LDS loads and the stores
-// as MUBUF this kernel produced rare, run-to-run varying stale tiles on gfx950, always in
-// the tile rows just above image rows 128 k; with either side as plain global
-// instructions, or with one workgroup per CU, results are bit-stable.  Cause not
-// understood; the plain global path below is the one every other kernel here uses.)
+// -- would save the 64-bit adds, and were tried: with the e4m3 copy's stores as
+// `buffer_store_dwordx4 ... sN offen` this kernel produced rare stale tiles at two workgroups
+// per CU.  Round 3 bisected it (tools/probes/fp8_stale_tile.sh PROBE_SET=bisect: soffset 0,
+// `s_nop 7` behind the store or a vmcnt(0) behind it each cure it) and reproduced the mechanism
+// standalone (tools/probes/mubuf_store_data.hip): a buffer store with an SGPR soffset reads its
+// data registers late when a second wave of the SIMD competes for the vector-memory issue, and
+// hipcc's hazard recogniser exempts exactly that form from the store-data wait states -- the
+// next store's address arithmetic / LDS read then reuses the registers too early.  Rule: no
+// soffset-SGPR buffer stores in kernels with more than one wave per SIMD)
 // 16 bytes per lane, memory -> LDS without a VGPR round trip (lands at l + lane * 16)
 // Probe builds only (tools/probes/fp8_stale_tile.sh, never the product): JU_FP8_MUBUF_LD / _ST (or
 // JU_FP8_MUBUF for both) move the same bytes with buffer instructions, JU_FP8_NOWAIT drops the
@@ -67,9 +71,31 @@ __device__ __forceinline__ void dmaToLds16(const unsigned char *base, unsigned u
 	    (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 #endif
 }
+// GROUP: 1 = the 16-bit stream's stores, 2 = the e4m3 copy's.  Further probe switches (bisecting
+// the MUBUF-store anomaly, tools/probes/fp8_stale_tile.sh): JU_FP8_ST_GROUPS = mask of the groups
+// that use buffer stores (default both), JU_FP8_ST_NOSOFF = whole offset in the VGPR (soffset 0),
+// JU_FP8_ST_NOP = `s_nop 7` behind every buffer store, JU_FP8_ST_DRAIN = vmcnt(0) behind it.
+#ifndef JU_FP8_ST_GROUPS
+#define JU_FP8_ST_GROUPS 3
+#endif
+template <int GROUP>
 __device__ __forceinline__ void store16(unsigned char *base, unsigned uniformOff, unsigned laneOff, i32x4 v) {
 #if defined(JU_FP8_MUBUF_ST)
-	__builtin_amdgcn_raw_buffer_store_b128(v, probeBuffer(base), static_cast<int>(laneOff), static_cast<int>(uniformOff), 0);
+	if constexpr ((JU_FP8_ST_GROUPS & GROUP) != 0) {
+#if defined(JU_FP8_ST_NOSOFF)
+		__builtin_amdgcn_raw_buffer_store_b128(v, probeBuffer(base), static_cast<int>(laneOff + uniformOff), 0, 0);
+#else
+		__builtin_amdgcn_raw_buffer_store_b128(v, probeBuffer(base), static_cast<int>(laneOff), static_cast<int>(uniformOff), 0);
+#endif
+#if defined(JU_FP8_ST_NOP)
+		asm volatile("s_nop 7" ::: "memory");
+#endif
+#if defined(JU_FP8_ST_DRAIN)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	} else {
+		*reinterpret_cast<i32x4 *>(base + uniformOff + laneOff) = v;
+	}
 #else
 	*reinterpret_cast<i32x4 *>(base + uniformOff + laneOff) = v;
 #endif
@@ -304,7 +330,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 				const int gy = gy0 + (i >> 1);
 				const int gx = gx0 + (i & 1) * 16 + (lane >> 2);
 				if (gy < p.H && gx < p.W) {
-					store16(static_cast<unsigned char *>(p.outT),
+					store16<1>(static_cast<unsigned char *>(p.outT),
 					    base + static_cast<unsigned>(((i >> 1) * p.pitch + (i & 1) * 16) * 128), halfOff, val);
 				}
 			}
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(kF8Threads, 2) void conv_tower_fp8_kernel(Fp8Kernel
 			const int gy = gy0 + i;
 			const int gx = gx0 + pxo;
 			if (gy < p.H && gx < p.W) {
-				store16(p.out8, static_cast<unsigned>(((gy + 1) * p.pitch + gx0 + 1) * 64 + ch * 32),
+				store16<2>(p.out8, static_cast<unsigned>(((gy + 1) * p.pitch + gx0 + 1) * 64 + ch * 32),
 				    static_cast<unsigned>(pxo * 64 + c * 16), i32x4{a[0], a[1], b[0], b[1]});
 			}
 		}

@@ -127,6 +127,16 @@ struct FlowBlockLaunch {
 	bool residual;
 	int act1, act2;  // ConvParams::relu codes
 	float slope;
+	// The flow net's first block (cin 16, cmid 32, pool) can build its input itself -- the work
+	// of launchPackFrames, one launch less: packOut != nullptr.  `in` is then unused; the block
+	// reads the u8 frame and the previous packed tensor, and writes the new packed tensor
+	// [H][W][16] (H, W = the padded size) as a side effect.
+	const std::uint8_t *packFrame;
+	std::ptrdiff_t packFrameStride;
+	const void *packPrev;
+	void *packOut;
+	int frameH, frameW, padTop, padLeft, numInputs;
+	const unsigned *sums;
 };
 bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHead);
 void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream);

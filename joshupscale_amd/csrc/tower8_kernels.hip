@@ -422,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 				}
 			}
 		}
+		asm volatile("s_nop 1" ::: "memory");  // (store-data hazard of soffset-SGPR buffer stores: tower_kernels.hip, publish)
 	};
 	auto fillHalo = [&](auto offTag, int layer) -> bool {
 		constexpr int off = decltype(offTag)::value;

@@ -984,6 +984,13 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				}
 			}
 		}
+		// MUBUF stores with an SGPR soffset read their data registers late when a second wave of
+		// the SIMD competes for the vector-memory issue, and hipcc inserts no wait state for this
+		// form (tools/probes/mubuf_store_data.hip).  This kernel runs ONE wave per
+		// SIMD, where the probe never saw it (gap 0, every configuration), and every slot is
+		// tag-checked by its consumer; the two wait states cost nothing and keep the store's data
+		// registers untouched for as long as the probe's worst case needed.
+		asm volatile("s_nop 1" ::: "memory");
 	};
 	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
 	// returns false on timeout (uniform across the workgroup)

@@ -183,6 +183,22 @@ def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
     assert all(np.array_equal(a, b) for a, b in zip(first, own))
     rt8.close()
     monkeypatch.delenv("JU_TAIL")
+    # the flow net's first block builds the packed flow input itself (round 3: one launch less);
+    # JU_PACK=split keeps pack_frames_kernel as its own launch: the same arithmetic, the same bytes,
+    # and the same recurrent history tensor
+    assert rt.time_steps("pack", 0)[1] == 0
+    rt.reset()
+    for f in frames:
+        rt.process_image(f)
+    hist = rt.read_tensor("flow_in").copy()
+    monkeypatch.setenv("JU_PACK", "split")
+    rt9 = R.Runtime(blob, 0, R.DTYPE_BF16)
+    assert rt9.time_steps("pack", 0)[1] == 1 and rt9.time_steps("flow", 0)[1] == rt.time_steps("flow", 0)[1]
+    packed = [rt9.process_image(f).copy() for f in frames]
+    assert all(np.array_equal(a, b) for a, b in zip(first, packed))
+    assert np.array_equal(rt9.read_tensor("flow_in"), hist) and np.abs(hist).max() > 0.1
+    rt9.close()
+    monkeypatch.delenv("JU_PACK")
     # per-layer flow convolutions (JU_FLOW_CONV=generic): same arithmetic as the one-launch
     # blocks up to the fp32 summation order; within that path the fused pool / upsample
     # variants are bit-exact (rounding is monotonic; the fused staging uses the same arithmetic)

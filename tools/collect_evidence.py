@@ -17,7 +17,7 @@ def newest(pattern):
     return max(files, key=os.path.getmtime) if files else None
 
 
-for t in ["final", "fp8_psp", "fp8_ps2", "ps2", "fast"]:
+for t in ["final", "lrelu", "fp8_psp", "fp8_ps2", "ps2", "fast"]:
     b = os.path.join(go, f"bench_{tag}_{t}.json")
     if os.path.exists(b):
         shutil.copy(b, os.path.join(pr, f"{tag}_{t}_bench.json"))

@@ -13,6 +13,10 @@
 set -u
 cd "$(dirname "$0")/../.."
 VARIANTS="mubuf_nowait:-DJU_FP8_MUBUF -DJU_FP8_NOWAIT|mubuf_wait:-DJU_FP8_MUBUF|mubuf_ld:-DJU_FP8_MUBUF_LD|mubuf_st:-DJU_FP8_MUBUF_ST|global_nowait:-DJU_FP8_NOWAIT"
+# round 3: bisecting the store anomaly (PROBE_SET=bisect): which store group, soffset or not, hazard / drain
+if [ "${PROBE_SET:-}" = bisect ]; then
+VARIANTS="st_stream:-DJU_FP8_MUBUF_ST -DJU_FP8_ST_GROUPS=1|st_e4m3:-DJU_FP8_MUBUF_ST -DJU_FP8_ST_GROUPS=2|st_nosoff:-DJU_FP8_MUBUF_ST -DJU_FP8_ST_NOSOFF|st_nop:-DJU_FP8_MUBUF_ST -DJU_FP8_ST_NOP|st_drain:-DJU_FP8_MUBUF_ST -DJU_FP8_ST_DRAIN|mubuf_st:-DJU_FP8_MUBUF_ST"
+fi
 if [ "${1:-}" = build ]; then
   make -s || exit 1
   mkdir -p build/probes
@@ -26,7 +30,9 @@ if [ "${1:-}" = build ]; then
   done
   exit 0
 fi
-for n in ${PROBE_VARIANTS:-mubuf_nowait mubuf_wait mubuf_ld mubuf_st global_nowait}; do
+DEFAULT_RUN="mubuf_nowait mubuf_wait mubuf_ld mubuf_st global_nowait"
+[ "${PROBE_SET:-}" = bisect ] && DEFAULT_RUN="mubuf_st st_stream st_e4m3 st_nosoff st_nop st_drain"
+for n in ${PROBE_VARIANTS:-$DEFAULT_RUN}; do
   for rep in 1 2 3; do
     JU_LIBRARY=build/probes/libju_fp8_$n.so timeout 300 python3 -m pytest tests/test_gpu_parity.py -q -m gpu \
       -k test_fp8_tower_bytes_do_not_depend_on_the_grid 2>&1 | grep -E "passed|failed" | sed "s/^/$n run $rep: /"

@@ -3,7 +3,7 @@
 # (host frames = PCIe-inclusive, fp16, psp-fast fp16, ps2-quality 16-bit and 8-bit, flow-resnet), condensed.
 R=$GRAFT_REPO_ROOT
 cd $R
-for v in "--location host" "--dtype fp16" "--preset psp-fast --dtype fp16" "--preset ps2-quality" "--preset ps2-quality --dtype fp8" "--preset psp-quality --dtype fp8" "--preset psp-quality-flowres"; do
+for v in "--location host" "--dtype fp16" "--preset psp-quality-lrelu" "--preset psp-quality-lrelu --dtype fp8" "--preset psp-fast --dtype fp16" "--preset ps2-quality" "--preset ps2-quality --dtype fp8" "--preset psp-quality --dtype fp8" "--preset psp-quality-flowres"; do
   timeout 200 python3 bench.py --no-cpu-baseline --steps 200 --warmup 20 $v 2>/dev/null | tail -1 | V="$v" python3 -c '
 import json, os, sys
 d = json.loads(sys.stdin.read())
