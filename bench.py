@@ -210,7 +210,10 @@ def main() -> int:
     result = None
     # a timed region that is not pure steady state is not a measurement of it: refuse
     graphs_on = os.environ.get("JU_NO_GRAPH", "0") != "1" and os.environ.get("JU_DIRECT_GRAPH", "1") != "0"
-    dirty = graphs_on and (timed_region["captures"] > 0 or timed_region["eager"] > 0)
+    # (a resident-tower fallback -- CUs held by another process -- re-captures its graphs: that run is
+    # reported as it went, with config.tower saying "per-layer launches", not refused)
+    fell_back = rt.stat("fallbacks") > 0
+    dirty = graphs_on and not fell_back and (timed_region["captures"] > 0 or timed_region["eager"] > 0)
     if dirty:
         print(f"bench.py: rank {rank}: the timed region contained {timed_region['captures']} graph capture(s) and "
               f"{timed_region['eager']} eager run(s) ({timed_region}); refusing to report a value. Register the "
@@ -287,6 +290,7 @@ def main() -> int:
                 "affinity": AFFINITY,
                 "boundary": "ju_process (synchronous processImage)",
                 "timed_region": timed_region,
+                "resident_fallbacks": int(rt.stat("fallbacks")),
                 "preroll_frames": args.preroll,
                 "submission": {"graph_replays": rt.stat("graph_replays"), "eager_runs": rt.stat("eager_runs"),
                                "cached_graphs": rt.stat("direct_graphs"), "prepared_captures": prepared,
