@@ -84,7 +84,7 @@ PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-lev
 PEAK_HBM_GBS = 8000.0  # HBM3E, same guide
 PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled e4m3 MFMA (same guide: twice the bf16 rate)
 PREROLL_FRAMES = 256  # ~0.15 s of frames before --warmup: the GPU's clocks ramp while the first frames run
-TRAFFIC_PROFILE = "r02_tower_traffic.json"  # PMC summary of the dominant kernel (tools/pmc_traffic.sh)
+TRAFFIC_PROFILE = "r03_tower_traffic.json"  # PMC summary of the dominant kernel (tools/pmc_traffic.sh)
 
 
 def cpu_baseline(blob: bytes, cfg, frames: np.ndarray, budget_s: float) -> dict:
@@ -228,7 +228,11 @@ def main() -> int:
         # dominant kernel: the 3x3 64->64 convolution of the residual tower,
         # timed with HIP events on the engine's own stream
         fp8 = args.dtype == "fp8"
-        ms, launches, flops = rt.time_steps("tower", args.roofline_iters)
+        # (timed inside whole frames: the kernel in the clock / cache context of the workload --
+        # what `rocprofv3 --kernel-trace --stats` of this command averages; the back-to-back
+        # figure of the launches alone is reported beside it)
+        ms, launches, flops = rt.time_steps("tower@frame", args.roofline_iters)
+        ms_alone = rt.time_steps("tower", args.roofline_iters)[0]
         flops_per_launch = flops / max(launches, 1)
         achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_MFMA_TFLOPS
@@ -238,7 +242,7 @@ def main() -> int:
             peak = PEAK_FP8_TFLOPS
         elif fp8 and launches == 1 + cfg.gen_blocks:
             # one launch per residual block (more regions than CUs): step 0 is the quantise kernel
-            ms, _, fl1 = rt.time_steps("tower#1", args.roofline_iters)
+            ms, _, fl1 = rt.time_steps("tower#1@frame", args.roofline_iters)
             launches, flops_per_launch = cfg.gen_blocks, fl1
             achieved = fl1 / (ms * 1e-3) / 1e12
             peak = PEAK_FP8_TFLOPS
@@ -246,8 +250,8 @@ def main() -> int:
             # 8-bit tower: step 0 of the stage is the quantise kernel, then per block the first
             # convolution (e4m3 in, e4m3 out: MFMA-bound by arithmetic) and the second (+ the
             # fp16 residual stream in and out: memory-bound, and the one most time goes to)
-            ms1, _, fl1 = rt.time_steps("tower#1", args.roofline_iters)
-            ms2, _, _ = rt.time_steps("tower#2", args.roofline_iters)
+            ms1, _, fl1 = rt.time_steps("tower#1@frame", args.roofline_iters)
+            ms2, _, _ = rt.time_steps("tower#2@frame", args.roofline_iters)
             px = h * w
             bytes2 = px * (64 + 128 + 128 + 64) + 9 * 64 * 64   # t8 in, stream in/out, x8 out, weights
             fp8_roofline = {
@@ -315,6 +319,9 @@ def main() -> int:
                 "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                 "traffic_source": traffic_source,
                 "launch_ms": ms, "launches_per_frame": launches,
+                "launch_ms_how": "HIP events around the kernel's launches inside whole frames on the engine's stream "
+                                 "(ju_time_steps tag@frame), mean over %d frames" % args.roofline_iters,
+                "launch_ms_back_to_back": ms_alone,
                 "flops_per_launch": flops_per_launch,
             },
         }

@@ -193,8 +193,12 @@ JU_API int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, siz
  * residual blocks, "flow", "warp", "gen_head", "tail", "pack", "" = all),
  * measured with HIP events on the runtime's own stream over `iters`
  * repetitions.  *launches = kernel launches per repetition, *flops = their
- * algorithmic FLOPs (2*MAC) per repetition.  Timing runs the launches outside the frame
- * sequence: the recurrent state is reset (as by ju_reset) before the call returns. */
+ * algorithmic FLOPs (2*MAC) per repetition.  "tag#k": only the k-th launch of the tag.
+ * "tag@frame" (also "tag#k@frame"): the tagged launches timed INSIDE whole frames -- every step
+ * of the frame runs, HIP events bracket the tagged launches -- i.e. the kernel in the clock and
+ * cache context of the real workload (what a kernel trace of the benchmark averages).  Timing
+ * overwrites scratch tensors and the recurrent state: the state is reset (as by ju_reset)
+ * before the call returns. */
 JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_per_launch,
     int *launches, double *flops);
 

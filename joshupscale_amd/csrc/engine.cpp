@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <stdexcept>
@@ -981,8 +982,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		if (m_UseGraph) {
 			for (int s = 0; s < 2; ++s) {
 				m_Graph[s] = GraphExec::capture(m_Stream, [&] {
-					for (const Step &st : m_Program[s]) st.run(m_Stream);
-				});
+				for (const Step &st : m_Program[s]) st.run(m_Stream);
+			});
 			}
 			m_Stream.synchronize();
 		}
@@ -1290,6 +1291,10 @@ Engine::DirectEntry &Engine::directEntry(const DirectKey &key) {
 
 // Records binding set idx's launches against m_IO (nothing executes).
 void Engine::captureDirect(DirectEntry *e, int idx) {
+	// ONE graph per frame: replaying the first launches as a graph of their own, so that the GPU
+	// starts while the CPU still submits the rest, was measured and lost 0.5-0.8 % (1943-1947 against
+	// 1926-1933 frames/s, tools/submit_overhead.py): hipGraphLaunch already streams its packets, and
+	// the second graph costs a boundary
 	e->graph = GraphExec::capture(m_Stream, [&] {
 		for (const Step &st : m_Program[idx]) st.run(m_Stream);
 	});
@@ -1490,7 +1495,10 @@ std::size_t Engine::readTensor(const std::string &name, float *dst, std::size_t 
 	return outCount;
 }
 
-double Engine::flopsOf(const std::string &tagSpec) const {
+double Engine::flopsOf(const std::string &tagSpecIn) const {
+	std::string tagSpec = tagSpecIn;
+	const std::size_t at = tagSpec.find("@frame");
+	if (at != std::string::npos) tagSpec = tagSpec.substr(0, at);
 	std::string tag = tagSpec;
 	int only = -1;
 	const std::size_t hash = tagSpec.find('#');
@@ -1509,9 +1517,20 @@ double Engine::flopsOf(const std::string &tagSpec) const {
 	return f;
 }
 
-double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
+double Engine::timeSteps(const std::string &tagSpecIn, int iters, int *launches) {
 	DeviceGuard g(m_Device);
-	// "flow#3" = only the 4th step tagged "flow" (per-layer timing)
+	// "flow#3" = only the 4th step tagged "flow" (per-layer timing); "tower@frame" = the steps
+	// tagged "tower" timed INSIDE whole frames (every step of the frame runs, events bracket the
+	// tagged launches): the kernel in the clock / cache context of the real workload, which is
+	// what a kernel trace of the benchmark averages -- back-to-back launches of the tower alone
+	// draw more power and read 4-5 % slower on the same box
+	std::string tagSpec = tagSpecIn;
+	bool inFrame = false;
+	const std::size_t at = tagSpec.find("@frame");
+	if (at != std::string::npos) {
+		inFrame = true;
+		tagSpec = tagSpec.substr(0, at);
+	}
 	std::string tag = tagSpec;
 	int only = -1;
 	const std::size_t hash = tagSpec.find('#');
@@ -1533,17 +1552,43 @@ double Engine::timeSteps(const std::string &tagSpec, int iters, int *launches) {
 	m_IO.inStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 4;
 	m_IO.out = m_OutStage.as<std::uint8_t>();
 	m_IO.outStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 16;
+	double ms = 0.0;
 	std::unique_lock<std::mutex> chain = chainBegin();  // (the timed launches may be resident towers)
-	for (const Step *s : steps) s->run(m_Stream);  // warm
-	Event t0, t1;
-	t0.record(m_Stream);
-	for (int i = 0; i < iters; ++i) {
-		for (const Step *s : steps) s->run(m_Stream);
+	if (inFrame) {
+		auto isTimed = [&](const Step *s) { return std::find(steps.begin(), steps.end(), s) != steps.end(); };
+		for (const Step &s : m_Program[m_Idx]) s.run(m_Stream);  // warm
+		std::vector<std::unique_ptr<Event>> ev;
+		for (int i = 0; i < iters; ++i) {
+			for (const Step &s : m_Program[m_Idx]) {
+				const bool timed = isTimed(&s);
+				if (timed) {
+					ev.emplace_back(new Event());
+					ev.back()->record(m_Stream);
+				}
+				s.run(m_Stream);
+				if (timed) {
+					ev.emplace_back(new Event());
+					ev.back()->record(m_Stream);
+				}
+			}
+		}
+		chainEnd(chain);
+		m_Stream.synchronize();
+		double sum = 0.0;
+		for (std::size_t i = 0; i + 1 < ev.size(); i += 2) sum += static_cast<double>(Event::elapsedMs(*ev[i], *ev[i + 1]));
+		ms = sum / (static_cast<double>(iters) * steps.size());
+	} else {
+		for (const Step *s : steps) s->run(m_Stream);  // warm
+		Event t0, t1;
+		t0.record(m_Stream);
+		for (int i = 0; i < iters; ++i) {
+			for (const Step *s : steps) s->run(m_Stream);
+		}
+		t1.record(m_Stream);
+		chainEnd(chain);
+		t1.synchronize();
+		ms = static_cast<double>(Event::elapsedMs(t0, t1)) / (static_cast<double>(iters) * steps.size());
 	}
-	t1.record(m_Stream);
-	chainEnd(chain);
-	t1.synchronize();
-	const double ms = static_cast<double>(Event::elapsedMs(t0, t1)) / (static_cast<double>(iters) * steps.size());
 	// The timed launches ran outside the frame sequence: scratch tensors, the output
 	// staging buffer and (with JU_TAIL=tower) the recurrent state were overwritten.  Start
 	// the stream from a clean state again, and do not leave a bounded-wait failure of the
