@@ -116,7 +116,8 @@ JU_API int ju_synchronize(ju_runtime *runtime);
  * a graph from the second use of a pair on.  JU_LOC_CPU / graphics-resource images need
  * nothing (their frames go through the staging buffers whose graphs exist from ju_create on):
  * the call checks the sizes and returns.  *captured (may be NULL) receives the number of
- * graphs captured by this call: 2 for a new device pair, 0 otherwise. */
+ * graphs captured by this call: 2 for a new device pair, 0 otherwise.  Up to 256 pairs stay
+ * registered; beyond that the pair used least recently is forgotten with its graphs. */
 JU_API int ju_prepare_frames(ju_runtime *runtime, const ju_image *input, const ju_image *output, int *captured);
 
 /* Replaces Runtime::getInputWidth/Height, getOutputWidth/Height (core.h:71-82). */

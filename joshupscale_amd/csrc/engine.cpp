@@ -1317,8 +1317,29 @@ int Engine::prepareFrames(const Frame &in, const Frame &out) {
 	const DirectKey pair{in.ptr, in.stride, out.ptr, out.stride, 0};
 	if (!m_RegisteredPairs.count(pair)) {
 		if (m_RegisteredPairs.size() >= kMaxRegisteredPairs) {
-			throw std::invalid_argument("prepareFrames: more than " + std::to_string(kMaxRegisteredPairs) +
-			                            " frame-buffer pairs registered");
+			// a caller that keeps registering new buffers (and never the old ones again): forget
+			// the pair whose graphs were used least recently, with its graphs
+			auto victim = m_RegisteredPairs.begin();
+			std::uint64_t oldest = ~std::uint64_t(0);
+			for (auto it = m_RegisteredPairs.begin(); it != m_RegisteredPairs.end(); ++it) {
+				std::uint64_t used = 0;
+				for (int idx = 0; idx < 2; ++idx) {
+					DirectKey key = *it;
+					key.idx = idx;
+					auto g = m_DirectGraphs.find(key);
+					if (g != m_DirectGraphs.end()) used = std::max(used, g->second.lastUse);
+				}
+				if (used < oldest) {
+					oldest = used;
+					victim = it;
+				}
+			}
+			for (int idx = 0; idx < 2; ++idx) {
+				DirectKey key = *victim;
+				key.idx = idx;
+				m_DirectGraphs.erase(key);
+			}
+			m_RegisteredPairs.erase(victim);
 		}
 		m_RegisteredPairs.insert(pair);
 	}
