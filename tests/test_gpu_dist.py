@@ -63,6 +63,13 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
     res1 = json.loads([ln for ln in bare.stdout.splitlines() if ln.startswith("{")][-1])
     assert res1["config"]["timed_region"] == {"replays": 20, "eager": 0, "captures": 0}
     assert abs(res["value"] / res1["value"] - 1.0) < 0.06, (res["value"], res1["value"])
+    # a timed region that is not pure replay is not reported: without registered buffers the 20
+    # timed steps would be eager first sightings and inline captures (round 2's driver figure)
+    dirty = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                            "--preroll", "0", "--no-prepare", "--no-cpu-baseline", "--preset", "psp-fast", "--dtype", "fp16"],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert dirty.returncode == 3 and "refusing to report" in dirty.stderr, dirty.stderr[-1500:]
+    assert not [ln for ln in dirty.stdout.splitlines() if ln.startswith("{")]
     # launched the wrong way, the bench refuses instead of measuring one GPU
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT)

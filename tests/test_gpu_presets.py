@@ -300,6 +300,40 @@ def test_prepare_frames_captures_in_setup_and_the_loop_only_replays():
     rt.close()
 
 
+def test_registered_pairs_are_bounded_and_the_oldest_is_forgotten():
+    """ju_prepare_frames keeps at most 256 pairs: a caller that registers new buffers for ever does
+    not grow the graph cache without bound; a forgotten pair still works (it is captured again at
+    its second use, like any unregistered pair) and produces the same bytes."""
+    import torch
+    from helpers import small_config
+    cfg = small_config()
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    h, w = cfg.frame_height, cfg.frame_width
+    frames = M.synthetic_frames(3, h, w, seed=61, kind="smooth")
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(frames).to(dev)
+    outs = torch.empty((260, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    rt = R.Runtime(blob, 0, R.DTYPE_F16)
+    want = [rt.process_image(f).copy() for f in frames]
+    rt.reset()
+    src = rt.device_image(d_in[0].data_ptr(), w, h)
+    for k in range(260):
+        assert rt.prepare_frames(src, rt.device_image(outs[k].data_ptr(), 4 * w, 4 * h)) == 2
+    assert rt.stat("registered_pairs") == 256 and rt.stat("direct_graphs") == 512
+    # pair 0 was forgotten (registered first, never used): its first use is an eager run again
+    for t in range(3):
+        rt.process(rt.device_image(d_in[t].data_ptr(), w, h), rt.device_image(outs[0].data_ptr(), 4 * w, 4 * h))
+        assert np.array_equal(outs[0].cpu().numpy(), want[t]), t
+    assert rt.stat("eager_runs") == 3        # (three different inputs: three tuples seen once)
+    # a pair that is still registered replays from its first frame
+    rt.reset()
+    before = rt.stat("graph_replays")
+    rt.process(src, rt.device_image(outs[259].data_ptr(), 4 * w, 4 * h))
+    assert rt.stat("graph_replays") == before + 1 and np.array_equal(outs[259].cpu().numpy(), want[0])
+    rt.close()
+
+
 def test_second_runtime_is_created_while_the_first_has_frames_in_flight():
     """Advisor finding: a runtime created while another resident runtime has enqueued frames
     must not run its constructor's tower launches beside them, and two threads calling the
