@@ -132,6 +132,8 @@ if __name__ == "__main__":
         # `activation: lrelu` models (reference models.py:24-27): both sub-models leaky
         "small_lrelu": (small_config(flow_activation="lrelu", gen_activation="lrelu",
                                      gen_negative_slope=0.2), 4, "smooth", 15, False),
+        # the 8-bit tower of a LeakyReLU generator (round 3: e4m3 clamped on both sides)
+        "small_fp8_lrelu": (small_config(gen_blocks=3, gen_activation="lrelu", gen_negative_slope=0.2), 3, "smooth", 16, True),
     }
     for name, (cfg, n, kind, seed, fp8) in smalls.items():
         if a.only is None or name in a.only:

@@ -39,6 +39,23 @@ def test_numpy_oracle_reproduces_the_fp8_golden():
     assert not np.array_equal(plain.run(g["frames"][0]), g["outputs"][0])   # it IS a different model
 
 
+def test_numpy_oracle_reproduces_the_fp8_lrelu_golden():
+    """The 8-bit scheme for `activation: lrelu` generators (LeakyReLU in full precision, e4m3
+    clamped at +-448): pinned like the ReLU one, and reproduced by the PyTorch restatement."""
+    from torch_restatement import TorchSession
+    g = load("small_fp8_lrelu")
+    cfg = small_config(gen_blocks=3, gen_activation="lrelu", gen_negative_slope=0.2)
+    wts = M.make_seeded_weights(cfg, seed=42)
+    assert hashlib.sha256(M.serialize(cfg, wts)).hexdigest() == str(g["model_sha256"])
+    sess = O.Session(wts, oracle_config(cfg, fp8_tower=True))
+    tsess = TorchSession(wts, oracle_config(cfg, fp8_tower=True))
+    for t, frame in enumerate(g["frames"]):
+        assert np.array_equal(sess.run(frame), g["outputs"][t]), t
+        assert np.array_equal(tsess.run(frame), g["outputs"][t]), t
+    relu8 = O.Session(M.make_seeded_weights(small_config(gen_blocks=3)), oracle_config(small_config(gen_blocks=3), fp8_tower=True))
+    assert not np.array_equal(relu8.run(g["frames"][0]), g["outputs"][0])
+
+
 @pytest.mark.parametrize("name", sorted(SMALL))
 def test_numpy_oracle_reproduces_small_goldens(name):
     g = load(name)

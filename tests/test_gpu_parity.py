@@ -1040,6 +1040,22 @@ def test_fp8_rejects_a_calibration_tensor_of_the_wrong_length():
     rt.close()
 
 
+def test_fp8_lrelu_committed_golden_vectors():
+    """tests/golden/small_fp8_lrelu.npz: the 8-bit tower of a LeakyReLU generator against the
+    committed vectors of its oracle (the bounds of the ReLU fixture below)."""
+    g = np.load(os.path.join(GOLD, "small_fp8_lrelu.npz"))
+    cfg = small_config(gen_blocks=3, gen_activation="lrelu", gen_negative_slope=0.2)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    assert hashlib.sha256(blob).hexdigest() == str(g["model_sha256"])
+    rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+    assert rt.stat("resident_tower") == 1
+    for t, frame in enumerate(g["frames"]):
+        out = rt.process_image(frame)
+        d = np.abs(out[..., :3].astype(int) - g["outputs"][t][..., :3].astype(int))
+        assert _psnr(out, g["outputs"][t]) >= 55.0 and d.max() <= 6, (t, _psnr(out, g["outputs"][t]), d.max())
+    rt.close()
+
+
 def test_fp8_committed_golden_vectors():
     """The 8-bit engine against the committed outputs of the 8-bit oracle."""
     g = np.load(os.path.join(GOLD, "small_fp8.npz"))
