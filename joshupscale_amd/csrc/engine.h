@@ -243,10 +243,11 @@ private:
 	// Device-resident frames (JU_LOC_DEVICE, no staging): the kernels take the caller's
 	// pointers, so a captured graph is valid for ONE (input, output, strides, binding set)
 	// tuple.  Callers reuse a handful of frame buffers (OBS: one texture pair; bench.py:
-	// 16 inputs, 1 output), so the graphs are cached by that tuple: the second call with
-	// a tuple captures it, every later one replays it (the reference replays a captured
-	// graph for every location, tensorrt_backend.cc:222-264, 274).  Tuples seen once run
-	// eagerly, so a caller that hands over a fresh pointer every frame never pays a capture.
+	// 16 inputs, 1 output), so the graphs are cached by that tuple: prepareFrames() captures
+	// a registered pair's two graphs at once (the reference captures in its constructor,
+	// tensorrt_backend.cc:257-263); for an unregistered tuple the second call captures it and
+	// every later one replays it.  Tuples seen once run eagerly, so a caller that hands over a
+	// fresh pointer every frame never pays a capture.
 	struct DirectKey {
 		const void *in;
 		std::ptrdiff_t inStride;

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 // res_block_kernel: one 64-filter residual block (models.py:193-254) per launch, PERSISTENT
 // ---------------------------------------------------------------------------
 // For towers that cannot use tower_resident_kernel (more 32 x 16 regions than CUs, e.g.
-// 640 x 448; LeakyReLU models; after a fallback).  One workgroup per CU loops over
+// 640 x 448; after a fallback).  One workgroup per CU loops over
 // 14 x 30-pixel tiles:
 //   * both convolutions' A fragments stay in registers for the whole launch (2 x 36
 //     fragments = 288 VGPRs per wave, one wave per SIMD): no weight traffic per tile;

@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		a2[0] = reinterpret_cast<const Vec8<T> *>(p.tailW2)[lane];
 		a2[1] = reinterpret_cast<const Vec8<T> *>(p.tailW2)[64 + lane];
 		const float b2v[3] = {p.tailB2[0], p.tailB2[1], p.tailB2[2]};
-		// (the resident tower runs ReLU models only: its halo tags live in the sign bits)
+		// (the fused tail is instantiated for ReLU models only: launchResidentTower refuses TAIL + LEAKY)
 		const TailRowArgs args{p.tailB1, p.frame, p.frameStride, p.state, p.outU8, p.outStride, p.H, p.W, -1.0f};
 		const float bright = brightnessOf(p.sums, 1.0f / static_cast<float>(p.H * p.W));
 		__syncthreads();
