@@ -625,11 +625,40 @@ void Engine::buildProgram(int set) {
 			rp.state = stateOut;
 			rp.sums = sums;
 		}
+		TailFusedLaunch tf{};  // (debug variants of the tower kernel have no fused-tail form: separate launch)
+		if (tailInTower) {
+			const ConvWeights &cw = m_Convs.at("generator/conv_trans_1");
+			const Operand xin = Op("trunk_b");
+			tf.x = xin.ptr;
+			tf.xPitch = xin.pitch;
+			tf.w1 = cw.w.get();
+			tf.b1 = cw.bias.as<float>();
+			tf.w2 = m_TailW2Frag.get();
+			tf.b2 = m_TailB2.as<float>();
+			tf.state = stateOut;
+			tf.sums = sums;
+			tf.H = H;
+			tf.W = W;
+			tf.slope = -1.0f;
+		}
 		prog.push_back({"tower",
 		    2.0 * H * W * 9.0 * (51.0 * 64 + 64.0 * 64 * 2 * c.genBlocks) +
 		        (tailInTower ? 2.0 * H * W * (64.0 * 128 + 4 * 4 * 32 * 3) : 0.0),
 		    [=](hipStream_t s) {
 			    ResidentTowerParams r = rp;
+			    if (r.tailW1 != nullptr && towerVariant() != 0) {
+				    // a diagnostic variant of the kernel (plain schedule, calibration, phase profile,
+				    // ablations): it writes the trunk, and the same tail code runs as its own launch
+				    r.tailW1 = nullptr;
+				    launchResidentTower(dt, r, s);
+				    TailFusedLaunch t = tf;
+				    t.frame = io->in;
+				    t.frameStride = io->inStride;
+				    t.outU8 = io->out;
+				    t.outStride = io->outStride;
+				    launchTailFused(dt, t, s);
+				    return;
+			    }
 			    if (r.tailW1 != nullptr) {  // caller's frames are known at launch time only
 				    r.frame = io->in;
 				    r.frameStride = io->inStride;
@@ -790,12 +819,13 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 
 	const char *tailMode = std::getenv("JU_TAIL");
 	m_FusedTail = !(tailMode && std::string(tailMode) == "split");
-	// JU_TAIL=tower: the fused tail runs inside the resident tower launch (its last
-	// layer is in LDS).  Bit-identical; measured -8 us of per-frame kernel time but only
-	// +0.5 % frames/s through the synchronous boundary, and the tower launch then
-	// carries the tail's HBM-bound work (its MFMA fraction reads 1.5 points lower), so
-	// the separate launch stays the default.
-	m_TailInTower = tailMode && std::string(tailMode) == "tower";
+	// The fused tail runs INSIDE the resident tower launch wherever that kernel is used with a
+	// ReLU generator (its last layer is in LDS: the trunk is never written or re-read, one launch
+	// less).  Bit-identical to the separate launch (same row code); round 2 measured +0.5-1 % and
+	// kept it opt-in, under round 3's steady-state timing it is +0.9 % at 480x270 and +1.9 % for
+	// psp-fast (tools/submit_overhead.py, three A/B rounds), so it is the default now.
+	// JU_TAIL=fused: the separate tail_fused_kernel launch; JU_TAIL=split: the two-kernel tail.
+	m_TailInTower = !(tailMode && (std::string(tailMode) == "fused" || std::string(tailMode) == "split"));
 	const char *packMode = std::getenv("JU_PACK");
 	m_PackInBlock = !(packMode && std::string(packMode) == "split");  // JU_PACK=split: pack_frames_kernel as its own launch
 	const char *poolMode = std::getenv("JU_POOL");

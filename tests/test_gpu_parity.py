@@ -177,8 +177,9 @@ def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
     split = [rt5.process_image(f).copy() for f in frames]
     assert all(u8_stats(a, b)["max"] <= 1 for a, b in zip(first, split))
     rt5.close()
-    monkeypatch.setenv("JU_TAIL", "tower")              # the fused tail inside the resident tower launch
-    rt8 = R.Runtime(blob, 0, R.DTYPE_BF16)               # instead of its own: same row code
+    monkeypatch.setenv("JU_TAIL", "fused")              # the fused tail as its own launch instead of inside
+    rt8 = R.Runtime(blob, 0, R.DTYPE_BF16)               # the resident tower launch (the default): same row code
+    assert rt.time_steps("tail", 0)[1] == 0 and rt8.time_steps("tail", 0)[1] == 1
     own = [rt8.process_image(f).copy() for f in frames]
     assert all(np.array_equal(a, b) for a, b in zip(first, own))
     rt8.close()

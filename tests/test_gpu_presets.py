@@ -170,7 +170,7 @@ def test_full_size_resident_tower_against_the_per_block_kernels(monkeypatch, dty
 
 
 @pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16])
-def test_resident_tower_schedule_does_not_change_the_bytes(dtype):
+def test_resident_tower_schedule_does_not_change_the_bytes(dtype, monkeypatch):
     """The product schedule of tower_resident_kernel (two units' halo-independent steps run around
     the halo loads with their accumulators kept across the sweep, the next layer's weights refilled
     behind the last unit's MFMAs, hand-issued fragment reads under 480 registers) against the PLAIN
@@ -191,21 +191,30 @@ def test_resident_tower_schedule_does_not_change_the_bytes(dtype):
     for cfg, n in cases:
         blob = M.serialize(cfg, M.make_seeded_weights(cfg))
         frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=11, kind="noise")
-        outs = {}
-        for variant in (0, 8):
-            lib.ju_debug_set(b"tower_variant", variant)
-            try:
-                rt = R.Runtime(blob, 0, dtype)
-                assert rt.stat("resident_tower") == 1 and rt.stat("tower_variant") == variant
-                outs[variant] = [rt.process_image(f).copy() for f in frames]
-                trunk = rt.read_tensor("trunk").copy()
-                outs[(variant, "trunk")] = trunk
-                rt.close()
-            finally:
-                lib.ju_debug_set(b"tower_variant", 0)
-        assert np.array_equal(outs[(0, "trunk")], outs[(8, "trunk")]), (cfg.frame_height, cfg.frame_width)
-        for a, b in zip(outs[0], outs[8]):
-            assert np.array_equal(a, b), (cfg.frame_height, cfg.frame_width)
+        # default: the product kernel carries the fused tail (no trunk tensor; the plain-schedule
+        # variant has no such form: it writes the trunk and the same tail code runs as a launch of
+        # its own) -- frames and state must be equal; JU_TAIL=fused: both write the trunk -- equal too
+        for tail_mode in ("tower", "fused"):
+            monkeypatch.setenv("JU_TAIL", tail_mode)
+            outs = {}
+            for variant in (0, 8):
+                lib.ju_debug_set(b"tower_variant", variant)
+                try:
+                    rt = R.Runtime(blob, 0, dtype)
+                    assert rt.stat("resident_tower") == 1 and rt.stat("tower_variant") == variant
+                    outs[variant] = [rt.process_image(f).copy() for f in frames]
+                    outs[(variant, "state")] = rt.read_tensor("state").copy()
+                    outs[(variant, "trunk")] = rt.read_tensor("trunk").copy()
+                    rt.close()
+                finally:
+                    lib.ju_debug_set(b"tower_variant", 0)
+            key = (cfg.frame_height, cfg.frame_width, cfg.gen_activation, tail_mode)
+            if tail_mode == "fused" or cfg.gen_activation != "relu":   # (lrelu: no fused-tail form, the trunk is written)
+                assert np.array_equal(outs[(0, "trunk")], outs[(8, "trunk")]), key
+            assert np.array_equal(outs[(0, "state")], outs[(8, "state")]), key
+            for a, b in zip(outs[0], outs[8]):
+                assert np.array_equal(a, b), key
+        monkeypatch.delenv("JU_TAIL")
 
 
 def test_device_frame_graphs_equal_eager_launches(monkeypatch):

@@ -3,6 +3,7 @@
 where the trunk differs most, by tile / row / column / channel.  Found the stale-tile race
 described in DESIGN.md section 4b.   usage: tools/fp8_diag.py H W blocks [frames]"""
 import sys, os
+os.environ.setdefault("JU_TAIL", "fused")  # the 16-bit engine's trunk tensor is read below: keep the tail a launch of its own
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from joshupscale_amd import model_file as M, runtime as R
