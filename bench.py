@@ -266,6 +266,7 @@ def main() -> int:
                                "frac": fl1 / (ms1 * 1e-3) / 1e12 / PEAK_FP8_TFLOPS},
             }
         total_flops = rt.time_steps("", 0)[2]
+        tail_inside = rt.time_steps("tail", 0)[1] == 0
         # HBM traffic of the dominant kernel from the committed PMC summary (bench.py cannot
         # run rocprofv3 around itself); only used when it describes the kernel measured here
         traffic = None
@@ -310,7 +311,8 @@ def main() -> int:
             },
             "roofline": {
                 "kernel": ("tower8_resident_kernel: all 3x3 64->64 e4m3 convs of the residual blocks, one launch" if fp8
-                           else "tower_resident_kernel: all 3x3 64->64 convs of the residual blocks, one launch")
+                           else "tower_resident_kernel: generator conv_1 + all 3x3 64->64 convs of the residual blocks"
+                                + (" + the generator tail on the LDS-resident last layer" if tail_inside else "") + ", one launch")
                           if launches == 1 else
                           ("res_block_fp8_kernel: one residual block (two 3x3 64->64 e4m3 convs) per launch" if fp8
                            else "res_block_kernel / conv_tower_kernel: 3x3 64->64 residual-block convs"),
