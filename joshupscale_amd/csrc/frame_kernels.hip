@@ -187,69 +187,17 @@ __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ 
 	const int pix = idx >> 2;
 	const int w = pix % W;
 	const int h = pix / W;
-	const int HH = H * 4, WW = W * 4;
 	// depth-to-space(4) of the flow head is just this channel addressing:
 	// flow[4h+i, 4w+j, k] = head[h, w, (i*4+j)*2 + k]  (keras_layers.py:175)
 	const Vec8<f16> f8 = *reinterpret_cast<const Vec8<f16> *>(
 	    flow + ((size_t)(h + padTop) * PW + (w + padLeft)) * 32 + i * 8);
-	float fl[8];
-#pragma unroll
-	for (int k = 0; k < 8; ++k) fl[k] = static_cast<float>(f8[k]);
-	T o[16];
-	Vec4<f16> pw[4];  // the same 4 HR pixels in [4H][4W][4] f16 for the temporal filter
-	const int Y = 4 * h + i;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const int X = 4 * w + j;
-		// tfa/dense_image_warp.py:232-245, 116-171
-		const float qy = static_cast<float>(Y) - fl[2 * j];
-		const float qx = static_cast<float>(X) - fl[2 * j + 1];
-		const float fy = fminf(fmaxf(0.0f, floorf(qy)), static_cast<float>(HH - 2));
-		const float fx = fminf(fmaxf(0.0f, floorf(qx)), static_cast<float>(WW - 2));
-		const float ay = fminf(fmaxf(0.0f, qy - fy), 1.0f);
-		const float ax = fminf(fmaxf(0.0f, qx - fx), 1.0f);
-		const int y0 = static_cast<int>(fy), x0 = static_cast<int>(fx);
-		const f16 *s0 = state + ((size_t)y0 * WW + x0) * 4;
-		const f16 *s1 = s0 + (size_t)WW * 4;
-		const Vec4<f16> tl = *reinterpret_cast<const Vec4<f16> *>(s0);
-		const Vec4<f16> tr = *reinterpret_cast<const Vec4<f16> *>(s0 + 4);
-		const Vec4<f16> bl = *reinterpret_cast<const Vec4<f16> *>(s1);
-		const Vec4<f16> br = *reinterpret_cast<const Vec4<f16> *>(s1 + 4);
-#pragma unroll
-		for (int c = 0; c < 3; ++c) {
-			const float a = static_cast<float>(tl[c]), b = static_cast<float>(tr[c]);
-			const float d = static_cast<float>(bl[c]), e = static_cast<float>(br[c]);
-			const float top = ax * (b - a) + a;
-			const float bot = ax * (e - d) + d;
-			const float v = ay * (bot - top) + top + bright;
-			o[j * 3 + c] = static_cast<T>(v);
-			pw[j][c] = static_cast<f16>(v);
-		}
-		pw[j][3] = static_cast<f16>(0.f);
-	}
+	Vec8<T> o0, o1;
+	Vec4<f16> pw[4];
+	warpQuarter<T>(state, f8, frame, frameStride, H, W, h, w, i, bright, o0, o1, pw);
 	if (preWarpOut != nullptr) {
-		f16 *d = preWarpOut + ((size_t)Y * WW + 4 * w) * 4;
+		f16 *d = preWarpOut + ((size_t)(4 * h + i) * (4 * W) + 4 * w) * 4;
 #pragma unroll
 		for (int j = 0; j < 4; ++j) *reinterpret_cast<Vec4<f16> *>(d + 4 * j) = pw[j];
-	}
-	float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-	if (i == 0) {
-		const unsigned v = *reinterpret_cast<const unsigned *>(frame + h * frameStride + w * 4);
-		l0 = preprocessU8(v & 0xff);
-		l1 = preprocessU8((v >> 8) & 0xff);
-		l2 = preprocessU8((v >> 16) & 0xff);
-	}
-	// spare slots: the LR frame rides in quarter 0, zeros elsewhere (x/255-0.5 of
-	// a real pixel is never needed for i != 0, and 0.0 weights nothing)
-	o[12] = static_cast<T>(l0);
-	o[13] = static_cast<T>(l1);
-	o[14] = static_cast<T>(l2);
-	o[15] = static_cast<T>(0.f);
-	Vec8<T> o0, o1;
-#pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		o0[k] = o[k];
-		o1[k] = o[8 + k];
 	}
 	T *dst = out + (size_t)pix * 64 + i * 16;
 	*reinterpret_cast<Vec8<T> *>(dst) = o0;

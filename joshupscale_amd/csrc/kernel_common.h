@@ -161,6 +161,71 @@ __device__ __forceinline__ float brightnessOf(const unsigned *__restrict__ sums,
 	return 0.114f * mb + 0.587f * mg + 0.2989f * mr;
 }
 
+// One quarter (HR row i of the 4 x 4 block) of an LR pixel's generator-input record:
+// dense_image_warp of the previous HR output (tfa/dense_image_warp.py:232-245, 116-171) +
+// space_to_depth(4) + concat (models.py:523-530) + pack: 4 warped HR pixels x 3 channels in
+// slots 0..11, the LR frame's pixel in 12..14 of quarter 0, zeros elsewhere.  Shared by
+// warp_pack_kernel and the flow head block (which warps its own tile, flow_kernels.hip).
+// f8: the flow head's 8 values (dy, dx) x 4 for this quarter; pw: the same 4 warped pixels as
+// f16 [4] records (the temporal filter's pre_warp).
+template <typename T>
+__device__ __forceinline__ void warpQuarter(const f16 *__restrict__ state, const Vec8<f16> f8,
+    const std::uint8_t *__restrict__ frame, std::ptrdiff_t frameStride, int H, int W, int h, int w, int i, float bright,
+    Vec8<T> &o0, Vec8<T> &o1, Vec4<f16> (&pw)[4]) {
+	const int HH = H * 4, WW = W * 4;
+	float fl[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) fl[k] = static_cast<float>(f8[k]);
+	T o[16];
+	const int Y = 4 * h + i;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int X = 4 * w + j;
+		const float qy = static_cast<float>(Y) - fl[2 * j];
+		const float qx = static_cast<float>(X) - fl[2 * j + 1];
+		const float fy = fminf(fmaxf(0.0f, floorf(qy)), static_cast<float>(HH - 2));
+		const float fx = fminf(fmaxf(0.0f, floorf(qx)), static_cast<float>(WW - 2));
+		const float ay = fminf(fmaxf(0.0f, qy - fy), 1.0f);
+		const float ax = fminf(fmaxf(0.0f, qx - fx), 1.0f);
+		const int y0 = static_cast<int>(fy), x0 = static_cast<int>(fx);
+		const f16 *s0 = state + ((size_t)y0 * WW + x0) * 4;
+		const f16 *s1 = s0 + (size_t)WW * 4;
+		const Vec4<f16> tl = *reinterpret_cast<const Vec4<f16> *>(s0);
+		const Vec4<f16> tr = *reinterpret_cast<const Vec4<f16> *>(s0 + 4);
+		const Vec4<f16> bl = *reinterpret_cast<const Vec4<f16> *>(s1);
+		const Vec4<f16> br = *reinterpret_cast<const Vec4<f16> *>(s1 + 4);
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			const float a = static_cast<float>(tl[c]), b = static_cast<float>(tr[c]);
+			const float d = static_cast<float>(bl[c]), e = static_cast<float>(br[c]);
+			const float top = ax * (b - a) + a;
+			const float bot = ax * (e - d) + d;
+			const float v = ay * (bot - top) + top + bright;
+			o[j * 3 + c] = static_cast<T>(v);
+			pw[j][c] = static_cast<f16>(v);
+		}
+		pw[j][3] = static_cast<f16>(0.f);
+	}
+	float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+	if (i == 0) {
+		const unsigned v = *reinterpret_cast<const unsigned *>(frame + h * frameStride + w * 4);
+		l0 = preprocessU8(v & 0xff);
+		l1 = preprocessU8((v >> 8) & 0xff);
+		l2 = preprocessU8((v >> 16) & 0xff);
+	}
+	// spare slots: the LR frame rides in quarter 0, zeros elsewhere (x/255-0.5 of
+	// a real pixel is never needed for i != 0, and 0.0 weights nothing)
+	o[12] = static_cast<T>(l0);
+	o[13] = static_cast<T>(l1);
+	o[14] = static_cast<T>(l2);
+	o[15] = static_cast<T>(0.f);
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		o0[k] = o[k];
+		o1[k] = o[8 + k];
+	}
+}
+
 // LDS footprint of the generator tail (tail_fused_kernel; the resident tower runs the
 // same row code in a free activation buffer)
 constexpr int kTailLdsRow = 32 * 128;             // 4 KiB: one LR row of 32 px x 64 ch
