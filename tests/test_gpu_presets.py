@@ -144,6 +144,25 @@ def test_benchmark_clip_at_full_size_on_host_and_device_paths(preset, dtype):
 
 
 @pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16])
+@pytest.mark.parametrize("h,w,extra", [(135, 241, {}), (203, 310, dict(gen_activation="lrelu", gen_negative_slope=0.2))])
+def test_mid_size_ragged_geometry_against_the_c_restatement(h, w, extra, dtype):
+    """Between the small cases the float64 oracle steps through and the presets: ragged sizes with
+    many partial 32 x 16 regions (135 x 241: 8 x 9 regions, the last column 17 px wide, the last
+    row 7 high; 203 x 310: 10 x 13), padded flow input (135 -> 136 rows), partial 30-px flow tiles,
+    six residual blocks -- whole frames against the C restatement, ReLU and LeakyReLU."""
+    from oracle.c_binding import CSession
+    cfg = M.ModelConfig(frame_height=h, frame_width=w, gen_blocks=6, **extra)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=7))
+    frames = M.synthetic_frames(4, h, w, seed=77, kind="noise")
+    cs = CSession(blob, h, w)
+    rt = R.Runtime(blob, 0, dtype)
+    assert rt.stat("resident_tower") == 1
+    for t, f in enumerate(frames):
+        check_u8(rt.process_image(f), cs.run(f), dtype, ("mid-size", h, w, sorted(extra), t), clip="noise")
+    rt.close()
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16])
 def test_full_size_resident_tower_against_the_per_block_kernels(monkeypatch, dtype):
     """The resident tower and the one-launch-per-block kernels share no exchange code and
     accumulate the taps in a different order (the resident kernel runs dx = 1 first for its
