@@ -417,10 +417,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 		for (int g = 0; g < 4; ++g) {
 			tOff[g] = px * G::PBT + ((static_cast<unsigned>(cb * 4 + g) ^ fbSwz<G::PBT>(px)) << 4) + hh * 8;
 		}
+		// (the bias comes in with the weights, once -- not a memory round trip per row pair -- where
+		// 16 more registers do not spill: not beside 144 registers of fragments at two waves per SIMD)
+		constexpr bool kHoistBiasA = G::NPL * 9 * G::KS1 * 4 < 144 || NW == 4;
+		f32x4 biasA[4];
+		if constexpr (kHoistBiasA) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) biasA[g] = *reinterpret_cast<const f32x4 *>(p.b1 + cb * 32 + 8 * g + 4 * hh);
+		}
 		auto initAcc = [&](f32x16(&a)[2]) {
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
-				const f32x4 bg = *reinterpret_cast<const f32x4 *>(p.b1 + cb * 32 + 8 * g + 4 * hh);
+				f32x4 bg;
+				if constexpr (kHoistBiasA) bg = biasA[g];
+				else bg = *reinterpret_cast<const f32x4 *>(p.b1 + cb * 32 + 8 * g + 4 * hh);
 #pragma unroll
 				for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -477,12 +487,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 		}
 	}
 
-	// ---- conv B weights (registers of conv A's fragments are free now) ----
+	// ---- conv B weights (registers of conv A's fragments are free now) and its bias: fetched in
+	// front of the barrier, so that the wait for the slowest wave's conv A hides the latency (the
+	// bias used to be loaded per row pair behind the barrier: a memory round trip in front of every
+	// pair's first MFMA) ----
 	Vec8<T> wb[9 * G::KS2];
+	f32x4 biasB[4];
 	{
 		const unsigned char *wsrc = static_cast<const unsigned char *>(p.w2) + (size_t)cb * (9 * G::KS2 * 1024) + lane * 16;
 #pragma unroll
 		for (int f = 0; f < 9 * G::KS2; ++f) wb[f] = *reinterpret_cast<const Vec8<T> *>(wsrc + (size_t)f * 1024);
+#pragma unroll
+		for (int g = 0; g < 4; ++g) biasB[g] = *reinterpret_cast<const f32x4 *>(p.b2 + cb * 32 + 8 * g + 4 * hh);
 	}
 	__syncthreads();  // T complete, X dead
 
@@ -499,11 +515,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 		f32x16 acc[2];
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
-			const f32x4 bg = *reinterpret_cast<const f32x4 *>(p.b2 + cb * 32 + 8 * g + 4 * hh);
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
 #pragma unroll
-				for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = bg[i];
+				for (int i = 0; i < 4; ++i) acc[r][4 * g + i] = biasB[g][i];
 			}
 		}
 		FbPair<T, G::KS2, G::PBT>::run(ldsBase + G::OFF_T + (2 * pair) * (kFbW * G::PBT), colOffB, colSwzB, hh, wb, acc);
