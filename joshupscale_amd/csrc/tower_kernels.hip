@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	__syncthreads();
 
 	// VARIANT 4 (diagnostic build only): per-wave cycle sums of the phases below
-	u64 prof[7] = {0, 0, 0, 0, 0, 0, 0};
+	u64 prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	float calibMax = 0.f;  // VARIANT 5: largest post-ReLU output of the current layer (this lane)
 	auto stamp = [&]() __attribute__((always_inline)) -> u64 {
 		if constexpr (VARIANT == 4) {
@@ -641,16 +641,61 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	};
 	const int firstWhole = isPre(rp) ? (preEnd < np2 ? preEnd : -1) : (rp < np2 ? rp : -1);
 	const bool streamsInUnit = (firstWhole >= 0 || mySingle) && !kNoMfma && !kPlain;  // the next layer's weights stream behind the last unit
+#ifndef JU_NO_DEFER
+	constexpr bool kDefer = kPreRun == 2 && !kNoMfma && !LEAKY && VARIANT != 5;
+#else
+	constexpr bool kDefer = false;
+#endif
+	// (see finishLayer) two pre-run pairs, then one or two whole pairs, no odd row
+	const bool deferShape = nPre == 2 && !mySingle && firstWhole >= 0 && (nextWhole(firstWhole) < 0 || nextWhole(nextWhole(firstWhole)) < 0);
 
 	// KIND 0: pre-run (accumulator init + positions 0..3); 1: finish (positions 4..11 +
 	// epilogue); 2: whole unit.  `primed`: the first step's fragments are already in flight
 	// in set 0.  nextUnit >= 0: prime that unit's first step at the end -- position 0
 	// (nextFinish false: a pre-run or whole unit) or 4 (a finish) -- so that its fragments
 	// travel while this unit's epilogue runs.
+	// Deferred epilogue (DEF): the previous unit of this wave (accumulators `dacc`, row pair `dunit`)
+	// has not been written yet -- its epilogue runs one (r, g) group per macro-step BEHIND this
+	// unit's MFMAs (VALU and the LDS write issue while the matrix pipe works on the macro-step's
+	// last two MFMAs), instead of as ~560 exposed cycles between the units.  Same arithmetic, same
+	// order per element.  EPI false: this unit leaves its own epilogue to its successor.
+	const bool lanesValid = px < rwv;
+	Vec4<T> rvNext[2][4];  // residual of the unit whose epilogue is pending
+	auto epiValue = [&](auto resTag, const f32x16 &a, const int g, const Vec4<T> &rv, float(&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) v[i] = a[4 * g + i];
+		if constexpr (decltype(resTag)::value) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[i]);
+		}
+		if constexpr (VARIANT == 5 && !LEAKY) {  // calibration build: range of the layer's output
+#pragma unroll
+			for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, v[i]);  // (= max of the ReLU'd values)
+		}
+	};
+	auto epiStore = [&](auto outTag, const int row, const int g, float(&v)[4]) __attribute__((always_inline)) {
+		constexpr int outOff = decltype(outTag)::value;
+		if constexpr (LEAKY) {
+			// slope in [0, 1] (model.cpp): max(x, slope * x) IS x < 0 ? slope * x : x
+#pragma unroll
+			for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * p.slope);
+			if constexpr (VARIANT == 5) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, fabsf(v[i]));
+			}
+			*reinterpret_cast<Vec4<T> *>(smem + outOff + row * kResRowBytes + outsw[g]) = pack4<T>(v[0], v[1], v[2], v[3]);
+		} else {
+			*reinterpret_cast<Vec4<T> *>(smem + outOff + row * kResRowBytes + outsw[g]) =
+			    reluPacked<T>(pack4<T>(v[0], v[1], v[2], v[3]));
+		}
+	};
 	auto unitSeg = [&](auto rowsTag, auto kindTag, auto resTag, auto inTag, auto outTag, f32x16(&acc)[2],
 	                   const int layer, const int unit, const bool primed, const int nextUnit,
-	                   const bool nextFinish, auto streamTag) __attribute__((always_inline)) {
+	                   const bool nextFinish, auto streamTag, auto defTag, f32x16(&dacc)[2], const int dunit,
+	                   auto epiTag) __attribute__((always_inline)) {
 		constexpr bool streamNext = decltype(streamTag)::value;  // (compile-time: no branch per macro-step)
+		constexpr bool DEF = decltype(defTag)::value;   // (a deferring segment is always primed and deferred units are row pairs)
+		constexpr bool EPI = decltype(epiTag)::value;
 		constexpr int ROWS = decltype(rowsTag)::value;
 		constexpr int KIND = decltype(kindTag)::value;
 		constexpr bool residual = decltype(resTag)::value;
@@ -667,6 +712,13 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			for (int r = 0; r < ROWS; ++r) acc[r] = biasVec;
 		}
 		const unsigned rowAddr = ldsBase + inOff + (2 * unit) * kResRowBytes;
+		// A unit whose epilogue is deferred (EPI false) fetches its residual behind the MFMAs of its own
+		// last macro-step into rvNext (plain C++ loads: the compiler's own waits count only what it
+		// knows of and are therefore never too lenient); its successor (DEF) consumes them.
+		constexpr bool kFetchRes = !EPI && residual && KIND != 0;
+		const int dra = 1 + 2 * dunit;
+		float dv[4];
+		unsigned dlo = 0, dhi = 0;
 		if (!kNoMfma) {
 			if (!primed) {
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -691,8 +743,20 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					if (fresh) {
 						// outstanding allowed = younger reads of this step + next step's issued so far
 						const int issuedNext = more ? (k < NR ? k : NR) : 0;
-						const int allowed = (NR - 1 - need) + issuedNext;
-						if (allowed >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+						// deferred epilogue: the residual reads sit behind the first step's fragments, a
+						// group's LDS write behind the fragments of the step after it
+						const int younger = (DEF && pos > P0 && pos - P0 <= 8 ? 1 : 0) +
+						                    (kFetchRes && pos == P1 - 1 ? 2 * (k < 4 ? k : 4) : 0);
+						const int allowed = (NR - 1 - need) + issuedNext + younger;
+						if (allowed >= 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+						else if (allowed == 11) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+						else if (allowed == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+						else if (allowed == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+						else if (allowed == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+						else if (allowed == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+						else if (allowed == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+						else if (allowed == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+						else if (allowed == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
 						else if (allowed == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
 						else if (allowed == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
 						else if (allowed == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
@@ -703,6 +767,43 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					acc[r] = mfma32(dx == 1 ? wm[dy * 4 + ks] : ws[dy * 8 + (dx >> 1) * 4 + ks], fb[set][need],
 					    (KIND != 1 && pos == P0 && dy == 0) ? biasVec : acc[r]);
 					if (more && k < NR) issue(rowAddr, kOrder[pos + 1 < 12 ? pos + 1 : 11], set ^ 1, k);
+					if constexpr (DEF) {
+						// group (r, g) = step index, at most three plain VALU instructions behind each MFMA
+						// (tools/probes/mfma_valu_overlap.hip: that many issue in an MFMA's shadow for
+						// free, a fourth and every packed-f32 one cost their full issue time):
+						// MFMA 0..3 value i = accumulator (+ residual), 4 convert, 5 ReLU + write
+						const int j = pos - P0;
+						if (j < 8) {
+							const int r = j >> 2, g = j & 3;
+							if (k < 4) {
+								dv[k] = dacc[r][4 * g + k];
+								if constexpr (residual) {
+									dv[k] += static_cast<float>(rvNext[r][g][k]);
+									asm volatile("" : "+v"(dv[k]));  // (keeps the four adds scalar and in their slots)
+								}
+							} else if (k == 4) {
+								const Vec4<T> pk = pack4<T>(dv[0], dv[1], dv[2], dv[3]);
+								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
+								const u32x2d w = __builtin_bit_cast(u32x2d, pk);
+								dlo = w[0];
+								dhi = w[1];
+								asm volatile("" : "+v"(dlo), "+v"(dhi));
+							} else {
+								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
+								const Vec4<T> o = reluPacked<T>(__builtin_bit_cast(Vec4<T>, u32x2d{dlo, dhi}));
+								if (lanesValid) *reinterpret_cast<Vec4<T> *>(smem + outOff + (dra + r) * kResRowBytes + outsw[g]) = o;
+							}
+						}
+					}
+					if constexpr (kFetchRes) {
+						if (pos == P1 - 1 && k < 4) {
+							const int ra0 = 1 + 2 * unit;
+							rvNext[(2 * k) >> 2][(2 * k) & 3] = *reinterpret_cast<const Vec4<T> *>(
+							    smem + outOff + (ra0 + ((2 * k) >> 2)) * kResRowBytes + outsw[(2 * k) & 3]);
+							rvNext[(2 * k + 1) >> 2][(2 * k + 1) & 3] = *reinterpret_cast<const Vec4<T> *>(
+							    smem + outOff + (ra0 + ((2 * k + 1) >> 2)) * kResRowBytes + outsw[(2 * k + 1) & 3]);
+						}
+					}
 					__builtin_amdgcn_sched_barrier(0);
 				}
 				// The wave's LAST unit of the layer: the three fragments of this step (and, after
@@ -739,8 +840,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			}
 		}
 		const u64 tu1 = stamp();
-		prof[5] += tu1 - tu0;
-		if constexpr (KIND != 0) {
+		if constexpr (KIND == 0) prof[7] += tu1 - tu0;
+		else prof[5] += tu1 - tu0;
+		if constexpr (KIND != 0 && EPI) {
 			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
 			// (row ra + r <= rhv always: units are whole pairs, or the odd last row)
 			if (px < rwv) {
@@ -765,30 +867,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #pragma unroll
 					for (int g = 0; g < 4; ++g) {
 						float v[4];
-#pragma unroll
-						for (int i = 0; i < 4; ++i) v[i] = acc[r][4 * g + i];
-						if (residual) {
-#pragma unroll
-							for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[r][g][i]);
-						}
-						if constexpr (VARIANT == 5 && !LEAKY) {  // calibration build: range of the layer's output
-#pragma unroll
-							for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, v[i]);  // (= max of the ReLU'd values)
-						}
-						if constexpr (LEAKY) {
-							// slope in [0, 1] (model.cpp): max(x, slope * x) IS x < 0 ? slope * x : x
-#pragma unroll
-							for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * p.slope);
-							if constexpr (VARIANT == 5) {
-#pragma unroll
-								for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, fabsf(v[i]));
-							}
-							*reinterpret_cast<Vec4<T> *>(smem + outOff + (ra + r) * kResRowBytes + outsw[g]) =
-							    pack4<T>(v[0], v[1], v[2], v[3]);
-						} else {
-							*reinterpret_cast<Vec4<T> *>(smem + outOff + (ra + r) * kResRowBytes + outsw[g]) =
-							    reluPacked<T>(pack4<T>(v[0], v[1], v[2], v[3]));
-						}
+						epiValue(resTag, acc[r], g, rv[r][g], v);
+						epiStore(outTag, ra + r, g, v);
 					}
 				}
 			}
@@ -810,7 +890,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			if (k < nPre) {
 				const int nu = (k + 1 < nPre) ? preFirst + 2 * (k + 1) : -1;
 				unitSeg(R2{}, KPre{}, std::false_type{}, inTag, outTag, acc, layer, preFirst + 2 * k,
-				    (k > 0 || primedFirst) && !kNoMfma, nu, false, std::false_type{});
+				    (k > 0 || primedFirst) && !kNoMfma, nu, false, std::false_type{}, std::false_type{}, acc, 0, std::true_type{});
 			}
 		};
 		if constexpr (LO <= 0 && 0 < HI) slot(accPre0, 0);
@@ -820,12 +900,34 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// the rest of the layer: the pre-run units' remaining steps, then the other units whole
 	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const bool streamW) __attribute__((always_inline)) {
 		const int afterPre = firstWhole >= 0 ? firstWhole : (mySingle ? np2 : -1);
+		if constexpr (kDefer) {
+			// The product's shape (two pre-run pairs, then one or two whole pairs: every wave of a
+			// 16- or 14-row region): each unit's epilogue runs behind its successor's MFMAs, only the
+			// last one is exposed.  The accumulators rotate through the two pre-run sets -- a set is
+			// free again once its epilogue has run, one segment later.
+			if (deferShape) {
+				using Y = std::true_type;
+				using N = std::false_type;
+				const int ua = firstWhole, ub = nextWhole(firstWhole);
+				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre0, layer, preFirst, false, preFirst + 2, true, N{}, N{}, accPre0, 0, N{});
+				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, true, ua, false, N{}, Y{}, accPre0, preFirst, N{});
+				if (ub >= 0) {
+					unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, ub, false, N{}, Y{}, accPre1, preFirst + 2, N{});
+					if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre1, layer, ub, true, -1, false, Y{}, Y{}, accPre0, ua, Y{});
+					else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre1, layer, ub, true, -1, false, N{}, Y{}, accPre0, ua, Y{});
+				} else {
+					if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, Y{}, Y{}, accPre1, preFirst + 2, Y{});
+					else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, N{}, Y{}, accPre1, preFirst + 2, Y{});
+				}
+				return;
+			}
+		}
 		auto slot = [&](f32x16(&acc)[2], const int k) __attribute__((always_inline)) {
 			if (k < nPre) {
 				const bool nextIsPre = k + 1 < nPre;
 				const int nu = nextIsPre ? preFirst + 2 * (k + 1) : afterPre;
 				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, acc, layer, preFirst + 2 * k, k > 0 && !kNoMfma, nu, nextIsPre,
-				    std::false_type{});
+				    std::false_type{}, std::false_type{}, acc, 0, std::true_type{});
 			}
 		};
 		if constexpr (kPreRun > 0) slot(accPre0, 0);
@@ -837,14 +939,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		for (int u = firstWhole; u >= 0;) {
 			const int nw = nextWhole(u);
 			const int nu = nw >= 0 ? nw : (mySingle ? np2 : -1);
-			if (streamW && nu < 0) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, std::true_type{});
-			else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, std::false_type{});
+			if (streamW && nu < 0) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, std::true_type{}, std::false_type{}, acc, 0, std::true_type{});
+			else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, acc, layer, u, primed, nu, false, std::false_type{}, std::false_type{}, acc, 0, std::true_type{});
 			primed = nu >= 0 && !kNoMfma;
 			u = nw;
 		}
 		if (mySingle) {
-			if (streamW) unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, std::true_type{});
-			else unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, std::false_type{});
+			if (streamW) unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, std::true_type{}, std::false_type{}, acc, 0, std::true_type{});
+			else unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, std::false_type{}, std::false_type{}, acc, 0, std::true_type{});
 		}
 	};
 
@@ -1160,7 +1262,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	}
 	if constexpr (VARIANT == 4) {
 		if (lane == 0 && p.debug != nullptr) {
-			for (int k = 0; k < 7; ++k) p.debug[(region * 4 + wave) * 8 + k] = prof[k];
+			for (int k = 0; k < 8; ++k) p.debug[(region * 4 + wave) * 8 + k] = prof[k];
 		}
 	}
 
@@ -1310,6 +1412,14 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	if ((p.nLayers & 1) != (p.hasHead ? 1 : 0)) {
 		throw std::invalid_argument("resident tower: layer count must be 2*blocks (+1 with a head)");
 	}
+#ifdef JU_TOWER_DEV  // developer builds: the bf16 ReLU instantiations only (compile time)
+	if (q.leaky || dt == kF16 || !p.hasHead) throw std::invalid_argument("resident tower: developer build");
+	if (p.tailW1 != nullptr) launchResidentT<bf16, 0, true, true>(p, stream);
+	else if (g_TowerVariant == 8) launchResidentT<bf16, 8, true>(p, stream);
+	else if (g_TowerVariant == 4) launchResidentT<bf16, 4, true>(p, stream);
+	else launchResidentT<bf16, 0, true>(p, stream);
+	return;
+#else
 	if (q.leaky) {
 		// `activation: lrelu` models: own instantiations (epoch beside the values, f32 LeakyReLU);
 		// variant 8 = the plain schedule (tests), 5 = calibration maxima
@@ -1357,6 +1467,7 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 		break;
 	default: launchResidentT<bf16, 0, true>(p, stream); break;
 	}
+#endif
 }
 
 

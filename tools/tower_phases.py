@@ -10,9 +10,9 @@ rt = R.Runtime(M.serialize(cfg, M.make_seeded_weights(cfg)), 0, R.DTYPE_BF16)
 lib = R.load_library()
 lib.ju_debug_set(b"tower_variant", 4)
 ms, n, fl = rt.time_steps("tower", 3)
-raw = rt.read_tensor("tower_profile").view(np.uint64).reshape(256, 4, 8)[:255, :, :7].astype(np.float64)
+raw = rt.read_tensor("tower_profile").view(np.uint64).reshape(256, 4, 8)[:255, :, :8].astype(np.float64)
 lib.ju_debug_set(b"tower_variant", 0)
-names = ["halo fill", "weight issue", "compute", "barrier", "publish", "(K loops)", "(epilogues)"]
+names = ["halo fill", "weight issue", "compute", "barrier", "publish", "(K loops)", "(epilogues)", "(pre-run K)"]
 print(f"diagnostic launch {ms*1e3:.0f} us; cycles per layer (49 layers), median over regions")
 for w in range(4):
     med = np.median(raw[:, w, :], axis=0) / 49
