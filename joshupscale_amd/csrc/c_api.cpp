@@ -267,6 +267,7 @@ int ju_debug_set(const char *key, int value) {
 		const std::string k = key ? key : "";
 		if (k == "tower_variant") ju::setTowerVariant(value);
 		else if (k == "resident_fault") ju::setResidentFault(value);
+		else if (k == "tower_fast") ju::setResidentTowerFast(value);
 		else throw std::invalid_argument("unknown debug key " + k);
 	});
 }

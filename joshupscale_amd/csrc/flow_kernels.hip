@@ -802,11 +802,374 @@ __global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
 	}
 }
 
+
+// ---------------------------------------------------------------------------
+// res_block_pipe_kernel: res_block_kernel with the epilogues in the MFMAs' shadow
+// ---------------------------------------------------------------------------
+// Same tiles, same LDS tiles, same arithmetic per output element as res_block_kernel (its bytes are
+// the reference: JU_RES_BLOCK=plain, tests compare), one wave per SIMD with both convolutions'
+// weights in registers -- but a row pair's epilogue no longer runs between two K loops (the plain
+// kernel: 23.7 of 58 us per block inside the K loops, the rest mostly epilogues at one wave per
+// SIMD).  A 32x32x16 MFMA leaves about three VALU issue slots free while it runs
+// (tools/probes/mfma_valu_overlap.hip), so pair P's epilogue is spread over the macro-steps of pair
+// P + 1's K loop: two accumulator sets alternate, a group of four values (row r, channel group g)
+// per macro-step -- value i behind MFMA i, pack behind MFMA 4, the LDS write behind MFMA 5.
+//   conv A: activation, zero outside the image, into the T tile; only the last pair's epilogue is
+//           exposed (T must be complete at the workgroup barrier).
+//   conv B: + skip, activation, into a per-wave staging tile of two rows (steps 3..10 -- the skip
+//           values are fetched behind the pair's OWN last macro-steps and need the time), read back
+//           transposed behind the last macro-step, and stored as whole 16-byte chunks at the start of
+//           the K loop after that (its `s_waitcnt lgkmcnt(0)` is the only place where the compiler's
+//           conservative wait for the read-back costs nothing).  The last pair of a tile finishes
+//           inside the next tile's first K loops.
+//   bias:   64 + 64 floats in LDS, fetched into a 16-register vector behind the previous K loop's
+//           last MFMAs and used as the C operand of the pair's first MFMAs (no accumulator is ever
+//           initialised by moves, no bias registers held for the whole launch).
+constexpr int kRpStageRow = kFbOutW * 64;         // one row of 30 px x 32 couts, 16-bit
+constexpr int kRpStageWave = 2 * kRpStageRow;
+constexpr int kRpLds = kRbX + kRbT + 4 * kRpStageWave + 512;
+static_assert(kRpLds <= 160 * 1024, "res block tile (pipelined)");
+
+// FbPair<T, 4, 128>::run with three hooks: `first` (the pair's bias vector: C operand of the first
+// MFMA of each row), `atStart()` behind the opening wait, `behind(m, k)` behind MFMA k of macro-step m.
+// LDS instructions issued by the hooks only make the counted waits stricter (they count what is
+// outstanding, the hooks' instructions are younger than the fragments waited for or complete before them).
+// STREAM: the OTHER convolution's fragments replace this one's as they die (behind each macro-step the three
+// fragments it used), so one set of 36 serves both convolutions: 144 registers instead of 288.
+template <typename T, bool STREAM, typename FS, typename FB>
+__device__ __forceinline__ void rbPipeRun(unsigned rowAddr, const unsigned (&colOff)[3], const unsigned (&colSwz)[3], int hh,
+    Vec8<T> (&w)[36], const unsigned char *nextW, f32x16 (&acc)[2], const f32x16 &first, FS &&atStart, FB &&behind) {
+	using P = FbPair<T, 4, 128>;
+	Vec8<T> fb[2][4];
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_sched_barrier(0);
+	atStart();
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int j = 0; j < 4; ++j) P::template issue<0>(fb[0], rowAddr, colOff, colSwz, hh, 0, j);
+#pragma unroll
+	for (int m = 0; m < 12; ++m) {
+		const int set = m & 1;
+		const bool more = m + 1 < 12;
+		const int dx = m / 4, ks = m % 4;
+#pragma unroll
+		for (int k = 0; k < 6; ++k) {
+			const int dy = k >> 1, r = k & 1;
+			const int need = r + dy;
+			const bool fresh = k == 0 || k == 1 || k == 3 || k == 5;
+			if (fresh) {
+				const int allowed = (3 - need) + (more ? (k < 4 ? k : 4) : 0);
+				if (allowed >= 4) P::template waitLgkm<4>();
+				else if (allowed == 3) P::template waitLgkm<3>();
+				else if (allowed == 2) P::template waitLgkm<2>();
+				else if (allowed == 1) P::template waitLgkm<1>();
+				else P::template waitLgkm<0>();
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			acc[r] = mfma32(w[(dy * 3 + dx) * 4 + ks], fb[set][need], (m == 0 && dy == 0) ? first : acc[r]);
+			if (more && k < 4) P::template issue<0>(fb[set ^ 1], rowAddr, colOff, colSwz, hh, m + 1, k);
+			behind(m, k);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if constexpr (STREAM) {
+#pragma unroll
+			for (int dy = 0; dy < 3; ++dy) {
+				const int f = (dy * 3 + dx) * 4 + ks;
+				w[f] = *reinterpret_cast<const Vec8<T> *>(nextW + (size_t)f * 1024);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int tid = threadIdx.x, lane = tid & 63, px = lane & 31, hh = lane >> 5;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: tile and pair coordinates stay in SGPRs)
+	const int cb = wave & 1, pl = wave >> 1;  // cout block, pair lane (pairs pl, pl + 2, ...)
+	const T *__restrict__ in = static_cast<const T *>(p.in);
+	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
+	    (__attribute__((address_space(3))) unsigned char *)smem));
+	unsigned char *smX = smem, *smT = smem + kRbX;
+	unsigned char *stage = smem + kRbX + kRbT + wave * kRpStageWave;
+	float *biasLds = reinterpret_cast<float *>(smem + kRbX + kRbT + 4 * kRpStageWave);
+
+	// ONE set of 36 fragments: conv A's, replaced by conv B's behind conv A's last K loop and back behind
+	// conv B's last one (72 KB per workgroup and phase from L2 -- the resident tower's rate)
+	Vec8<T> w[36];
+	const unsigned char *wPtrA = static_cast<const unsigned char *>(p.w1) + (size_t)cb * (36 * 1024) + lane * 16;
+	const unsigned char *wPtrB = static_cast<const unsigned char *>(p.w2) + (size_t)cb * (36 * 1024) + lane * 16;
+#pragma unroll
+	for (int f = 0; f < 36; ++f) w[f] = *reinterpret_cast<const Vec8<T> *>(wPtrA + (size_t)f * 1024);
+	if (tid < 64) biasLds[tid] = p.b1[tid];
+	else if (tid < 128) biasLds[tid] = p.b2[tid - 64];
+	// this lane's 16 accumulator values of a row: channel cb * 32 + 8 g + 4 hh + i at index 4 g + i
+	auto loadBias = [&](int conv) __attribute__((always_inline)) -> f32x16 {
+		const float *b = biasLds + conv * 64 + cb * 32 + 4 * hh;
+		const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b), b1 = *reinterpret_cast<const f32x4 *>(b + 8),
+		            b2 = *reinterpret_cast<const f32x4 *>(b + 16), b3 = *reinterpret_cast<const f32x4 *>(b + 24);
+		return f32x16{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], b2[0], b2[1], b2[2], b2[3], b3[0], b3[1], b3[2], b3[3]};
+	};
+	unsigned colOff[3], colSwz[3], tOff[4];
+#pragma unroll
+	for (int dx = 0; dx < 3; ++dx) {
+		colOff[dx] = (px + dx) * 128;
+		colSwz[dx] = fbSwz<128>(px + dx);
+	}
+#pragma unroll
+	for (int g = 0; g < 4; ++g) tOff[g] = px * 128 + ((static_cast<unsigned>(cb * 4 + g) ^ fbSwz<128>(px)) << 4) + hh * 8;
+	const bool stageLane = px < kFbOutW;
+
+	auto stageX = [&](int tile) {
+		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
+		constexpr int NPIX = kRbXR * kFbW;
+		constexpr int NINSTR = (NPIX + 7) / 8;  // 8 pixels (1 KiB) per wave-instruction
+		const bool border = y0 - 2 < 0 || y0 + kRbTH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
+		for (int i = wave; i < NINSTR; i += 4) {
+			const int q = i * 8 + (lane >> 3);
+			const int r = q / kFbW, k = q - r * kFbW;
+			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
+			const unsigned c = static_cast<unsigned>(lane & 7) ^ fbSwz<128>(k);
+			const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+			if (q < NPIX && inside) {
+				fbGlds16(in + ((size_t)gy * p.inPitch + gx) * 64 + c * 8, smX + i * 1024);
+			} else if (border && q < NPIX) {
+				*reinterpret_cast<uint4 *>(smX + i * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+			}
+		}
+	};
+
+	// ---- pipeline state ----
+	f32x16 S0[2], S1[2];       // the two accumulator sets
+	Vec4<T> resv[2][4];        // skip values of the conv B pair whose epilogue is pending
+	uint4 stg[4];              // a finished pair's two rows, transposed, on their way to global memory
+	int stY = 0, stX = 0;      // ... and where they go: image row of its first row, first column
+	bool stOn = false;
+	int epY = 0, epX = 0;      // the pending conv B pair's first image row / first column
+	bool epOn = false;         // a conv B epilogue is pending (from the previous tile)
+
+	const auto noStart = []() __attribute__((always_inline)) {};
+	const auto noBehind = [](int, int) __attribute__((always_inline)) {};
+	// stores of the pair in `stg` (behind a K loop's opening wait: the read-back has landed)
+	auto storeRows = [&]() __attribute__((always_inline)) {
+		if (stOn) {
+			unsigned char *outp = static_cast<unsigned char *>(p.out);
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int gy = stY + r;
+#pragma unroll
+				for (int it = 0; it < 2; ++it) {
+					const int pi = it * 16 + (lane >> 2);
+					const unsigned slot = static_cast<unsigned>(lane & 3);
+					const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & 3u);
+					const int gx = stX + pi;
+					if (pi < kFbOutW && gy < p.H && gx < p.W) {
+						*reinterpret_cast<uint4 *>(outp + (((size_t)gy * p.outPitch + gx) * 64 + cb * 32) * 2 + chunk * 16) = stg[r * 2 + it];
+					}
+				}
+			}
+			stOn = false;
+		}
+	};
+	// skip values of the pair at image row gy0 (two rows), this lane's channels
+	auto loadSkip = [&](int gy0, int x0, int r, int g) __attribute__((always_inline)) {
+		const int gy = min(gy0 + r, p.H - 1), gx = min(x0 + px, p.W - 1);
+		const T *rp = in + ((size_t)gy * p.inPitch + gx) * 64 + cb * 32 + 4 * hh;
+		resv[r][g] = *reinterpret_cast<const Vec4<T> *>(rp + 8 * g);
+	};
+	// conv A epilogue of the pair in `acc` (T rows 2 pair, 2 pair + 1), group j behind macro-step j
+	float dv[4];
+	unsigned dlo = 0, dhi = 0;
+	typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+	auto epiA = [&](const f32x16 &a0, const f32x16 &a1, int pair, float keep0, float keep1, int m, int k) __attribute__((always_inline)) {
+		if (m < 8) {
+			const int r = m >> 2, g = m & 3;
+			if (k < 4) {
+				const float x = (r ? a1 : a0)[4 * g + k];
+				dv[k] = fbAct(x, p.s1) * (r ? keep1 : keep0);
+			} else if (k == 4) {
+				const u32x2r w = __builtin_bit_cast(u32x2r, pack4<T>(dv[0], dv[1], dv[2], dv[3]));
+				dlo = w[0];
+				dhi = w[1];
+			} else {
+				*reinterpret_cast<u32x2r *>(smT + (2 * pair + r) * (kFbW * 128) + tOff[g]) = u32x2r{dlo, dhi};
+			}
+		}
+	};
+	// conv B epilogue of the pair in `acc` (skip values in resv): groups behind macro-steps 3..10,
+	// the transposed read-back behind macro-step 11
+	auto epiB = [&](const f32x16 &a0, const f32x16 &a1, int m, int k) __attribute__((always_inline)) {
+		if (m >= 3 && m < 11) {
+			const int j = m - 3, r = j >> 2, g = j & 3;
+			if (k < 4) {
+				const float x = (r ? a1 : a0)[4 * g + k] + static_cast<float>(resv[r][g][k]);
+				dv[k] = fbAct(x, p.s2);
+			} else if (k == 4) {
+				const u32x2r w = __builtin_bit_cast(u32x2r, pack4<T>(dv[0], dv[1], dv[2], dv[3]));
+				dlo = w[0];
+				dhi = w[1];
+			} else {
+				const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(px) & 3u);
+				if (stageLane) *reinterpret_cast<u32x2r *>(stage + r * kRpStageRow + px * 64 + (c << 4) + hh * 8) = u32x2r{dlo, dhi};
+			}
+		} else if (m == 11) {
+			if (k == 0) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			} else if (k < 5) {
+				const int r = (k - 1) >> 1, it = (k - 1) & 1;
+				const int pi = it * 16 + (lane >> 2);
+				const unsigned slot = static_cast<unsigned>(lane & 3);
+				// (pi 30, 31 read the neighbouring row's / wave's bytes: never stored)
+				stg[r * 2 + it] = *reinterpret_cast<const uint4 *>(stage + r * kRpStageRow + pi * 64 + (slot << 4));
+			}
+		}
+	};
+
+	int tile = blockIdx.x;
+	if (tile < p.numTiles) stageX(tile);
+	__syncthreads();  // (the bias floats are in LDS)
+	f32x16 bias = loadBias(0);
+	for (; tile < p.numTiles; tile += gridDim.x) {
+		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's X has landed (and the last tile's stores left)
+		__syncthreads();                                  // ... for every wave; all are done with T too
+		const int gxA = x0 - 1 + px;
+		const bool colIn = gxA >= 0 && gxA < p.W;
+		auto keepOf = [&](int pair, int r) __attribute__((always_inline)) {
+			const int gy = y0 - 1 + 2 * pair + r;
+			return (colIn && gy >= 0 && gy < p.H) ? 1.0f : 0.0f;
+		};
+		// ---- conv A: pairs pl, pl + 2, pl + 4, pl + 6 of the 16 T rows; sets S0, S1, S0, S1 ----
+		{
+			// pair 0 of this wave; behind it the previous tile's last conv B epilogue (its accumulators are in S1)
+			const bool pend = epOn;
+			const f32x16 e0 = S1[0], e1 = S1[1];
+			rbPipeRun<T, false>(ldsBase + (2 * pl) * (kFbW * 128), colOff, colSwz, hh, w, nullptr, S0, bias, storeRows,
+			    [&](int m, int k) __attribute__((always_inline)) { if (pend) epiB(e0, e1, m, k); });
+			if (pend) {
+				stY = epY;
+				stX = epX;
+				stOn = true;
+				epOn = false;
+			}
+		}
+#pragma unroll
+		for (int q = 1; q < 4; ++q) {
+			const int pair = pl + 2 * q, prev = pair - 2;
+			const float k0 = keepOf(prev, 0), k1 = keepOf(prev, 1);
+			if (q == 3) {  // (conv A's last K loop: conv B's fragments stream in behind it)
+				const f32x16 e0 = S0[0], e1 = S0[1];
+				rbPipeRun<T, true>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, w, wPtrB, S1, bias, storeRows,
+				    [&](int m, int k) __attribute__((always_inline)) { epiA(e0, e1, prev, k0, k1, m, k); });
+			} else if (q & 1) {
+				const f32x16 e0 = S0[0], e1 = S0[1];
+				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, w, nullptr, S1, bias, storeRows,
+				    [&](int m, int k) __attribute__((always_inline)) { epiA(e0, e1, prev, k0, k1, m, k); });
+			} else {
+				const f32x16 e0 = S1[0], e1 = S1[1];
+				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, w, nullptr, S0, bias, storeRows,
+				    [&](int m, int k) __attribute__((always_inline)) { epiA(e0, e1, prev, k0, k1, m, k); });
+			}
+		}
+		{
+			// the last pair's epilogue (in S1): exposed, T must be complete at the barrier
+			const int pair = pl + 6;
+			const float k0 = keepOf(pair, 0), k1 = keepOf(pair, 1);
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				unsigned char *row = smT + (2 * pair + r) * (kFbW * 128);
+				const float keep = r ? k1 : k0;
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					*reinterpret_cast<Vec4<T> *>(row + tOff[g]) =
+					    pack4<T>(fbAct(S1[r][4 * g + 0], p.s1) * keep, fbAct(S1[r][4 * g + 1], p.s1) * keep,
+					        fbAct(S1[r][4 * g + 2], p.s1) * keep, fbAct(S1[r][4 * g + 3], p.s1) * keep);
+				}
+			}
+		}
+		bias = loadBias(1);
+		// the first conv B pair's skip values (its predecessors fetch theirs behind their own last macro-steps)
+#pragma unroll
+		for (int r = 0; r < 2; ++r) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) loadSkip(y0 + 2 * pl, x0, r, g);
+		}
+		__syncthreads();  // T complete, X dead
+		if (tile + static_cast<int>(gridDim.x) < p.numTiles) stageX(tile + gridDim.x);
+		// ---- conv B: pairs pl, pl + 2, ... < 7; the LAST pair accumulates in S1 (4 pairs: S0 S1 S0 S1; 3: S1 S0 S1) ----
+		// A pair fetches the NEXT pair's... no: its OWN skip values behind its last two macro-steps (the
+		// previous pair's were consumed by macro-step 10), so one set of skip registers serves the pipeline.
+		const int nB = pl == 0 ? 4 : 3;
+		auto runB = [&](f32x16 (&acc)[2], const f32x16 (&prevAcc)[2], const int q, const bool hasPrev, auto lastTag) __attribute__((always_inline)) {
+			constexpr bool last = decltype(lastTag)::value;  // conv B's last K loop: conv A's fragments stream back in
+			const int pair = pl + 2 * q;
+			const f32x16 e0 = prevAcc[0], e1 = prevAcc[1];
+			const int gyNext = y0 + 2 * pair;
+			rbPipeRun<T, last>(ldsBase + kRbX + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, w, wPtrA, acc, bias, storeRows,
+			    [&](int m, int k) __attribute__((always_inline)) {
+				    if (hasPrev) {
+					    epiB(e0, e1, m, k);
+					    // this pair's own skip values: the registers are free from macro-step 11 on
+					    if (m == 11 && k >= 1 && k < 5) {
+						    const int r = (k - 1) >> 1, gg = ((k - 1) & 1) * 2;
+						    loadSkip(gyNext, x0, r, gg);
+						    loadSkip(gyNext, x0, r, gg + 1);
+					    }
+				    }
+			    });
+			if (hasPrev) {  // (the pair before this one is now in `stg`)
+				stY = y0 + 2 * (pair - 2);
+				stX = x0;
+				stOn = true;
+			}
+		};
+		if (nB == 4) {
+			runB(S0, S1, 0, false, std::false_type{});
+			runB(S1, S0, 1, true, std::false_type{});
+			runB(S0, S1, 2, true, std::false_type{});
+			runB(S1, S0, 3, true, std::true_type{});
+		} else {
+			runB(S1, S0, 0, false, std::false_type{});
+			runB(S0, S1, 1, true, std::false_type{});
+			runB(S1, S0, 2, true, std::true_type{});
+		}
+		epY = y0 + 2 * (pl + 2 * (nB - 1));
+		epX = x0;
+		epOn = true;
+		bias = loadBias(0);
+	}
+	// ---- drain: the last tile's last pair ----
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	storeRows();
+	if (epOn) {
+#pragma unroll
+		for (int m = 3; m < 12; ++m) {
+#pragma unroll
+			for (int k = 0; k < 6; ++k) epiB(S1[0], S1[1], m, k);
+		}
+		stY = epY;
+		stX = epX;
+		stOn = true;
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		storeRows();
+	}
+}
+
 template <typename T>
 void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
-	auto kern = res_block_kernel<T>;
-	static std::atomic<std::uint64_t> ldsDone{0};
-	ensureDynamicLds(reinterpret_cast<const void *>(kern), kRbLds, &ldsDone, "res block");
+	// the pipelined form (epilogues behind the next pair's MFMAs); JU_RES_BLOCK=plain: the plain kernel (tests, A/B).
+	// A slope outside [0, 1] (no model the container accepts has one) also takes the plain kernel.
+	static const bool plainEnv = [] { const char *e = std::getenv("JU_RES_BLOCK"); return e == nullptr || std::string(e) != "pipe"; }();  // (work in progress: opt-in)
+	const bool pipe = !plainEnv && !(q.slope < 0.0f || q.slope > 1.0f) && ablationSkipBits() == 0;
+	auto kern = pipe ? res_block_pipe_kernel<T> : res_block_kernel<T>;
+	const int ldsBytes = pipe ? kRpLds : kRbLds;
+	static std::atomic<std::uint64_t> ldsDone{0}, ldsDonePipe{0};
+	ensureDynamicLds(reinterpret_cast<const void *>(kern), ldsBytes, pipe ? &ldsDonePipe : &ldsDone, "res block");
 	const int cus = currentDeviceCUs();
 	ResBlockParams p{};
 	p.in = q.in;
@@ -825,7 +1188,7 @@ void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.s2 = q.act2 == 1 ? 0.0f : (q.act2 == 2 ? q.slope : 1.0f);
 	p.skip = ablationSkipBits();
 	const int grid = p.numTiles < cus ? p.numTiles : cus;
-	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kRbLds, stream, p);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, p);
 	hipCheckLaunch("res_block");
 }
 

@@ -394,6 +394,34 @@ constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of 
 #ifndef JU_PREBEFORE
 #define JU_PREBEFORE 1
 #endif
+// The fast schedule (FAST instantiations): pre-run units per wave; a wave keeps at least one whole unit.
+// (Measured: 2 -> 356 us per tower, 3 -> 394 us: the third accumulator set pushes the LDS addresses the
+// compiler hoists out of the layer loop into scratch, and each reload waits for memory in front of a
+// fragment read.  JU_PREBEFORE 0 / 1 / 2 with two units: 366 / 352 / 354 us, 0.80 / 0.33 / 0.18 extra sweep
+// passes per layer.)
+#ifndef JU_FAST_PRERUN
+#define JU_FAST_PRERUN 2
+#endif
+
+// The fast schedule's region shape (tower_resident_kernel, FAST): with two pre-run pairs per wave both
+// row-pair parities are left with one or two whole pairs, there is no odd row, and the left and the right
+// edge column are different lanes.  16- and 14-row regions qualify (480x270: 15 x 17 regions of 32 x 16,
+// the last row 14 high), 12-row ones too.
+__host__ __device__ inline bool residentFastShape(int rhv, int rwv) {
+	if ((rhv & 1) || rwv < 2) return false;
+	const int np2 = rhv >> 1;
+	for (int par = 0; par < 2; ++par) {
+		const int first = par ? 1 : 2;
+		int n = 0;
+		for (int k = 0; k < 2; ++k) {
+			const int u = first + 2 * k;
+			if (u < np2 && 2 * u + 3 <= rhv) n = k + 1;
+		}
+		const int mine = (np2 - par + 1) >> 1;  // pairs of this parity
+		if (n != 2 || (mine != 3 && mine != 4)) return false;
+	}
+	return true;
+}
 
 struct ResidentParams {
 	const void *in;           // first layer's input, addressed at image pixel (0,0)
@@ -435,8 +463,14 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // x < 0 ? slope * x : x in f32, and -- the outputs having no free sign bit -- the halo slots
 // carry their epoch beside the values instead of inside them (see publish / fillHalo).  A
 // separate instantiation: the ReLU kernel is byte for byte what it was.
-template <typename T, int VARIANT, bool HEAD, bool TAIL = false, bool LEAKY = false>
+// FAST: every region of the frame has the "deferred" shape (residentTowerFastGeometry: two pre-run
+// pairs and one or two whole pairs per wave, no odd row, at least two columns) -- the instantiation
+// holds ONLY that schedule: epilogues behind the next unit's MFMAs, edges published from the
+// epilogues.  The general schedule below it serves every other geometry (and LeakyReLU models,
+// calibration, the ablation variants) and is what it was.
+template <typename T, int VARIANT, bool HEAD, bool TAIL = false, bool LEAKY = false, bool FAST = false>
 __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
+	static_assert(!FAST || (!LEAKY && (VARIANT == 0 || VARIANT == 4) && (JU_FAST_PRERUN == 2 || JU_FAST_PRERUN == 3)), "the fast schedule is built for the product only");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	// (variants 1 .. 3 are bit masks; 4, 5, 8 are NOT -- round 2 tested `VARIANT & 1` and ran the
 	// calibration build, variant 5, without the halo exchange: its maxima drifted by up to 10 %)
@@ -571,6 +605,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 
 	// VARIANT 4 (diagnostic build only): per-wave cycle sums of the phases below
 	u64 prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	u64 extraPasses = 0;  // VARIANT 4: sweep passes after the first
 	float calibMax = 0.f;  // VARIANT 5: largest post-ReLU output of the current layer (this lane)
 	auto stamp = [&]() __attribute__((always_inline)) -> u64 {
 		if constexpr (VARIANT == 4) {
@@ -600,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// product's schedule (accumulators kept across the sweep, registers refilled behind MFMAs, asm
 	// fragment reads under its register pressure) loses or corrupts nothing.
 	constexpr bool kPlain = VARIANT == 8;
-	constexpr int kPreRun = kPlain ? 0 : JU_PRERUN;
+	constexpr int kPreRun = kPlain ? 0 : FAST ? JU_FAST_PRERUN : JU_PRERUN;
 	constexpr int kPreBefore = kPlain ? 0 : JU_PREBEFORE;  // how many of them run BEFORE the halo loads are issued
 	f32x16 accPre0[2], accPre1[2], accPre2[2];  // (separate objects: an array indexed by the slot would live in scratch)
 	static_assert(kPreRun >= 0 && kPreRun <= 3, "at most three interior units per wave");
@@ -631,6 +666,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		const int u = preFirst + 2 * k;
 		if (u < np2 && 2 * u + 3 <= rhv) nPre = k + 1;
 	}
+	if constexpr (FAST && kPreRun == 3) {
+		// (one whole unit stays: the next layer's weights stream behind it)
+		const int mine = (np2 - rp + 1) >> 1;
+		nPre = nPre < mine - 1 ? nPre : mine - 1;
+	}
 	const int preEnd = preFirst + 2 * nPre;  // first unit of this wave's parity at or after preFirst that is NOT pre-run
 	auto isPre = [&](int u) __attribute__((always_inline)) { return u >= preFirst && u < preEnd; };
 	// next unit of this wave after `u` that runs whole (not pre-run), or -1
@@ -641,13 +681,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	};
 	const int firstWhole = isPre(rp) ? (preEnd < np2 ? preEnd : -1) : (rp < np2 ? rp : -1);
 	const bool streamsInUnit = (firstWhole >= 0 || mySingle) && !kNoMfma && !kPlain;  // the next layer's weights stream behind the last unit
-#ifndef JU_NO_DEFER
-	constexpr bool kDefer = kPreRun == 2 && !kNoMfma && !LEAKY && VARIANT != 5;
-#else
-	constexpr bool kDefer = false;
-#endif
-	// (see finishLayer) two pre-run pairs, then one or two whole pairs, no odd row
-	const bool deferShape = nPre == 2 && !mySingle && firstWhole >= 0 && (nextWhole(firstWhole) < 0 || nextWhole(nextWhole(firstWhole)) < 0);
+	constexpr bool kDefer = FAST;
+	const bool deferShape = residentFastShape(rhv, rwv);  // (region-uniform: a function of the region's size only)
+	if constexpr (FAST) {
+		if (!deferShape) {  // (the host chose the wrong instantiation: fail loudly, never compute something else)
+			if (tid == 0) __hip_atomic_store((gu32 *)p.error, 0x6f0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			return;
+		}
+	}
 
 	// KIND 0: pre-run (accumulator init + positions 0..3); 1: finish (positions 4..11 +
 	// epilogue); 2: whole unit.  `primed`: the first step's fragments are already in flight
@@ -660,6 +701,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// last two MFMAs), instead of as ~560 exposed cycles between the units.  Same arithmetic, same
 	// order per element.  EPI false: this unit leaves its own epilogue to its successor.
 	const bool lanesValid = px < rwv;
+	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
+	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * (LEAKY ? 2 : 1) * kResMailSlots * 16), 0x00020000);
+	constexpr int kSc1 = 16;  // cache-policy bit of sc1 (write-through store / L2-bypassing load)
+	// (Measured and dropped: publishing the edges from the epilogue groups themselves -- 8-byte stores of
+	// the edge lanes, no cooperative publish after the barrier.  Bytes equal, 434 against 361 us: a
+	// sparse write-through store costs ~90 cycles of issue wherever it stands
+	// (tools/probes/mfma_valu_overlap.hip: the chip accepts ~13 such instructions per clock), and the
+	// epilogues need 36 per wave and layer where the cooperative publish needs 4 dense ones.)
 	Vec4<T> rvNext[2][4];  // residual of the unit whose epilogue is pending
 	auto epiValue = [&](auto resTag, const f32x16 &a, const int g, const Vec4<T> &rv, float(&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -717,6 +767,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		// knows of and are therefore never too lenient); its successor (DEF) consumes them.
 		constexpr bool kFetchRes = !EPI && residual && KIND != 0;
 		const int dra = 1 + 2 * dunit;
+		// (by value, constant indices: an element read of `dacc[j >> 2]` is a dynamic index until the loops
+		// are unrolled, by when the loads had been merged into partial vectors and the array stayed in scratch)
+		const f32x16 dacc0 = dacc[0], dacc1 = dacc[1];
 		float dv[4];
 		unsigned dlo = 0, dhi = 0;
 		if (!kNoMfma) {
@@ -776,7 +829,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 						if (j < 8) {
 							const int r = j >> 2, g = j & 3;
 							if (k < 4) {
-								dv[k] = dacc[r][4 * g + k];
+								dv[k] = (r ? dacc1 : dacc0)[4 * g + k];
 								if constexpr (residual) {
 									dv[k] += static_cast<float>(rvNext[r][g][k]);
 									asm volatile("" : "+v"(dv[k]));  // (keeps the four adds scalar and in their slots)
@@ -901,27 +954,53 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const bool streamW) __attribute__((always_inline)) {
 		const int afterPre = firstWhole >= 0 ? firstWhole : (mySingle ? np2 : -1);
 		if constexpr (kDefer) {
-			// The product's shape (two pre-run pairs, then one or two whole pairs: every wave of a
+			// The fast schedule's shape (two pre-run pairs, then one or two whole pairs: every wave of a
 			// 16- or 14-row region): each unit's epilogue runs behind its successor's MFMAs, only the
 			// last one is exposed.  The accumulators rotate through the two pre-run sets -- a set is
 			// free again once its epilogue has run, one segment later.
-			if (deferShape) {
+			// In every shape the LAST unit accumulates into accPre0 and leaves its epilogue too: that one runs
+			// once, below the branches (emitted per branch, the identical tails are merged by the optimiser into
+			// one that picks its accumulator array through a pointer -- and the arrays then live in scratch).
+			{
 				using Y = std::true_type;
 				using N = std::false_type;
 				const int ua = firstWhole, ub = nextWhole(firstWhole);
+				int lastUnit = ua;
 				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre0, layer, preFirst, false, preFirst + 2, true, N{}, N{}, accPre0, 0, N{});
-				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, true, ua, false, N{}, Y{}, accPre0, preFirst, N{});
-				if (ub >= 0) {
-					unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, ub, false, N{}, Y{}, accPre1, preFirst + 2, N{});
-					if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre1, layer, ub, true, -1, false, Y{}, Y{}, accPre0, ua, Y{});
-					else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre1, layer, ub, true, -1, false, N{}, Y{}, accPre0, ua, Y{});
+				if (kPreRun == 3 && nPre == 3) {
+					// (16-row regions: three pre-run pairs, one whole pair)
+					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, true, preFirst + 4, true, N{}, Y{}, accPre0, preFirst, N{});
+					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre2, layer, preFirst + 4, true, ua, false, N{}, Y{}, accPre1, preFirst + 2, N{});
+					if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, Y{}, Y{}, accPre2, preFirst + 4, N{});
+					else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, N{}, Y{}, accPre2, preFirst + 4, N{});
 				} else {
-					if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, Y{}, Y{}, accPre1, preFirst + 2, Y{});
-					else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, N{}, Y{}, accPre1, preFirst + 2, Y{});
+					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, true, ua, false, N{}, Y{}, accPre0, preFirst, N{});
+					if (ub >= 0) {
+						// (the third set takes the first whole pair, so that the last one finds accPre0 free)
+						unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre2, layer, ua, true, ub, false, N{}, Y{}, accPre1, preFirst + 2, N{});
+						if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ub, true, -1, false, Y{}, Y{}, accPre2, ua, N{});
+						else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ub, true, -1, false, N{}, Y{}, accPre2, ua, N{});
+						lastUnit = ub;
+					} else {
+						if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, Y{}, Y{}, accPre1, preFirst + 2, N{});
+						else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, N{}, Y{}, accPre1, preFirst + 2, N{});
+					}
 				}
-				return;
+				// the one exposed epilogue of the layer (its residual was fetched behind the unit's last MFMAs)
+				const u64 te0 = stamp();
+				const int ra = 1 + 2 * lastUnit;
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						float v[4];
+						epiValue(resTag, accPre0[r], g, rvNext[r][g], v);
+						if (lanesValid) epiStore(outTag, ra + r, g, v);
+					}
+				}
+				prof[6] += stamp() - te0;
 			}
-		}
+		} else {
 		auto slot = [&](f32x16(&acc)[2], const int k) __attribute__((always_inline)) {
 			if (k < nPre) {
 				const bool nextIsPre = k + 1 < nPre;
@@ -948,15 +1027,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			if (streamW) unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, std::true_type{}, std::false_type{}, acc, 0, std::true_type{});
 			else unitSeg(R1{}, KWhole{}, resTag, inTag, outTag, acc, layer, np2, primed, -1, false, std::false_type{}, std::false_type{}, acc, 0, std::true_type{});
 		}
+		}
 	};
 
 	// ------------------------------------------------------------------------
 	// edge ring -> mailbox (publish) and neighbours' mailboxes -> halo ring
 	// ------------------------------------------------------------------------
-	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
-	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * (LEAKY ? 2 : 1) * kResMailSlots * 16), 0x00020000);
-	constexpr int kSc1 = 16;  // cache-policy bit of sc1 (write-through store / L2-bypassing load)
 	// Self-validating slots: every tower output is post-ReLU (>= 0), so the sign bit
 	// of each of the 8 values in a 16-byte slot is free.  EVERY dword carries the same
 	// 2-bit epoch e = (number of writes to this slot so far) & 3 in its two sign bits:
@@ -1157,6 +1233,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			__builtin_amdgcn_s_sleep(1);
 			loadPass();
 			checkPass();
+			if constexpr (VARIANT == 4) extraPasses += 1;
 		}
 		__syncthreads();
 		return *failFlag == 0;
@@ -1231,7 +1308,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 		const u64 t5 = stamp();
 		prof[0] += t5 - t4;
-		prof[1] += t4 - t3;
+		prof[1] += (VARIANT == 4 && FAST) ? extraPasses * 1000 : t4 - t3;  // (fast schedule: sweep passes beyond the first, x 1000)
+		extraPasses = 0;
 		prof[2] += t1 - t0;
 		prof[3] += t2 - t1;
 		prof[4] += t3 - t2;
@@ -1323,9 +1401,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	}
 }
 
-template <typename T, int VARIANT, bool HEAD, bool TAIL = false, bool LEAKY = false>
+template <typename T, int VARIANT, bool HEAD, bool TAIL = false, bool LEAKY = false, bool FAST = false>
 void launchResidentT(const ResidentParams &p, hipStream_t stream) {
-	auto kern = tower_resident_kernel<T, VARIANT, HEAD, TAIL, LEAKY>;
+	auto kern = tower_resident_kernel<T, VARIANT, HEAD, TAIL, LEAKY, FAST>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), kResLds, &ldsDone, "resident tower");
 	// (g_ResidentFault > 0, tests only: some regions are never computed, their neighbours'
@@ -1360,6 +1438,11 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 }
 
 void setTowerVariant(int v) { g_TowerVariant = v; }
+// the fast schedule where the geometry allows it (default); 0 (JU_TOWER_FAST=0 or the tests' switch): the
+// general schedule everywhere
+static std::atomic<int> g_TowerFast{[] { const char *e = std::getenv("JU_TOWER_FAST"); return (e != nullptr && e[0] == '0') ? 0 : 1; }()};
+void setResidentTowerFast(int on) { g_TowerFast = on ? 1 : 0; }
+bool residentTowerFast() { return g_TowerFast.load() != 0; }
 int towerVariant() { return g_TowerVariant; }
 void setResidentFault(int n) { g_ResidentFault = n; }
 int residentFaultForTests() { return g_ResidentFault; }
@@ -1372,6 +1455,12 @@ bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH) 
 	*GY = gy;
 	*RH = (H + gy - 1) / gy;  // <= kResMaxRH, balances the last row of regions
 	return true;
+}
+
+bool residentTowerFastGeometry(int H, int W, int GX, int GY, int RH) {
+	const int lastH = H - (GY - 1) * RH, lastW = W - (GX - 1) * kResRW;
+	return residentFastShape(RH, kResRW) && residentFastShape(lastH, kResRW) && residentFastShape(RH, lastW) &&
+	       residentFastShape(lastH, lastW);
 }
 
 std::size_t residentMailboxBytes(int GX, int GY, bool leaky) {
@@ -1412,11 +1501,18 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	if ((p.nLayers & 1) != (p.hasHead ? 1 : 0)) {
 		throw std::invalid_argument("resident tower: layer count must be 2*blocks (+1 with a head)");
 	}
+	// the fast schedule where every region has its shape (JU_TOWER_FAST=0: the general one, for A/B runs)
+	const bool fast = residentTowerFast() && !q.leaky && residentTowerFastGeometry(p.H, p.W, p.GX, p.GY, p.RH);
 #ifdef JU_TOWER_DEV  // developer builds: the bf16 ReLU instantiations only (compile time)
 	if (q.leaky || dt == kF16 || !p.hasHead) throw std::invalid_argument("resident tower: developer build");
-	if (p.tailW1 != nullptr) launchResidentT<bf16, 0, true, true>(p, stream);
-	else if (g_TowerVariant == 8) launchResidentT<bf16, 8, true>(p, stream);
-	else if (g_TowerVariant == 4) launchResidentT<bf16, 4, true>(p, stream);
+	if (p.tailW1 != nullptr) {
+		if (fast) launchResidentT<bf16, 0, true, true, false, true>(p, stream);
+		else launchResidentT<bf16, 0, true, true>(p, stream);
+	} else if (g_TowerVariant == 8) launchResidentT<bf16, 8, true>(p, stream);
+	else if (g_TowerVariant == 4) {
+		if (fast) launchResidentT<bf16, 4, true, false, false, true>(p, stream);
+		else launchResidentT<bf16, 4, true>(p, stream);
+	} else if (fast) launchResidentT<bf16, 0, true, false, false, true>(p, stream);
 	else launchResidentT<bf16, 0, true>(p, stream);
 	return;
 #else
@@ -1441,17 +1537,28 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 		return;
 	}
 	if (!p.hasHead) {
-		if (dt == kF16) launchResidentT<f16, 0, false>(p, stream);
-		else launchResidentT<bf16, 0, false>(p, stream);
+		if (fast) {
+			if (dt == kF16) launchResidentT<f16, 0, false, false, false, true>(p, stream);
+			else launchResidentT<bf16, 0, false, false, false, true>(p, stream);
+		} else {
+			if (dt == kF16) launchResidentT<f16, 0, false>(p, stream);
+			else launchResidentT<bf16, 0, false>(p, stream);
+		}
 		return;
 	}
 	if (p.tailW1 != nullptr) {  // fused tail: product kernel only (the ablation variants keep the split)
-		if (dt == kF16) launchResidentT<f16, 0, true, true>(p, stream);
-		else launchResidentT<bf16, 0, true, true>(p, stream);
+		if (fast) {
+			if (dt == kF16) launchResidentT<f16, 0, true, true, false, true>(p, stream);
+			else launchResidentT<bf16, 0, true, true, false, true>(p, stream);
+		} else {
+			if (dt == kF16) launchResidentT<f16, 0, true, true>(p, stream);
+			else launchResidentT<bf16, 0, true, true>(p, stream);
+		}
 		return;
 	}
 	if (dt == kF16) {
 		if (g_TowerVariant == 8) launchResidentT<f16, 8, true>(p, stream);
+		else if (fast) launchResidentT<f16, 0, true, false, false, true>(p, stream);
 		else launchResidentT<f16, 0, true>(p, stream);
 		return;
 	}
@@ -1460,12 +1567,18 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 	case 1: launchResidentT<bf16, 1, true>(p, stream); break;
 	case 2: launchResidentT<bf16, 2, true>(p, stream); break;
 	case 3: launchResidentT<bf16, 3, true>(p, stream); break;
-	case 4: launchResidentT<bf16, 4, true>(p, stream); break;
+	case 4:
+		if (fast) launchResidentT<bf16, 4, true, false, false, true>(p, stream);
+		else launchResidentT<bf16, 4, true>(p, stream);
+		break;
 	case 5:  // calibration: per-layer output maxima of this frame in debug[0 .. nLayers)
 		(void)hipMemsetAsync(p.debug, 0, static_cast<std::size_t>(p.nLayers) * sizeof(unsigned), stream);
 		launchResidentT<bf16, 5, true>(p, stream);
 		break;
-	default: launchResidentT<bf16, 0, true>(p, stream); break;
+	default:
+		if (fast) launchResidentT<bf16, 0, true, false, false, true>(p, stream);
+		else launchResidentT<bf16, 0, true>(p, stream);
+		break;
 	}
 #endif
 }

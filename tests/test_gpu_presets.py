@@ -203,6 +203,8 @@ def test_resident_tower_schedule_does_not_change_the_bytes(dtype, monkeypatch):
     from helpers import small_config
     cases.append((small_config(frame_height=34, frame_width=50, gen_blocks=3), 4))
     cases.append((small_config(frame_height=17, frame_width=33, gen_blocks=2), 3))
+    # a small frame whose regions all have the fast schedule's shape (rows 16 / 16 / 14, columns 32 / 32 / 6)
+    cases.append((small_config(frame_height=46, frame_width=70, gen_blocks=3), 4))
     # the LEAKY instantiation (`activation: lrelu`: 16-bit epoch beside the values, f32 LeakyReLU)
     cases.append((M.PRESETS["psp-quality-lrelu"], 3))
     cases.append((small_config(frame_height=34, frame_width=50, gen_blocks=3, gen_activation="lrelu",
@@ -216,18 +218,27 @@ def test_resident_tower_schedule_does_not_change_the_bytes(dtype, monkeypatch):
         for tail_mode in ("tower", "fused"):
             monkeypatch.setenv("JU_TAIL", tail_mode)
             outs = {}
-            for variant in (0, 8):
-                lib.ju_debug_set(b"tower_variant", variant)
+            # 0: the product (the FAST instantiation where every region has its shape: epilogues behind the
+            # next unit's MFMAs), "general": the general schedule forced, 8: the plain schedule
+            fast_expected = cfg.gen_activation == "relu" and (cfg.frame_height, cfg.frame_width) in ((270, 480), (46, 70))
+            for variant in (0, "general", 8):
+                lib.ju_debug_set(b"tower_variant", 8 if variant == 8 else 0)
+                lib.ju_debug_set(b"tower_fast", 0 if variant == "general" else 1)
                 try:
                     rt = R.Runtime(blob, 0, dtype)
-                    assert rt.stat("resident_tower") == 1 and rt.stat("tower_variant") == variant
+                    assert rt.stat("resident_tower") == 1 and rt.stat("tower_variant") == (8 if variant == 8 else 0)
+                    assert rt.stat("tower_fast") == (1 if fast_expected and variant != "general" else 0), (variant, cfg.frame_height)
                     outs[variant] = [rt.process_image(f).copy() for f in frames]
                     outs[(variant, "state")] = rt.read_tensor("state").copy()
                     outs[(variant, "trunk")] = rt.read_tensor("trunk").copy()
                     rt.close()
                 finally:
                     lib.ju_debug_set(b"tower_variant", 0)
+                    lib.ju_debug_set(b"tower_fast", 1)
             key = (cfg.frame_height, cfg.frame_width, cfg.gen_activation, tail_mode)
+            assert np.array_equal(outs[("general", "state")], outs[(0, "state")]), key
+            for a, b in zip(outs[0], outs["general"]):
+                assert np.array_equal(a, b), key
             if tail_mode == "fused" or cfg.gen_activation != "relu":   # (lrelu: no fused-tail form, the trunk is written)
                 assert np.array_equal(outs[(0, "trunk")], outs[(8, "trunk")]), key
             assert np.array_equal(outs[(0, "state")], outs[(8, "state")]), key

@@ -24,12 +24,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-enum Kind { kNone, kCvtPk, kPkMax, kAddF32, kPkAddF32, kMov64, kDsWrite64, kDsRead128, kLshl, kSaveExec };
+enum Kind { kNone, kCvtPk, kPkMax, kAddF32, kPkAddF32, kMov64, kDsWrite64, kDsRead128, kLshl, kSaveExec, kStore4, kStore64, kStore4Wb, kStoreEvery8 };
 static const char *kNames[] = {"(nothing)", "v_cvt_pk_bf16_f32", "v_pk_max_i16", "v_add_f32", "v_pk_add_f32", "v_mov_b64",
-    "ds_write_b64", "ds_read_b128 (+wait at the end)", "v_lshlrev_b32", "s_and_saveexec + s_or exec"};
+    "ds_write_b64", "ds_read_b128 (+wait at the end)", "v_lshlrev_b32", "s_and_saveexec + s_or exec",
+    "buffer_store_dwordx2 sc1, 4 lanes", "buffer_store_dwordx2 sc1, 64 lanes", "buffer_store_dwordx2 (no sc1), 4 lanes", "buffer_store_dwordx2 sc1, 4 lanes, every 8th MFMA"};
 
 template <int KIND, int N>
-__global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *ticks, int iters) {
+__global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *ticks, int iters, void *scratch) {
 	__shared__ __attribute__((aligned(16))) unsigned char lds[65536];
 	const int lane = threadIdx.x & 63;
 	bf16x8 a, b;
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *
 	unsigned ldsAddr = (threadIdx.x * 16) & 0xffff;
 	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 	u32x4 rd = {};
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(scratch, 0, 0x7fffffff, 0x00020000);
 	unsigned long long t0, t1;
 	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
 	for (int it = 0; it < iters; ++it) {
@@ -61,6 +63,13 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *
 				if constexpr (KIND == kDsWrite64) asm volatile("ds_write_b64 %0, %1" ::"v"(ldsAddr), "v"(w) : "memory");
 				if constexpr (KIND == kDsRead128) asm volatile("ds_read_b128 %0, %1" : "=v"(rd) : "v"(ldsAddr) : "memory");
 				if constexpr (KIND == kLshl) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(u0) : "v"(u1));
+				if constexpr (KIND == kStore4 || KIND == kStore64 || KIND == kStore4Wb || KIND == kStoreEvery8) {
+					if (KIND != kStoreEvery8 || m == 7) {
+						const bool on = KIND == kStore64 || (lane & 31) == 0 || (lane & 31) == 31;
+						const unsigned off = (blockIdx.x * 256 + threadIdx.x) * 8 + ((it * 8 + m) & 63) * 2048 * 256;
+						if (on) __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, off & 0x7ffffff, 0, KIND == kStore4Wb ? 0 : 16);
+					}
+				}
 				if constexpr (KIND == kSaveExec) asm volatile("s_and_saveexec_b64 s[40:41], vcc\n\ts_or_b64 exec, exec, s[40:41]" ::: "s40", "s41");
 			}
 			__builtin_amdgcn_sched_barrier(0);
@@ -74,15 +83,17 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *
 	if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
+static void *g_scratch = nullptr;
+
 template <int KIND, int N>
 double run(float *out, unsigned long long *ticks, int iters) {
-	hipLaunchKernelGGL((probe<KIND, N>), dim3(256), dim3(256), 0, 0, out, ticks, iters);
+	hipLaunchKernelGGL((probe<KIND, N>), dim3(256), dim3(256), 0, 0, out, ticks, iters, g_scratch);
 	CHECK(hipDeviceSynchronize());
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0));
 	CHECK(hipEventCreate(&e1));
 	CHECK(hipEventRecord(e0));
-	hipLaunchKernelGGL((probe<KIND, N>), dim3(256), dim3(256), 0, 0, out, ticks, iters);
+	hipLaunchKernelGGL((probe<KIND, N>), dim3(256), dim3(256), 0, 0, out, ticks, iters, g_scratch);
 	CHECK(hipEventRecord(e1));
 	CHECK(hipDeviceSynchronize());
 	float ms = 0;
@@ -104,6 +115,7 @@ int main() {
 	unsigned long long *ticks;
 	CHECK(hipMalloc(&out, 256 * 256 * 4));
 	CHECK(hipMalloc(&ticks, 256 * 8));
+	CHECK(hipMalloc(&g_scratch, 256u << 20));
 	const int iters = 20000;
 	const double base = run<kNone, 0>(out, ticks, iters);
 	std::printf("one wave per SIMD, v_mfma_f32_32x32x16_bf16 back to back: %.2f ns per MFMA (= 32 cycles at %.2f GHz)\n", base, 32.0 / base);
@@ -117,5 +129,9 @@ int main() {
 	sweep<kDsWrite64>(out, ticks, iters, base);
 	sweep<kDsRead128>(out, ticks, iters, base);
 	sweep<kSaveExec>(out, ticks, iters, base);
+	sweep<kStore4>(out, ticks, iters, base);
+	sweep<kStore64>(out, ticks, iters, base);
+	sweep<kStore4Wb>(out, ticks, iters, base);
+	sweep<kStoreEvery8>(out, ticks, iters, base);
 	return 0;
 }
