@@ -644,6 +644,7 @@ struct ResBlockParams {
 	int tilesX, numTiles;
 	float s1, s2;          // activation multipliers (fbActS)
 	int skip;              // timing ablation (JU_FB_SKIP, developer only)
+	unsigned long long *prof;  // developer builds (-DJU_RB_PROF): per-wave cycle sums of workgroup 0
 };
 
 template <typename T>
@@ -838,9 +839,14 @@ static_assert(kRpLds <= 160 * 1024, "res block tile (pipelined)");
 // fragments it used), so one set of 36 serves both convolutions: 144 registers instead of 288.
 template <typename T, bool STREAM, typename FS, typename FB>
 __device__ __forceinline__ void rbPipeRun(unsigned rowAddr, const unsigned (&colOff)[3], const unsigned (&colSwz)[3], int hh,
-    Vec8<T> (&w)[36], const unsigned char *nextW, f32x16 (&acc)[2], const f32x16 &first, FS &&atStart, FB &&behind) {
+    Vec8<T> (&w)[36], const __amdgpu_buffer_rsrc_t nextW, unsigned nextLane, unsigned nextBase, f32x16 (&acc)[2],
+    const f32x16 &first, FS &&atStart, FB &&behind) {
 	using P = FbPair<T, 4, 128>;
+	typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 	Vec8<T> fb[2][4];
+	// (opaque: with every K loop of the tile unrolled, the 12 fragment addresses of each are loop-invariant
+	// over the tiles and the compiler keeps all 132 of them in registers -- and spills)
+	asm volatile("" : "+s"(rowAddr));
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	__builtin_amdgcn_sched_barrier(0);
 	atStart();
@@ -867,15 +873,19 @@ __device__ __forceinline__ void rbPipeRun(unsigned rowAddr, const unsigned (&col
 				__builtin_amdgcn_sched_barrier(0);
 			}
 			acc[r] = mfma32(w[(dy * 3 + dx) * 4 + ks], fb[set][need], (m == 0 && dy == 0) ? first : acc[r]);
+			__builtin_amdgcn_sched_barrier(0);  // (the MFMA first: what follows runs in its shadow, not in front of it)
 			if (more && k < 4) P::template issue<0>(fb[set ^ 1], rowAddr, colOff, colSwz, hh, m + 1, k);
 			behind(m, k);
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		if constexpr (STREAM) {
+			// (buffer loads: lane offset in ONE register, the fragment's offset scalar -- flat loads 1 KiB
+			// apart are out of immediate range and cost a 64-bit address each)
 #pragma unroll
 			for (int dy = 0; dy < 3; ++dy) {
 				const int f = (dy * 3 + dx) * 4 + ks;
-				w[f] = *reinterpret_cast<const Vec8<T> *>(nextW + (size_t)f * 1024);
+				const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(nextW, nextLane, nextBase + f * 1024, 0);
+				w[f] = __builtin_bit_cast(Vec8<T>, v);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 		}
@@ -885,6 +895,8 @@ __device__ __forceinline__ void rbPipeRun(unsigned rowAddr, const unsigned (&col
 template <typename T>
 __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+	typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
 	const int tid = threadIdx.x, lane = tid & 63, px = lane & 31, hh = lane >> 5;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: tile and pair coordinates stay in SGPRs)
 	const int cb = wave & 1, pl = wave >> 1;  // cout block, pair lane (pairs pl, pl + 2, ...)
@@ -894,14 +906,32 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 	unsigned char *smX = smem, *smT = smem + kRbX;
 	unsigned char *stage = smem + kRbX + kRbT + wave * kRpStageWave;
 	float *biasLds = reinterpret_cast<float *>(smem + kRbX + kRbT + 4 * kRpStageWave);
+	// Global memory through buffer instructions: the lane's part of an address is ONE loop-invariant
+	// 32-bit register, the tile / row / fragment part is scalar (a tensor is < 2 GiB).
+	const __amdgpu_buffer_rsrc_t rsrcWa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w1), 0, 2 * 36 * 1024, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rsrcWb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w2), 0, 2 * 36 * 1024, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rsrcIn = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, 0x7ffffff0, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rsrcOut = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+	const unsigned wLane = static_cast<unsigned>(lane) * 16u;
+	const unsigned wBase = static_cast<unsigned>(cb) * (36u * 1024u);
 
-	// ONE set of 36 fragments: conv A's, replaced by conv B's behind conv A's last K loop and back behind
-	// conv B's last one (72 KB per workgroup and phase from L2 -- the resident tower's rate)
-	Vec8<T> w[36];
-	const unsigned char *wPtrA = static_cast<const unsigned char *>(p.w1) + (size_t)cb * (36 * 1024) + lane * 16;
-	const unsigned char *wPtrB = static_cast<const unsigned char *>(p.w2) + (size_t)cb * (36 * 1024) + lane * 16;
+	// Both convolutions' fragments for the whole launch, in accumulation registers (an MFMA reads them there;
+	// left alone the compiler keeps part of them in VGPRs and parks addresses in the AGPRs instead, one copy
+	// per use).  (One set of 36 with the other convolution's streamed in behind the last K loop of each phase
+	// -- the resident tower's way -- was measured: 144 KB of requests per workgroup and phase fill the CU's
+	// 64 B/clk vector-memory path for a whole K loop, the streaming loops took 4900-5900 cycles instead of
+	// 3450.)
+	Vec8<T> wa[36], wb[36];
 #pragma unroll
-	for (int f = 0; f < 36; ++f) w[f] = *reinterpret_cast<const Vec8<T> *>(wPtrA + (size_t)f * 1024);
+	for (int f = 0; f < 36; ++f) {
+		wa[f] = __builtin_bit_cast(Vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrcWa, wLane, wBase + f * 1024, 0));
+		wb[f] = __builtin_bit_cast(Vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrcWb, wLane, wBase + f * 1024, 0));
+	}
+#pragma unroll
+	for (int f = 0; f < 36; ++f) {
+		asm volatile("" : "+a"(wa[f]));
+		asm volatile("" : "+a"(wb[f]));
+	}
 	if (tid < 64) biasLds[tid] = p.b1[tid];
 	else if (tid < 128) biasLds[tid] = p.b2[tid - 64];
 	// this lane's 16 accumulator values of a row: channel cb * 32 + 8 g + 4 hh + i at index 4 g + i
@@ -920,13 +950,66 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 #pragma unroll
 	for (int g = 0; g < 4; ++g) tOff[g] = px * 128 + ((static_cast<unsigned>(cb * 4 + g) ^ fbSwz<128>(px)) << 4) + hh * 8;
 	const bool stageLane = px < kFbOutW;
+	// staging tile: write offset of group g (+ r * kRpStageRow), read-back offset of chunk it (+ r * kRpStageRow)
+	unsigned stW[4];
+#pragma unroll
+	for (int g = 0; g < 4; ++g) stW[g] = px * 64 + ((static_cast<unsigned>(g) ^ (static_cast<unsigned>(px) & 3u)) << 4) + hh * 8;
+	const unsigned stR = (lane >> 2) * 64 + ((lane & 3) << 4);
+	// output: lane part of chunk `it` (pixel pi = it * 16 + lane / 4 of the row)
+	unsigned outLane[2];
+	int outPi[2];
+#pragma unroll
+	for (int it = 0; it < 2; ++it) {
+		const int pi = it * 16 + (lane >> 2);
+		const unsigned chunk = static_cast<unsigned>(lane & 3) ^ (static_cast<unsigned>(pi) & 3u);
+		outLane[it] = static_cast<unsigned>(pi * 64 + cb * 32) * 2u + chunk * 16u;
+		outPi[it] = pi < kFbOutW ? pi : 0x40000000;  // (never below a column limit)
+	}
 
+	// X tile staging.  An interior tile (no pixel outside the image: all but the frame's edge tiles) is 19-20
+	// LDS-DMA instructions per wave whose per-lane source offsets relative to the tile's first pixel do not
+	// depend on the tile: computed once (xOff), the tile's origin is the scalar offset -- the per-instruction
+	// address arithmetic of the general path (divisions by 34, four bound tests, a 64-bit multiply-add: ~60
+	// instructions each) was 5 k cycles per tile, 14 % of the kernel.
+	constexpr int kXPix = kRbXR * kFbW;
+	constexpr int kXInstr = (kXPix + 7) / 8;        // 77: 8 pixels (1 KiB) per wave-instruction
+	constexpr int kXPerWave = (kXInstr + 3) / 4;    // 20
+	unsigned xOff[kXPerWave];
+#pragma unroll
+	for (int n = 0; n < kXPerWave; ++n) {
+		const int q = (wave + 4 * n) * 8 + (lane >> 3);
+		const int r = q / kFbW, k = q - r * kFbW;
+		const unsigned c = static_cast<unsigned>(lane & 7) ^ fbSwz<128>(k);
+		xOff[n] = static_cast<unsigned>(r * p.inPitch + k) * 128u + c * 16u;
+	}
+	const bool xLastLane = (kXInstr - 1) * 8 + (lane >> 3) < kXPix;  // the 77th instruction covers 4 pixels
+	// instruction n of this wave for the interior tile whose first X pixel is at byte offset `so`
+	auto stageXOne = [&](unsigned so, int n) __attribute__((always_inline)) {
+		const int i = wave + 4 * n;
+		auto dst = (__attribute__((address_space(3))) void *)(smX + i * 1024);
+		if (i < kXInstr - 1) {
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcIn, dst, 16, xOff[n], so, 0, 0);
+		} else if (i == kXInstr - 1) {
+			if (xLastLane) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcIn, dst, 16, xOff[n], so, 0, 0);
+		}
+	};
+	auto tileIsBorder = [&](int tile) __attribute__((always_inline)) {
+		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
+		return y0 - 2 < 0 || y0 + kRbTH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
+	};
 	auto stageX = [&](int tile) {
 		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
 		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
 		constexpr int NPIX = kRbXR * kFbW;
 		constexpr int NINSTR = (NPIX + 7) / 8;  // 8 pixels (1 KiB) per wave-instruction
 		const bool border = y0 - 2 < 0 || y0 + kRbTH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
+		if (!border) {
+			const unsigned so = static_cast<unsigned>((y0 - 2) * p.inPitch + (x0 - 2)) * 128u;
+#pragma unroll
+			for (int n = 0; n < kXPerWave; ++n) stageXOne(so, n);
+			return;
+		}
 		for (int i = wave; i < NINSTR; i += 4) {
 			const int q = i * 8 + (lane >> 3);
 			const int r = q / kFbW, k = q - r * kFbW;
@@ -943,113 +1026,146 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 
 	// ---- pipeline state ----
 	f32x16 S0[2], S1[2];       // the two accumulator sets
-	Vec4<T> resv[2][4];        // skip values of the conv B pair whose epilogue is pending
-	uint4 stg[4];              // a finished pair's two rows, transposed, on their way to global memory
+	u32x2r resv[2][4];         // skip values (4 x 16 bit) of the conv B pair whose epilogue is pending
+	u32x4w stg0 = {}, stg1 = {}, stg2 = {}, stg3 = {};  // a finished pair's two rows x two chunks, transposed, on their way out
 	int stY = 0, stX = 0;      // ... and where they go: image row of its first row, first column
 	bool stOn = false;
 	int epY = 0, epX = 0;      // the pending conv B pair's first image row / first column
 	bool epOn = false;         // a conv B epilogue is pending (from the previous tile)
 
-	const auto noStart = []() __attribute__((always_inline)) {};
-	const auto noBehind = [](int, int) __attribute__((always_inline)) {};
-	// stores of the pair in `stg` (behind a K loop's opening wait: the read-back has landed)
+	// stores of the pair in stg0..3 (behind a K loop's opening wait: the read-back has landed)
 	auto storeRows = [&]() __attribute__((always_inline)) {
 		if (stOn) {
-			unsigned char *outp = static_cast<unsigned char *>(p.out);
+			const int lim = p.W - stX;  // columns of the tile inside the image
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
 				const int gy = stY + r;
-#pragma unroll
-				for (int it = 0; it < 2; ++it) {
-					const int pi = it * 16 + (lane >> 2);
-					const unsigned slot = static_cast<unsigned>(lane & 3);
-					const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & 3u);
-					const int gx = stX + pi;
-					if (pi < kFbOutW && gy < p.H && gx < p.W) {
-						*reinterpret_cast<uint4 *>(outp + (((size_t)gy * p.outPitch + gx) * 64 + cb * 32) * 2 + chunk * 16) = stg[r * 2 + it];
-					}
+				const unsigned so = static_cast<unsigned>(gy * p.outPitch + stX) * 128u;
+				if (gy < p.H) {
+					if (outPi[0] < lim) __builtin_amdgcn_raw_buffer_store_b128(r ? stg2 : stg0, rsrcOut, outLane[0], so, 0);
+					if (outPi[1] < lim) __builtin_amdgcn_raw_buffer_store_b128(r ? stg3 : stg1, rsrcOut, outLane[1], so, 0);
 				}
 			}
+			// (MUBUF stores with a scalar offset read their data late when a second wave competes for the
+			// vector-memory issue -- DESIGN.md 4b; this kernel runs one wave per SIMD, the wait states are free)
+			asm volatile("s_nop 1" ::: "memory");
 			stOn = false;
 		}
 	};
-	// skip values of the pair at image row gy0 (two rows), this lane's channels
-	auto loadSkip = [&](int gy0, int x0, int r, int g) __attribute__((always_inline)) {
-		const int gy = min(gy0 + r, p.H - 1), gx = min(x0 + px, p.W - 1);
-		const T *rp = in + ((size_t)gy * p.inPitch + gx) * 64 + cb * 32 + 4 * hh;
-		resv[r][g] = *reinterpret_cast<const Vec4<T> *>(rp + 8 * g);
+	// skip values of the pair whose first image row is gy0, row r, groups g and g + 1
+	auto loadSkip2 = [&](int gy0, int x0, int r, int g) __attribute__((always_inline)) {
+		const int gy = min(gy0 + r, p.H - 1);
+		const int gx = min(x0 + px, p.W - 1);
+		const unsigned vo = static_cast<unsigned>(gx * 64 + cb * 32 + 4 * hh) * 2u;
+		const unsigned so = static_cast<unsigned>(gy * p.inPitch) * 128u;
+		resv[r][g] = __builtin_amdgcn_raw_buffer_load_b64(rsrcIn, vo, so + g * 16, 0);
+		resv[r][g + 1] = __builtin_amdgcn_raw_buffer_load_b64(rsrcIn, vo, so + (g + 1) * 16, 0);
 	};
-	// conv A epilogue of the pair in `acc` (T rows 2 pair, 2 pair + 1), group j behind macro-step j
+	// The epilogues, a group of four values (row r, channel group g) per macro-step, at most three plain VALU
+	// operations behind each MFMA -- what issues in an MFMA's shadow for nothing; more than that, packed-f32
+	// operations or wait states between them are paid in full (measured: with the generic x < 0 ? s x : x
+	// activation in f32, 19-21 operations per group, the K loops took 3300-3600 cycles instead of 2304 and
+	// the kernel gained nothing).  So this kernel serves ReLU blocks only (the host sends every other
+	// activation to res_block_kernel): ReLU on the PACKED 16-bit values (a signed 16-bit max with 0, as in
+	// the resident tower) and the outside-the-image zeroing as an AND mask.  Negative inputs give +0 where
+	// the f32 form gives -0: the tensors differ in the sign of zeros only, every later value is the same.
 	float dv[4];
 	unsigned dlo = 0, dhi = 0;
-	typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
-	auto epiA = [&](const f32x16 &a0, const f32x16 &a1, int pair, float keep0, float keep1, int m, int k) __attribute__((always_inline)) {
+	// conv A epilogue of the pair in (a0, a1) (T rows 2 pair, 2 pair + 1): group j behind macro-step j
+	auto epiA = [&](const f32x16 &a0, const f32x16 &a1, int pair, unsigned keep0, unsigned keep1, int m, int k) __attribute__((always_inline)) {
 		if (m < 8) {
 			const int r = m >> 2, g = m & 3;
-			if (k < 4) {
-				const float x = (r ? a1 : a0)[4 * g + k];
-				dv[k] = fbAct(x, p.s1) * (r ? keep1 : keep0);
+			if (k == 0) {
+				const u32x2r wv = __builtin_bit_cast(u32x2r, reluPacked<T>(pack4<T>((r ? a1 : a0)[4 * g + 0], (r ? a1 : a0)[4 * g + 1],
+				    (r ? a1 : a0)[4 * g + 2], (r ? a1 : a0)[4 * g + 3])));
+				dlo = wv[0];
+				dhi = wv[1];
+			} else if (k == 2) {
+				dlo &= (r ? keep1 : keep0);
+				dhi &= (r ? keep1 : keep0);
 			} else if (k == 4) {
-				const u32x2r w = __builtin_bit_cast(u32x2r, pack4<T>(dv[0], dv[1], dv[2], dv[3]));
-				dlo = w[0];
-				dhi = w[1];
-			} else {
 				*reinterpret_cast<u32x2r *>(smT + (2 * pair + r) * (kFbW * 128) + tOff[g]) = u32x2r{dlo, dhi};
 			}
 		}
 	};
-	// conv B epilogue of the pair in `acc` (skip values in resv): groups behind macro-steps 3..10,
+	// conv B epilogue of the pair in (a0, a1) (skip values in resv): groups behind macro-steps 3..10 (value i
+	// = accumulator + skip behind MFMA i, pack + ReLU behind MFMA 4, the staging write behind MFMA 5) and
 	// the transposed read-back behind macro-step 11
 	auto epiB = [&](const f32x16 &a0, const f32x16 &a1, int m, int k) __attribute__((always_inline)) {
 		if (m >= 3 && m < 11) {
 			const int j = m - 3, r = j >> 2, g = j & 3;
 			if (k < 4) {
-				const float x = (r ? a1 : a0)[4 * g + k] + static_cast<float>(resv[r][g][k]);
-				dv[k] = fbAct(x, p.s2);
+				const Vec4<T> rv = __builtin_bit_cast(Vec4<T>, resv[r][g]);
+				dv[k] = (r ? a1 : a0)[4 * g + k] + static_cast<float>(rv[k]);
+				asm volatile("" : "+v"(dv[k]));  // (keeps the four adds scalar and in their slots)
 			} else if (k == 4) {
-				const u32x2r w = __builtin_bit_cast(u32x2r, pack4<T>(dv[0], dv[1], dv[2], dv[3]));
-				dlo = w[0];
-				dhi = w[1];
+				const u32x2r wv = __builtin_bit_cast(u32x2r, reluPacked<T>(pack4<T>(dv[0], dv[1], dv[2], dv[3])));
+				dlo = wv[0];
+				dhi = wv[1];
 			} else {
-				const unsigned c = static_cast<unsigned>(g) ^ (static_cast<unsigned>(px) & 3u);
-				if (stageLane) *reinterpret_cast<u32x2r *>(stage + r * kRpStageRow + px * 64 + (c << 4) + hh * 8) = u32x2r{dlo, dhi};
+				if (stageLane) *reinterpret_cast<u32x2r *>(stage + r * kRpStageRow + stW[g]) = u32x2r{dlo, dhi};
 			}
 		} else if (m == 11) {
+			// (pixels 30, 31 of the read-back are the neighbouring row's / wave's bytes: never stored)
 			if (k == 0) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			} else if (k < 5) {
-				const int r = (k - 1) >> 1, it = (k - 1) & 1;
-				const int pi = it * 16 + (lane >> 2);
-				const unsigned slot = static_cast<unsigned>(lane & 3);
-				// (pi 30, 31 read the neighbouring row's / wave's bytes: never stored)
-				stg[r * 2 + it] = *reinterpret_cast<const uint4 *>(stage + r * kRpStageRow + pi * 64 + (slot << 4));
+			} else if (k == 1) {
+				stg0 = *reinterpret_cast<const u32x4w *>(stage + stR);
+			} else if (k == 2) {
+				stg1 = *reinterpret_cast<const u32x4w *>(stage + 16 * 64 + stR);
+			} else if (k == 3) {
+				stg2 = *reinterpret_cast<const u32x4w *>(stage + kRpStageRow + stR);
+			} else if (k == 4) {
+				stg3 = *reinterpret_cast<const u32x4w *>(stage + kRpStageRow + 16 * 64 + stR);
 			}
 		}
 	};
 
+#ifdef JU_RB_PROF
+	unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long {
+		unsigned long long t;
+		__builtin_amdgcn_sched_barrier(0);
+		asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+		__builtin_amdgcn_sched_barrier(0);
+		return t;
+	};
+	const unsigned long long tKernel = stamp();
+#define RB_STAMP(var) const unsigned long long var = stamp()
+#define RB_ADD(slot, a, b) prof[slot] += (b) - (a)
+#else
+#define RB_STAMP(var)
+#define RB_ADD(slot, a, b)
+#endif
 	int tile = blockIdx.x;
 	if (tile < p.numTiles) stageX(tile);
 	__syncthreads();  // (the bias floats are in LDS)
 	f32x16 bias = loadBias(0);
+	RB_STAMP(tPro);
+	RB_ADD(0, tKernel, tPro);
 	for (; tile < p.numTiles; tile += gridDim.x) {
 		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
 		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
+		RB_STAMP(t0);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's X has landed (and the last tile's stores left)
+		RB_STAMP(t1);
 		__syncthreads();                                  // ... for every wave; all are done with T too
+		RB_STAMP(t2);
+		RB_ADD(2, t0, t2);
 		const int gxA = x0 - 1 + px;
 		const bool colIn = gxA >= 0 && gxA < p.W;
-		auto keepOf = [&](int pair, int r) __attribute__((always_inline)) {
+		auto keepOf = [&](int pair, int r) __attribute__((always_inline)) -> unsigned {
 			const int gy = y0 - 1 + 2 * pair + r;
-			return (colIn && gy >= 0 && gy < p.H) ? 1.0f : 0.0f;
+			return (colIn && gy >= 0 && gy < p.H) ? 0xffffffffu : 0u;
 		};
 		// ---- conv A: pairs pl, pl + 2, pl + 4, pl + 6 of the 16 T rows; sets S0, S1, S0, S1 ----
 		{
 			// pair 0 of this wave; behind it the previous tile's last conv B epilogue (its accumulators are in S1)
 			const bool pend = epOn;
 			const f32x16 e0 = S1[0], e1 = S1[1];
-			rbPipeRun<T, false>(ldsBase + (2 * pl) * (kFbW * 128), colOff, colSwz, hh, w, nullptr, S0, bias, storeRows,
+			rbPipeRun<T, false>(ldsBase + (2 * pl) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S0, bias, storeRows,
 			    [&](int m, int k) __attribute__((always_inline)) { if (pend) epiB(e0, e1, m, k); });
 			if (pend) {
 				stY = epY;
@@ -1061,68 +1177,87 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 #pragma unroll
 		for (int q = 1; q < 4; ++q) {
 			const int pair = pl + 2 * q, prev = pair - 2;
-			const float k0 = keepOf(prev, 0), k1 = keepOf(prev, 1);
-			if (q == 3) {  // (conv A's last K loop: conv B's fragments stream in behind it)
+			const unsigned k0 = keepOf(prev, 0), k1 = keepOf(prev, 1);
+			if (q & 1) {
 				const f32x16 e0 = S0[0], e1 = S0[1];
-				rbPipeRun<T, true>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, w, wPtrB, S1, bias, storeRows,
-				    [&](int m, int k) __attribute__((always_inline)) { epiA(e0, e1, prev, k0, k1, m, k); });
-			} else if (q & 1) {
-				const f32x16 e0 = S0[0], e1 = S0[1];
-				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, w, nullptr, S1, bias, storeRows,
+				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S1, bias, storeRows,
 				    [&](int m, int k) __attribute__((always_inline)) { epiA(e0, e1, prev, k0, k1, m, k); });
 			} else {
 				const f32x16 e0 = S1[0], e1 = S1[1];
-				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, w, nullptr, S0, bias, storeRows,
+				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S0, bias, storeRows,
 				    [&](int m, int k) __attribute__((always_inline)) { epiA(e0, e1, prev, k0, k1, m, k); });
 			}
 		}
+		RB_STAMP(t3);
+		RB_ADD(3, t2, t3);
 		{
 			// the last pair's epilogue (in S1): exposed, T must be complete at the barrier
 			const int pair = pl + 6;
-			const float k0 = keepOf(pair, 0), k1 = keepOf(pair, 1);
+			const unsigned k0 = keepOf(pair, 0), k1 = keepOf(pair, 1);
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
 				unsigned char *row = smT + (2 * pair + r) * (kFbW * 128);
-				const float keep = r ? k1 : k0;
+				const unsigned keep = r ? k1 : k0;
 #pragma unroll
 				for (int g = 0; g < 4; ++g) {
-					*reinterpret_cast<Vec4<T> *>(row + tOff[g]) =
-					    pack4<T>(fbAct(S1[r][4 * g + 0], p.s1) * keep, fbAct(S1[r][4 * g + 1], p.s1) * keep,
-					        fbAct(S1[r][4 * g + 2], p.s1) * keep, fbAct(S1[r][4 * g + 3], p.s1) * keep);
+					const u32x2r wv = __builtin_bit_cast(u32x2r, reluPacked<T>(pack4<T>(S1[r][4 * g + 0], S1[r][4 * g + 1],
+					    S1[r][4 * g + 2], S1[r][4 * g + 3])));
+					*reinterpret_cast<u32x2r *>(row + tOff[g]) = u32x2r{wv[0] & keep, wv[1] & keep};
 				}
 			}
 		}
 		bias = loadBias(1);
-		// the first conv B pair's skip values (its predecessors fetch theirs behind their own last macro-steps)
-#pragma unroll
-		for (int r = 0; r < 2; ++r) {
-#pragma unroll
-			for (int g = 0; g < 4; ++g) loadSkip(y0 + 2 * pl, x0, r, g);
-		}
+		// the first conv B pair's skip values (the later pairs fetch theirs behind their own last macro-step)
+		loadSkip2(y0 + 2 * pl, x0, 0, 0);
+		loadSkip2(y0 + 2 * pl, x0, 0, 2);
+		loadSkip2(y0 + 2 * pl, x0, 1, 0);
+		loadSkip2(y0 + 2 * pl, x0, 1, 2);
+		RB_STAMP(t4);
+		RB_ADD(4, t3, t4);
 		__syncthreads();  // T complete, X dead
-		if (tile + static_cast<int>(gridDim.x) < p.numTiles) stageX(tile + gridDim.x);
+		RB_STAMP(t5);
+		RB_ADD(2, t4, t5);
+		// The next tile's X: an interior tile's 20 LDS-DMA instructions go out behind the MFMAs of this wave's
+		// first conv B K loop (all four waves issuing them at once fill the CU's vector-memory queue and stall
+		// ~3 k cycles); an edge tile takes the general path here.
+		const int nextTile = tile + static_cast<int>(gridDim.x);
+		bool xBehind = false;
+		unsigned xSo = 0;
+		if (nextTile < p.numTiles) {
+			if (tileIsBorder(nextTile)) {
+				stageX(nextTile);
+			} else {
+				const int nty = nextTile / p.tilesX, ntx = nextTile - nty * p.tilesX;
+				xSo = static_cast<unsigned>((nty * kRbTH - 2) * p.inPitch + (ntx * kFbOutW - 2)) * 128u;
+				xBehind = true;
+			}
+		}
+		RB_STAMP(t6);
+		RB_ADD(5, t5, t6);
 		// ---- conv B: pairs pl, pl + 2, ... < 7; the LAST pair accumulates in S1 (4 pairs: S0 S1 S0 S1; 3: S1 S0 S1) ----
-		// A pair fetches the NEXT pair's... no: its OWN skip values behind its last two macro-steps (the
-		// previous pair's were consumed by macro-step 10), so one set of skip registers serves the pipeline.
+		// A pair fetches its OWN skip values behind its last macro-step (the previous pair's were consumed by
+		// macro-step 10), so one set of skip registers serves the pipeline.
 		const int nB = pl == 0 ? 4 : 3;
 		auto runB = [&](f32x16 (&acc)[2], const f32x16 (&prevAcc)[2], const int q, const bool hasPrev, auto lastTag) __attribute__((always_inline)) {
-			constexpr bool last = decltype(lastTag)::value;  // conv B's last K loop: conv A's fragments stream back in
+			constexpr bool last = decltype(lastTag)::value;  // (profiling only)
 			const int pair = pl + 2 * q;
 			const f32x16 e0 = prevAcc[0], e1 = prevAcc[1];
-			const int gyNext = y0 + 2 * pair;
-			rbPipeRun<T, last>(ldsBase + kRbX + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, w, wPtrA, acc, bias, storeRows,
+			const int gyOwn = y0 + 2 * pair;
+			RB_STAMP(tb0);
+			rbPipeRun<T, false>(ldsBase + kRbX + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wb, rsrcWa, wLane, wBase, acc, bias, storeRows,
 			    [&](int m, int k) __attribute__((always_inline)) {
 				    if (hasPrev) {
 					    epiB(e0, e1, m, k);
-					    // this pair's own skip values: the registers are free from macro-step 11 on
-					    if (m == 11 && k >= 1 && k < 5) {
-						    const int r = (k - 1) >> 1, gg = ((k - 1) & 1) * 2;
-						    loadSkip(gyNext, x0, r, gg);
-						    loadSkip(gyNext, x0, r, gg + 1);
-					    }
+					    if (m == 11 && k >= 1 && k < 5) loadSkip2(gyOwn, x0, (k - 1) >> 1, ((k - 1) & 1) * 2);
+				    } else if (xBehind) {
+					    // (the first conv B pair has no epilogue to run: the next tile's X instead)
+					    if (k == 2) stageXOne(xSo, m);
+					    else if (k == 5 && m < kXPerWave - 12) stageXOne(xSo, 12 + m);
 				    }
 			    });
-			if (hasPrev) {  // (the pair before this one is now in `stg`)
+			RB_STAMP(tb1);
+			RB_ADD((q == 0 ? 1 : (last ? 7 : 6)), tb0, tb1);
+			if (hasPrev) {  // (the pair before this one is now in stg0..3)
 				stY = y0 + 2 * (pair - 2);
 				stX = x0;
 				stOn = true;
@@ -1143,6 +1278,7 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 		epOn = true;
 		bias = loadBias(0);
 	}
+	RB_STAMP(tLoop);
 	// ---- drain: the last tile's last pair ----
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	storeRows();
@@ -1158,14 +1294,29 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		storeRows();
 	}
+#ifdef JU_RB_PROF
+	{
+		const unsigned long long tEnd = stamp();
+		if (blockIdx.x == 0 && lane == 0 && p.prof != nullptr) {
+			for (int k = 0; k < 8; ++k) p.prof[wave * 8 + k] = prof[k];
+			if (wave == 0) p.prof[32] = tEnd - tKernel;
+		}
+	}
+#endif
 }
+
+// JU_RES_BLOCK=plain (or the tests' switch): res_block_kernel for every block
+static std::atomic<int> g_ResBlockPlain{[] { const char *e = std::getenv("JU_RES_BLOCK"); return (e != nullptr && std::string(e) == "plain") ? 1 : 0; }()};
+}  // namespace
+void setResBlockPlain(int on) { g_ResBlockPlain = on ? 1 : 0; }
+bool resBlockPlain() { return g_ResBlockPlain.load() != 0; }
+namespace {
 
 template <typename T>
 void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
 	// the pipelined form (epilogues behind the next pair's MFMAs); JU_RES_BLOCK=plain: the plain kernel (tests, A/B).
 	// A slope outside [0, 1] (no model the container accepts has one) also takes the plain kernel.
-	static const bool plainEnv = [] { const char *e = std::getenv("JU_RES_BLOCK"); return e == nullptr || std::string(e) != "pipe"; }();  // (work in progress: opt-in)
-	const bool pipe = !plainEnv && !(q.slope < 0.0f || q.slope > 1.0f) && ablationSkipBits() == 0;
+	const bool pipe = !resBlockPlain() && q.act1 == 1 && q.act2 == 1 && ablationSkipBits() == 0;  // (ReLU blocks)
 	auto kern = pipe ? res_block_pipe_kernel<T> : res_block_kernel<T>;
 	const int ldsBytes = pipe ? kRpLds : kRbLds;
 	static std::atomic<std::uint64_t> ldsDone{0}, ldsDonePipe{0};
@@ -1188,8 +1339,27 @@ void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.s2 = q.act2 == 1 ? 0.0f : (q.act2 == 2 ? q.slope : 1.0f);
 	p.skip = ablationSkipBits();
 	const int grid = p.numTiles < cus ? p.numTiles : cus;
+#ifdef JU_RB_PROF
+	static unsigned long long *profBuf = [] { void *b = nullptr; (void)hipMalloc(&b, 64 * 8); return static_cast<unsigned long long *>(b); }();
+	static int profLaunches = 0;
+	p.prof = profBuf;
+#endif
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, p);
 	hipCheckLaunch("res_block");
+#ifdef JU_RB_PROF
+	if (pipe && ++profLaunches == 200) {  // (developer build: one dump, of a warm launch)
+		unsigned long long h[33];
+		(void)hipDeviceSynchronize();
+		(void)hipMemcpy(h, profBuf, sizeof(h), hipMemcpyDeviceToHost);
+		const char *names[8] = {"prologue", "B first loop (no hooks)", "X wait + barriers", "conv A loops", "A3 epilogue + skip", "stage X issue", "B middle loops", "B last loop (stream)"};
+		std::fprintf(stderr, "res_block_pipe workgroup 0: %llu ticks in the kernel\n", h[32]);
+		for (int wv = 0; wv < 4; ++wv) {
+			std::fprintf(stderr, " wave %d:", wv);
+			for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %s %llu,", names[k], h[wv * 8 + k]);
+			std::fprintf(stderr, "\n");
+		}
+	}
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -238,6 +238,8 @@ bool residentTowerGeometry(int H, int W, int numCUs, int *GX, int *GY, int *RH);
 std::size_t residentMailboxBytes(int GX, int GY, bool leaky = false);
 // every region of the frame has the shape the fast schedule of the resident tower is built for
 bool residentTowerFastGeometry(int H, int W, int GX, int GY, int RH);
+void setResBlockPlain(int on);       // tests / JU_RES_BLOCK=plain: res_block_kernel instead of res_block_pipe_kernel
+bool resBlockPlain();
 void setResidentTowerFast(int on);  // tests / JU_TOWER_FAST=0: the general schedule everywhere
 bool residentTowerFast();
 inline std::size_t residentCounterBytes(int GX, int GY) {

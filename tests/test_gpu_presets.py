@@ -189,6 +189,42 @@ def test_full_size_resident_tower_against_the_per_block_kernels(monkeypatch, dty
 
 
 @pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16])
+def test_pipelined_residual_block_kernel_gives_the_plain_kernels_frames(dtype, monkeypatch):
+    """res_block_pipe_kernel (a row pair's epilogue spread over the next pair's MFMAs, ReLU on the packed
+    16-bit values, two accumulator sets, the last pair of a tile finished inside the next tile's first K loops,
+    the next tile's X issued behind the first conv B loop) against res_block_kernel (JU_RES_BLOCK=plain):
+    same arithmetic per element up to the sign of zeros in the intermediate tensors, so the frames and the
+    recurrent state must be EQUAL -- at the PS2 size (704 tiles: interior and all four kinds of edge tiles,
+    three tiles per workgroup), on frames small enough for one tile per workgroup and ragged in both
+    directions, and with the resident tower switched off at 480x270 (JU_TOWER=layers)."""
+    lib = R.load_library()
+    from helpers import small_config
+    monkeypatch.setenv("JU_TOWER", "layers")
+    cases = [(M.PRESETS["ps2-quality"], 3), (M.PRESETS["psp-quality"], 2),
+             (small_config(frame_height=61, frame_width=97, gen_blocks=3), 4),
+             (small_config(frame_height=14, frame_width=30, gen_blocks=2), 3),
+             (small_config(frame_height=33, frame_width=31, gen_blocks=2), 3)]
+    for cfg, n in cases:
+        blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+        frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=21, kind="noise")
+        outs = {}
+        for plain in (0, 1):
+            lib.ju_debug_set(b"res_block_plain", plain)
+            try:
+                rt = R.Runtime(blob, 0, dtype)
+                assert rt.stat("resident_tower") == 0
+                outs[plain] = [rt.process_image(f).copy() for f in frames]
+                outs[(plain, "state")] = rt.read_tensor("state").copy()
+                rt.close()
+            finally:
+                lib.ju_debug_set(b"res_block_plain", 0)
+        key = (cfg.frame_height, cfg.frame_width)
+        assert np.array_equal(outs[(0, "state")], outs[(1, "state")]), key
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b), key
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16])
 def test_resident_tower_schedule_does_not_change_the_bytes(dtype, monkeypatch):
     """The product schedule of tower_resident_kernel (two units' halo-independent steps run around
     the halo loads with their accumulators kept across the sweep, the next layer's weights refilled

@@ -24,10 +24,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-enum Kind { kNone, kCvtPk, kPkMax, kAddF32, kPkAddF32, kMov64, kDsWrite64, kDsRead128, kLshl, kSaveExec, kStore4, kStore64, kStore4Wb, kStoreEvery8 };
+enum Kind { kNone, kCvtPk, kPkMax, kAddF32, kPkAddF32, kMov64, kDsWrite64, kDsRead128, kLshl, kSaveExec, kStore4, kStore64, kStore4Wb, kStoreEvery8, kDepChain, kIndep3, kAccRead };
 static const char *kNames[] = {"(nothing)", "v_cvt_pk_bf16_f32", "v_pk_max_i16", "v_add_f32", "v_pk_add_f32", "v_mov_b64",
     "ds_write_b64", "ds_read_b128 (+wait at the end)", "v_lshlrev_b32", "s_and_saveexec + s_or exec",
-    "buffer_store_dwordx2 sc1, 4 lanes", "buffer_store_dwordx2 sc1, 64 lanes", "buffer_store_dwordx2 (no sc1), 4 lanes", "buffer_store_dwordx2 sc1, 4 lanes, every 8th MFMA"};
+    "buffer_store_dwordx2 sc1, 4 lanes", "buffer_store_dwordx2 sc1, 64 lanes", "buffer_store_dwordx2 (no sc1), 4 lanes", "buffer_store_dwordx2 sc1, 4 lanes, every 8th MFMA",
+    "N x (add -> mul -> max, each on the last result)", "N x (add, mul, max, independent)", "N x v_add_f32 reading the OTHER accumulator"};
 
 template <int KIND, int N>
 __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *ticks, int iters, void *scratch) {
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *
 		b[i] = (__bf16)(0.002f * (lane - i));
 	}
 	f32x16 acc0 = {}, acc1 = {};
-	float x0 = lane, x1 = 2 * lane, x2 = 3, x3 = 4;
+	float x0 = lane, x1 = 2 * lane, x2 = 3, x3 = 4, y2 = 5;
 	unsigned u0 = lane, u1 = lane * 3;
 	u32x2 w = {u0, u1};
 	unsigned ldsAddr = (threadIdx.x * 16) & 0xffff;
@@ -70,6 +71,21 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *
 						if (on) __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, off & 0x7ffffff, 0, KIND == kStore4Wb ? 0 : 16);
 					}
 				}
+				if constexpr (KIND == kDepChain) {
+					asm volatile("v_add_f32 %0, %1, %2" : "=v"(x2) : "v"(x0), "v"(x1));
+					asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x3) : "v"(x2), "v"(x1));
+					asm volatile("v_max_f32 %0, %1, %2" : "=v"(x2) : "v"(x2), "v"(x3));
+				}
+				if constexpr (KIND == kIndep3) {
+					asm volatile("v_add_f32 %0, %1, %2" : "=v"(x2) : "v"(x0), "v"(x1));
+					asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x3) : "v"(x0), "v"(x1));
+					asm volatile("v_max_f32 %0, %1, %2" : "=v"(y2) : "v"(x0), "v"(x1));
+				}
+				if constexpr (KIND == kAccRead) {
+					// reads an element of the accumulator the CURRENT MFMA does not write
+					float e = (m & 1) ? acc0[n & 15] : acc1[n & 15];
+					asm volatile("v_add_f32 %0, %1, %2" : "=v"(x2) : "v"(e), "v"(x1));
+				}
 				if constexpr (KIND == kSaveExec) asm volatile("s_and_saveexec_b64 s[40:41], vcc\n\ts_or_b64 exec, exec, s[40:41]" ::: "s40", "s41");
 			}
 			__builtin_amdgcn_sched_barrier(0);
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *
 	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
 	float s = 0;
 	for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
-	out[blockIdx.x * 256 + threadIdx.x] = s + x2 + x3 + u0 + w[0] + w[1] + rd[0] + lds[threadIdx.x];
+	out[blockIdx.x * 256 + threadIdx.x] = s + x2 + x3 + y2 + u0 + w[0] + w[1] + rd[0] + lds[threadIdx.x];
 	if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
@@ -133,5 +149,8 @@ int main() {
 	sweep<kStore64>(out, ticks, iters, base);
 	sweep<kStore4Wb>(out, ticks, iters, base);
 	sweep<kStoreEvery8>(out, ticks, iters, base);
+	sweep<kDepChain>(out, ticks, iters, base);
+	sweep<kIndep3>(out, ticks, iters, base);
+	sweep<kAccRead>(out, ticks, iters, base);
 	return 0;
 }
