@@ -921,19 +921,15 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 	// -- the resident tower's way -- was measured: 144 KB of requests per workgroup and phase fill the CU's
 	// 64 B/clk vector-memory path for a whole K loop, the streaming loops took 4900-5900 cycles instead of
 	// 3450.)
+	// (the bias floats are requested first and go to LDS below: their wait must not cover the fragments)
+	const float biasMine = tid < 64 ? p.b1[tid] : (tid < 128 ? p.b2[tid - 64] : 0.0f);
+	// (conv B's set is requested after the first tile's X and pinned in front of the first conv B phase: the
+	// first tile starts on conv A's 36 KB instead of waiting for all 72)
 	Vec8<T> wa[36], wb[36];
 #pragma unroll
 	for (int f = 0; f < 36; ++f) {
 		wa[f] = __builtin_bit_cast(Vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrcWa, wLane, wBase + f * 1024, 0));
-		wb[f] = __builtin_bit_cast(Vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrcWb, wLane, wBase + f * 1024, 0));
 	}
-#pragma unroll
-	for (int f = 0; f < 36; ++f) {
-		asm volatile("" : "+a"(wa[f]));
-		asm volatile("" : "+a"(wb[f]));
-	}
-	if (tid < 64) biasLds[tid] = p.b1[tid];
-	else if (tid < 128) biasLds[tid] = p.b2[tid - 64];
 	// this lane's 16 accumulator values of a row: channel cb * 32 + 8 g + 4 hh + i at index 4 g + i
 	auto loadBias = [&](int conv) __attribute__((always_inline)) -> f32x16 {
 		const float *b = biasLds + conv * 64 + cb * 32 + 4 * hh;
@@ -975,14 +971,52 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 	constexpr int kXInstr = (kXPix + 7) / 8;        // 77: 8 pixels (1 KiB) per wave-instruction
 	constexpr int kXPerWave = (kXInstr + 3) / 4;    // 20
 	unsigned xOff[kXPerWave];
+	{
+		// pixel q = (wave + 4 n) * 8 + lane / 8 of the tile: row r, column k; q advances by 32 per n
+		const int q0 = wave * 8 + (lane >> 3);
+		int r = q0 / kFbW, k = q0 - r * kFbW;
 #pragma unroll
-	for (int n = 0; n < kXPerWave; ++n) {
-		const int q = (wave + 4 * n) * 8 + (lane >> 3);
-		const int r = q / kFbW, k = q - r * kFbW;
-		const unsigned c = static_cast<unsigned>(lane & 7) ^ fbSwz<128>(k);
-		xOff[n] = static_cast<unsigned>(r * p.inPitch + k) * 128u + c * 16u;
+		for (int n = 0; n < kXPerWave; ++n) {
+			const unsigned c = static_cast<unsigned>(lane & 7) ^ fbSwz<128>(k);
+			xOff[n] = static_cast<unsigned>(r * p.inPitch + k) * 128u + c * 16u;
+			k += 32;
+			if (k >= kFbW) {
+				k -= kFbW;
+				r += 1;
+			}
+		}
 	}
 	const bool xLastLane = (kXInstr - 1) * 8 + (lane >> 3) < kXPix;  // the 77th instruction covers 4 pixels
+	// Slot v (workgroup b's round r: v = r * grid + b) -> tile.  Edge tiles stage their X through the general
+	// path (~5 k cycles where an interior tile pays nothing), and the launch ends with its slowest workgroup:
+	// so the edge tiles go to the workgroups that have a round less to run (704 tiles on 256 workgroups: 64 of
+	// them run two tiles instead of three), the interior tiles fill the other slots in row-major order.
+	const int tRounds = (p.numTiles + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+	const int tLast = p.numTiles - (tRounds - 1) * static_cast<int>(gridDim.x);  // tiles of the last round
+	const int tSlack = static_cast<int>(gridDim.x) - tLast;                       // workgroups with a round less
+	const int tilesY = p.numTiles / p.tilesX;
+	const int tEdge = 2 * p.tilesX + 2 * (tilesY - 2);
+	const bool tRemap = tRounds >= 2 && p.tilesX >= 3 && tilesY >= 3 && tEdge <= (tRounds - 1) * tSlack;
+	auto tileXY = [&](int v, int &ty, int &tx) __attribute__((always_inline)) {
+		if (!tRemap) {
+			ty = v / p.tilesX;
+			tx = v - ty * p.tilesX;
+			return;
+		}
+		const int r = v / static_cast<int>(gridDim.x), b = v - r * static_cast<int>(gridDim.x);
+		const bool slack = b >= tLast && r < tRounds - 1;
+		const int sBefore = r < tRounds - 1 ? r * tSlack + (b > tLast ? b - tLast : 0) : (tRounds - 1) * tSlack;
+		if (slack && sBefore < tEdge) {
+			const int e = sBefore;  // edge tile number e: top row, bottom row, then the two columns
+			if (e < p.tilesX) { ty = 0; tx = e; }
+			else if (e < 2 * p.tilesX) { ty = tilesY - 1; tx = e - p.tilesX; }
+			else { ty = 1 + ((e - 2 * p.tilesX) >> 1); tx = ((e - 2 * p.tilesX) & 1) ? p.tilesX - 1 : 0; }
+		} else {
+			const int n = v - (sBefore < tEdge ? sBefore : tEdge);  // interior tile number
+			ty = 1 + n / (p.tilesX - 2);
+			tx = 1 + n - (ty - 1) * (p.tilesX - 2);
+		}
+	};
 	// instruction n of this wave for the interior tile whose first X pixel is at byte offset `so`
 	auto stageXOne = [&](unsigned so, int n) __attribute__((always_inline)) {
 		const int i = wave + 4 * n;
@@ -994,12 +1028,14 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 		}
 	};
 	auto tileIsBorder = [&](int tile) __attribute__((always_inline)) {
-		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		int ty, tx;
+		tileXY(tile, ty, tx);
 		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
 		return y0 - 2 < 0 || y0 + kRbTH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
 	};
 	auto stageX = [&](int tile) {
-		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		int ty, tx;
+		tileXY(tile, ty, tx);
 		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
 		constexpr int NPIX = kRbXR * kFbW;
 		constexpr int NINSTR = (NPIX + 7) / 8;  // 8 pixels (1 KiB) per wave-instruction
@@ -1141,15 +1177,28 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 #endif
 	int tile = blockIdx.x;
 	if (tile < p.numTiles) stageX(tile);
+#pragma unroll
+	for (int f = 0; f < 36; ++f) {
+		wb[f] = __builtin_bit_cast(Vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrcWb, wLane, wBase + f * 1024, 0));
+	}
+#pragma unroll
+	for (int f = 0; f < 36; ++f) asm volatile("" : "+a"(wa[f]));  // (accumulation registers, see above)
+	bool firstTile = true;
+	if (tid < 128) biasLds[tid] = biasMine;
 	__syncthreads();  // (the bias floats are in LDS)
 	f32x16 bias = loadBias(0);
 	RB_STAMP(tPro);
 	RB_ADD(0, tKernel, tPro);
 	for (; tile < p.numTiles; tile += gridDim.x) {
-		const int ty = tile / p.tilesX, tx = tile - ty * p.tilesX;
+		int ty, tx;
+		tileXY(tile, ty, tx);
 		const int y0 = ty * kRbTH, x0 = tx * kFbOutW;
 		RB_STAMP(t0);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's X has landed (and the last tile's stores left)
+		// this tile's X has landed (and the last tile's stores left); the first tile: everything but the 36
+		// requests of conv B's fragments behind it
+		if (firstTile) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+		else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		firstTile = false;
 		RB_STAMP(t1);
 		__syncthreads();                                  // ... for every wave; all are done with T too
 		RB_STAMP(t2);
@@ -1206,6 +1255,8 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 				}
 			}
 		}
+#pragma unroll
+		for (int f = 0; f < 36; ++f) asm volatile("" : "+a"(wb[f]));
 		bias = loadBias(1);
 		// the first conv B pair's skip values (the later pairs fetch theirs behind their own last macro-step)
 		loadSkip2(y0 + 2 * pl, x0, 0, 0);
@@ -1227,7 +1278,8 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 			if (tileIsBorder(nextTile)) {
 				stageX(nextTile);
 			} else {
-				const int nty = nextTile / p.tilesX, ntx = nextTile - nty * p.tilesX;
+				int nty, ntx;
+				tileXY(nextTile, nty, ntx);
 				xSo = static_cast<unsigned>((nty * kRbTH - 2) * p.inPitch + (ntx * kFbOutW - 2)) * 128u;
 				xBehind = true;
 			}

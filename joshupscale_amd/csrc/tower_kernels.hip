@@ -395,10 +395,10 @@ constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of 
 #define JU_PREBEFORE 1
 #endif
 // The fast schedule (FAST instantiations): pre-run units per wave; a wave keeps at least one whole unit.
-// (Measured: 2 -> 356 us per tower, 3 -> 394 us: the third accumulator set pushes the LDS addresses the
-// compiler hoists out of the layer loop into scratch, and each reload waits for memory in front of a
-// fragment read.  JU_PREBEFORE 0 / 1 / 2 with two units: 366 / 352 / 354 us, 0.80 / 0.33 / 0.18 extra sweep
-// passes per layer.)
+// (Measured: 2 -> 348-352 us per tower; 3 -> 350-358 us once the fragment addresses were kept out of the
+// registers (before: 394 us, hoisted LDS addresses spilled to scratch): what the third unit takes out of
+// the finish phase the halo fill gives back, the exchange's ~2.1 k cycles beside the pre-run stay.
+// JU_PREBEFORE 0 / 1 / 2 with two units: 366 / 352 / 354 us, 0.80 / 0.33 / 0.18 extra sweep passes per layer.)
 #ifndef JU_FAST_PRERUN
 #define JU_FAST_PRERUN 2
 #endif
@@ -761,7 +761,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #pragma unroll
 			for (int r = 0; r < ROWS; ++r) acc[r] = biasVec;
 		}
-		const unsigned rowAddr = ldsBase + inOff + (2 * unit) * kResRowBytes;
+		// (opaque: otherwise every (unit, macro-step) fragment address is loop-invariant over the layers and is
+		// kept in a register of its own -- 67 registers of the fast instantiation; with them gone a third
+		// pre-run unit fits without scratch, and was measured no faster: 350-358 against 348-352 us)
+		unsigned rowAddr = ldsBase + inOff + (2 * unit) * kResRowBytes;
+		asm volatile("" : "+v"(rowAddr));
 		// A unit whose epilogue is deferred (EPI false) fetches its residual behind the MFMAs of its own
 		// last macro-step into rvNext (plain C++ loads: the compiler's own waits count only what it
 		// knows of and are therefore never too lenient); its successor (DEF) consumes them.
