@@ -73,6 +73,18 @@ __device__ __forceinline__ int t8Quantize4(float a, float b, float c, float d, f
 	return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
 }
 
+// the same value with single multiplies (for the shadow of an MFMA, where packed f32 is not hidden)
+template <bool LEAKY = false>
+__device__ __forceinline__ int t8Quantize4s(float a, float b, float c, float d, float mul) {
+	constexpr float lo = LEAKY ? -448.0f : 0.0f;
+	a = __builtin_amdgcn_fmed3f(a * mul, lo, 448.0f);
+	b = __builtin_amdgcn_fmed3f(b * mul, lo, 448.0f);
+	c = __builtin_amdgcn_fmed3f(c * mul, lo, 448.0f);
+	d = __builtin_amdgcn_fmed3f(d * mul, lo, 448.0f);
+	int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+	return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+}
+
 struct Tower8Params {
 	const void *in;            // 16-bit stream (generator conv_1's output), tower layout, allocation start
 	void *out;                 // 16-bit stream after the last block, tower layout, allocation start
@@ -202,6 +214,18 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	};
 
 	// one convolution over the region; SECOND: conv B of a block (+ stream, both outputs)
+	// A unit's epilogue -- ~150 VALU instructions of residual add, activation, two roundings -- no longer
+	// runs between two units' MFMAs (1.9 of 6.7 us per layer at one wave per SIMD): its VALU part is computed
+	// in the shadow of the NEXT unit's 18 MFMAs (32x32x64: 16 passes each), two accumulator sets and two sets
+	// of stream values alternating; only the 16 masked LDS writes stay between the units, and the last unit
+	// of the layer keeps its epilogue.  A group of four values (row r, channel group g) goes behind two MFMAs:
+	// sums and activation behind the first, the two roundings behind the second.  (Left to the scheduler with
+	// sched_group_barrier pipelines the VALU block stayed where it was.)  Same arithmetic per element in the same order
+	// (the packed f32 multiplies / adds of the plain form as single ones: same values): the bytes do not
+	// change -- JU_T8_DEFER=0 at build time keeps the plain form for A/B runs.
+#ifndef JU_T8_DEFER
+#define JU_T8_DEFER 1
+#endif
 	auto computeLayer = [&](auto secondTag, const int layer, const i32x8(&w)[9]) {
 		constexpr bool SECOND = decltype(secondTag)::value;
 		constexpr int inOff = SECOND ? kT8OffT : kT8OffX;
@@ -212,8 +236,13 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		const float mul = p.outMul[layer];
 		const int np2 = (rhv + 1) >> 1;  // row pairs (an odd last row: its partner row is masked)
 		const int sw = ((px + 1) >> 2) & 3;
-		for (int u = rp; u < np2; u += 2) {
-			f32x16 acc[2];
+		const unsigned ssw = ((px + 1) >> 1) & 7;
+		auto streamRec = [&](int u) __attribute__((always_inline)) {
+			return smem + kT8OffS + (2 * u + 1) * kT8SRow + (px + 1) * 128 + hh * 8;
+		};
+		// the unit's 18 MFMAs; `behind`: VALU-only work the scheduler spreads behind them
+		auto kloop = [&](const int u, f32x16(&acc)[2], Vec4<T>(&rv)[2][4], auto deferTag, auto &&behind) __attribute__((always_inline)) {
+			constexpr bool DEFER = decltype(deferTag)::value;
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
 				const f32x4 bg = *reinterpret_cast<const f32x4 *>(biasPtr + 8 * g);
@@ -229,16 +258,14 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			// LDS operations return in order.)
 			i32x8 f0[4], f1[4];
 			if (!(JU_SKIP(p) & 2)) {
-			loadFrags(inOff, u, 0, f0);
-			loadFrags(inOff, u, 1, f1);
+				loadFrags(inOff, u, 0, f0);
+				loadFrags(inOff, u, 1, f1);
 			}
 			// conv B: this lane's pieces of the stream (2 rows x 4 groups of 4 channels) are
 			// read behind the last fragments, so they return during the remaining 12 instructions
 			// (LDS operations return in order); unconditional reads, masked writes: a read under
 			// a lane condition makes hipcc wait per element
-			const unsigned ssw = ((px + 1) >> 1) & 7;
-			unsigned char *srec = smem + kT8OffS + (2 * u + 1) * kT8SRow + (px + 1) * 128 + hh * 8;
-			Vec4<T> rv[2][4];
+			const unsigned char *srec = streamRec(u);
 #pragma unroll
 			// taps in the order dx = 1, 0, 2 (all three 8-bit kernels: the fp32 summation order is
 			// part of their byte equality): the middle tap reads no halo column
@@ -262,48 +289,151 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 					for (int r = 0; r < 2; ++r) {
 						acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w[dy * 3 + dx], (t == 1 ? f0 : f1)[r + dy], acc[r],
 						    0, 0, 0, scA, 0, scB);
+						if constexpr (DEFER) {
+							// (an MFMA on plainly loaded fragments has no ordered neighbour: without a use that
+							// is ordered, instruction selection emits all 18 in front of the barriers)
+							asm volatile("" : "+v"(acc[r]));
+							__builtin_amdgcn_sched_barrier(0);  // (the MFMA first, the deferred work in its shadow)
+							behind(t * 6 + dy * 2 + r);
+							__builtin_amdgcn_sched_barrier(0);
+						}
 					}
 				}
 			}
-			// ---- epilogue ----
-			if (!(JU_SKIP(p) & 4)) {
+		};
+		// the epilogue's arithmetic: accumulators (+ stream) -> activation -> 16-bit stream values / e4m3 bytes
+		// the deferred form: group j = (r, g) behind MFMAs 2 j (sums and activation) and 2 j + 1 (the roundings)
+		float dv[4];
+		auto epiHalf = [&](const f32x16(&acc)[2], const Vec4<T>(&rv)[2][4], int(&o8)[2][4], Vec4<T>(&o16)[2][4], const int k)
+		                   __attribute__((always_inline)) {
+			const int j = k >> 1;
+			if (j < 8) {
+				const int r = j >> 2, g = j & 3;
+				if ((k & 1) == 0) {
 #pragma unroll
-				for (int r = 0; r < 2; ++r) {
-					const int row = 2 * u + r;  // region row; buffer row index row + 1
-					const bool valid = px < rwv && row < rhv;
-					unsigned char *q8 = smem + outOff + (row + 1) * kT8QRow + (px + 1) * 64;
-					Vec4<T> o16[4];
-					int o8[4];
+					for (int i = 0; i < 4; ++i) {
+						float x = acc[r][4 * g + i];
+						if constexpr (SECOND) x += static_cast<float>(rv[r][g][i]);
+						if constexpr (SECOND || LEAKY) x = act8<LEAKY>(x, p.slope);
+						dv[i] = x;
+						// (pinned: the results are used under the lane mask of the stores, and the optimiser
+						// sinks unpinned arithmetic into that branch -- out of the MFMAs' shadow)
+						asm volatile("" : "+v"(dv[i]));
+					}
+				} else {
+					if constexpr (SECOND) {
+						typedef unsigned u32x2t __attribute__((ext_vector_type(2)));
+						u32x2t w16 = __builtin_bit_cast(u32x2t, pack4<T>(dv[0], dv[1], dv[2], dv[3]));
+						asm volatile("" : "+v"(w16));
+						o16[r][g] = __builtin_bit_cast(Vec4<T>, w16);
+					}
+					o8[r][g] = t8Quantize4s<LEAKY>(dv[0], dv[1], dv[2], dv[3], mul);
+					asm volatile("" : "+v"(o8[r][g]));
+				}
+			}
+		};
+		auto epiValues = [&](const f32x16(&acc)[2], const Vec4<T>(&rv)[2][4], int(&o8)[2][4], Vec4<T>(&o16)[2][4], auto singleTag)
+		                     __attribute__((always_inline)) {
+			constexpr bool SINGLE = decltype(singleTag)::value;  // single f32 instructions (the deferred form)
 #pragma unroll
-					for (int g = 0; g < 4; ++g) {
-						if constexpr (SECOND) {
+			for (int r = 0; r < 2; ++r) {
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					if constexpr (SECOND) {
+						float v[4];
+						if constexpr (SINGLE) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i) v[i] = act8<LEAKY>(acc[r][4 * g + i] + static_cast<float>(rv[r][g][i]), p.slope);
+						} else {
 							// (the residual adds as two packed v_pk_add_f32)
 							const t8f32x2 s01 = t8f32x2{acc[r][4 * g], acc[r][4 * g + 1]} +
 							                    t8f32x2{static_cast<float>(rv[r][g][0]), static_cast<float>(rv[r][g][1])};
 							const t8f32x2 s23 = t8f32x2{acc[r][4 * g + 2], acc[r][4 * g + 3]} +
 							                    t8f32x2{static_cast<float>(rv[r][g][2]), static_cast<float>(rv[r][g][3])};
-							const float v[4] = {act8<LEAKY>(s01[0], p.slope), act8<LEAKY>(s01[1], p.slope), act8<LEAKY>(s23[0], p.slope),
-							    act8<LEAKY>(s23[1], p.slope)};
-							o16[g] = pack4<T>(v[0], v[1], v[2], v[3]);
-							o8[g] = t8Quantize4<LEAKY>(v[0], v[1], v[2], v[3], mul);
-						} else if constexpr (LEAKY) {
-							o8[g] = t8Quantize4<true>(act8<true>(acc[r][4 * g], p.slope), act8<true>(acc[r][4 * g + 1], p.slope),
-							    act8<true>(acc[r][4 * g + 2], p.slope), act8<true>(acc[r][4 * g + 3], p.slope), mul);
-						} else {
-							o8[g] = t8Quantize4(acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3], mul);
+							v[0] = act8<LEAKY>(s01[0], p.slope);
+							v[1] = act8<LEAKY>(s01[1], p.slope);
+							v[2] = act8<LEAKY>(s23[0], p.slope);
+							v[3] = act8<LEAKY>(s23[1], p.slope);
 						}
-					}
-					if (valid) {
-#pragma unroll
-						for (int g = 0; g < 4; ++g) {
-							if constexpr (SECOND) {
-								*reinterpret_cast<Vec4<T> *>(srec + r * kT8SRow + ((static_cast<unsigned>(ch * 4 + g) ^ ssw) << 4)) = o16[g];
-							}
-							*reinterpret_cast<int *>(q8 + (((2 * ch + (g >> 1)) ^ sw) << 4) + (g & 1) * 8 + hh * 4) = o8[g];
-						}
+						o16[r][g] = pack4<T>(v[0], v[1], v[2], v[3]);
+						o8[r][g] = SINGLE ? t8Quantize4s<LEAKY>(v[0], v[1], v[2], v[3], mul) : t8Quantize4<LEAKY>(v[0], v[1], v[2], v[3], mul);
+					} else if constexpr (LEAKY) {
+						const float v0 = act8<true>(acc[r][4 * g], p.slope), v1 = act8<true>(acc[r][4 * g + 1], p.slope),
+						            v2 = act8<true>(acc[r][4 * g + 2], p.slope), v3 = act8<true>(acc[r][4 * g + 3], p.slope);
+						o8[r][g] = SINGLE ? t8Quantize4s<true>(v0, v1, v2, v3, mul) : t8Quantize4<true>(v0, v1, v2, v3, mul);
+					} else {
+						o8[r][g] = SINGLE ? t8Quantize4s(acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3], mul)
+						                  : t8Quantize4(acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3], mul);
 					}
 				}
 			}
+		};
+		auto epiStores = [&](const int u, const int(&o8)[2][4], const Vec4<T>(&o16)[2][4]) __attribute__((always_inline)) {
+			unsigned char *srec = streamRec(u);
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int row = 2 * u + r;  // region row; buffer row index row + 1
+				const bool valid = px < rwv && row < rhv;
+				unsigned char *q8 = smem + outOff + (row + 1) * kT8QRow + (px + 1) * 64;
+				if (valid) {
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						if constexpr (SECOND) {
+							*reinterpret_cast<Vec4<T> *>(srec + r * kT8SRow + ((static_cast<unsigned>(ch * 4 + g) ^ ssw) << 4)) = o16[r][g];
+						}
+						*reinterpret_cast<int *>(q8 + (((2 * ch + (g >> 1)) ^ sw) << 4) + (g & 1) * 8 + hh * 4) = o8[r][g];
+					}
+				}
+			}
+		};
+		const auto nothing = [](int) __attribute__((always_inline)) {};
+		int o8[2][4];
+		Vec4<T> o16[2][4];
+		if (JU_T8_DEFER == 0 || (JU_SKIP(p) & 6) != 0) {
+			// the plain form: a unit's epilogue right behind its MFMAs
+			for (int u = rp; u < np2; u += 2) {
+				f32x16 acc[2];
+				Vec4<T> rv[2][4];
+				kloop(u, acc, rv, std::false_type{}, nothing);
+				if (!(JU_SKIP(p) & 4)) {
+					epiValues(acc, rv, o8, o16, std::false_type{});
+					epiStores(u, o8, o16);
+				}
+			}
+			return;
+		}
+		int u = rp;
+		if (u >= np2) return;
+		f32x16 A[2], B[2];
+		Vec4<T> rvA[2][4], rvB[2][4];
+		kloop(u, A, rvA, std::false_type{}, nothing);
+		bool lastInB = false;
+		for (u += 2; u < np2;) {
+			kloop(u, B, rvB, std::true_type{}, [&](int k) __attribute__((always_inline)) { epiHalf(A, rvA, o8, o16, k); });
+			epiStores(u - 2, o8, o16);
+			u += 2;
+			if (u >= np2) {
+				lastInB = true;
+				break;
+			}
+			kloop(u, A, rvA, std::true_type{}, [&](int k) __attribute__((always_inline)) { epiHalf(B, rvB, o8, o16, k); });
+			epiStores(u - 2, o8, o16);
+			u += 2;
+		}
+		// the layer's last unit: its epilogue is exposed.  ONE code path, the set selected by value (two
+		// branches with the same code on different arrays are merged into one that takes the array through a
+		// pointer, and the arrays then live in scratch).
+		{
+			f32x16 L[2];
+			Vec4<T> rvL[2][4];
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				L[r] = lastInB ? B[r] : A[r];
+#pragma unroll
+				for (int g = 0; g < 4; ++g) rvL[r][g] = lastInB ? rvB[r][g] : rvA[r][g];
+			}
+			epiValues(L, rvL, o8, o16, std::false_type{});
+			epiStores(u - 2, o8, o16);
 		}
 	};
 
