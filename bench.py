@@ -315,7 +315,8 @@ def main() -> int:
                                 + (" + the generator tail on the LDS-resident last layer" if tail_inside else "") + ", one launch")
                           if launches == 1 else
                           ("res_block_fp8_kernel: one residual block (two 3x3 64->64 e4m3 convs) per launch" if fp8
-                           else "res_block_kernel / conv_tower_kernel: 3x3 64->64 residual-block convs"),
+                           else "res_block_pipe_kernel (ReLU blocks; res_block_kernel otherwise): one residual block "
+                                "(two 3x3 64->64 convs) per launch"),
                 "bound": "mfma", "achieved": achieved, "peak": peak,
                 "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",

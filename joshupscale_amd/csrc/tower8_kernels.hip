@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	// sums and activation behind the first, the two roundings behind the second.  (Left to the scheduler with
 	// sched_group_barrier pipelines the VALU block stayed where it was.)  Same arithmetic per element in the same order
 	// (the packed f32 multiplies / adds of the plain form as single ones: same values): the bytes do not
-	// change -- JU_T8_DEFER=0 at build time keeps the plain form for A/B runs.
+	// change -- JU_T8_DEFER=0 at build time keeps the plain form for A/B runs.  (Also measured, no faster: the
+	// groups' LDS writes behind the same MFMAs and the bias as the first MFMAs' C operand, 284-288 against
+	// 283-285 us.)
 #ifndef JU_T8_DEFER
 #define JU_T8_DEFER 1
 #endif
