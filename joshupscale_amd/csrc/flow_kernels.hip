@@ -921,8 +921,14 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 	// -- the resident tower's way -- was measured: 144 KB of requests per workgroup and phase fill the CU's
 	// 64 B/clk vector-memory path for a whole K loop, the streaming loops took 4900-5900 cycles instead of
 	// 3450.)
-	// (the bias floats are requested first and go to LDS below: their wait must not cover the fragments)
-	const float biasMine = tid < 64 ? p.b1[tid] : (tid < 128 ? p.b2[tid - 64] : 0.0f);
+	// (the bias floats go to LDS by DMA: no register, no wait of their own -- the first tile's wait covers them)
+	if (wave == 0) {
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.b1 + lane),
+		    (__attribute__((address_space(3))) void *)biasLds, 4, 0, 0);
+	} else if (wave == 1) {
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.b2 + lane),
+		    (__attribute__((address_space(3))) void *)(biasLds + 64), 4, 0, 0);
+	}
 	// (conv B's set is requested after the first tile's X and pinned in front of the first conv B phase: the
 	// first tile starts on conv A's 36 KB instead of waiting for all 72)
 	Vec8<T> wa[36], wb[36];
@@ -977,6 +983,14 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 		int r = q0 / kFbW, k = q0 - r * kFbW;
 #pragma unroll
 		for (int n = 0; n < kXPerWave; ++n) {
+			if (n == kXPerWave - 1) {
+				// the 77th instruction (wave 0's 20th) has 4 pixels left: it fetches the tile's LAST 8 pixels, four
+				// of them a second time -- under a lane mask it sits in a block of its own and the compiler
+				// puts an `s_waitcnt vmcnt(0)` in front of it (LDS-DMA after LDS-DMA it can no longer tell apart)
+				const int ql = kXPix - 8 + (lane >> 3);
+				r = ql / kFbW;
+				k = ql - r * kFbW;
+			}
 			const unsigned c = static_cast<unsigned>(lane & 7) ^ fbSwz<128>(k);
 			xOff[n] = static_cast<unsigned>(r * p.inPitch + k) * 128u + c * 16u;
 			k += 32;
@@ -986,7 +1000,6 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 			}
 		}
 	}
-	const bool xLastLane = (kXInstr - 1) * 8 + (lane >> 3) < kXPix;  // the 77th instruction covers 4 pixels
 	// Slot v (workgroup b's round r: v = r * grid + b) -> tile.  Edge tiles stage their X through the general
 	// path (~5 k cycles where an interior tile pays nothing), and the launch ends with its slowest workgroup:
 	// so the edge tiles go to the workgroups that have a round less to run (704 tiles on 256 workgroups: 64 of
@@ -1020,11 +1033,10 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 	// instruction n of this wave for the interior tile whose first X pixel is at byte offset `so`
 	auto stageXOne = [&](unsigned so, int n) __attribute__((always_inline)) {
 		const int i = wave + 4 * n;
-		auto dst = (__attribute__((address_space(3))) void *)(smX + i * 1024);
-		if (i < kXInstr - 1) {
-			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcIn, dst, 16, xOff[n], so, 0, 0);
+		if (n < kXPerWave - 1) {
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcIn, (__attribute__((address_space(3))) void *)(smX + i * 1024), 16, xOff[n], so, 0, 0);
 		} else if (i == kXInstr - 1) {
-			if (xLastLane) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcIn, dst, 16, xOff[n], so, 0, 0);
+			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcIn, (__attribute__((address_space(3))) void *)(smX + (kXPix - 8) * 128), 16, xOff[n], so, 0, 0);
 		}
 	};
 	auto tileIsBorder = [&](int tile) __attribute__((always_inline)) {
@@ -1069,7 +1081,8 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 	int epY = 0, epX = 0;      // the pending conv B pair's first image row / first column
 	bool epOn = false;         // a conv B epilogue is pending (from the previous tile)
 
-	// stores of the pair in stg0..3 (behind a K loop's opening wait: the read-back has landed)
+	const auto noStart = []() __attribute__((always_inline)) {};
+	// stores of the pair in stg0..3 (read back behind the previous K loop's last macro-step)
 	auto storeRows = [&]() __attribute__((always_inline)) {
 		if (stOn) {
 			const int lim = p.W - stX;  // columns of the tile inside the image
@@ -1177,16 +1190,19 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 #endif
 	int tile = blockIdx.x;
 	if (tile < p.numTiles) stageX(tile);
+	// (scheduling fences: the first tile's wait below counts on these 36 requests being the YOUNGEST
+	// vector-memory operations in flight.  A wrong order would not go unnoticed silently for long -- the
+	// frames are compared with the plain kernel's -- but it must not depend on the scheduler's mood.)
+#pragma unroll
+	for (int f = 0; f < 36; ++f) asm volatile("" : "+a"(wa[f]));  // (accumulation registers, see above)
+	__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 	for (int f = 0; f < 36; ++f) {
 		wb[f] = __builtin_bit_cast(Vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(rsrcWb, wLane, wBase + f * 1024, 0));
 	}
-#pragma unroll
-	for (int f = 0; f < 36; ++f) asm volatile("" : "+a"(wa[f]));  // (accumulation registers, see above)
+	__builtin_amdgcn_sched_barrier(0);
 	bool firstTile = true;
-	if (tid < 128) biasLds[tid] = biasMine;
-	__syncthreads();  // (the bias floats are in LDS)
-	f32x16 bias = loadBias(0);
+	f32x16 bias;
 	RB_STAMP(tPro);
 	RB_ADD(0, tKernel, tPro);
 	for (; tile < p.numTiles; tile += gridDim.x) {
@@ -1203,6 +1219,7 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 		__syncthreads();                                  // ... for every wave; all are done with T too
 		RB_STAMP(t2);
 		RB_ADD(2, t0, t2);
+		bias = loadBias(0);
 		const int gxA = x0 - 1 + px;
 		const bool colIn = gxA >= 0 && gxA < p.W;
 		auto keepOf = [&](int pair, int r) __attribute__((always_inline)) -> unsigned {
@@ -1214,8 +1231,11 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 			// pair 0 of this wave; behind it the previous tile's last conv B epilogue (its accumulators are in S1)
 			const bool pend = epOn;
 			const f32x16 e0 = S1[0], e1 = S1[1];
-			rbPipeRun<T, false>(ldsBase + (2 * pl) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S0, bias, storeRows,
-			    [&](int m, int k) __attribute__((always_inline)) { if (pend) epiB(e0, e1, m, k); });
+			rbPipeRun<T, false>(ldsBase + (2 * pl) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S0, bias, noStart,
+			    [&](int m, int k) __attribute__((always_inline)) {
+				    if (pend) epiB(e0, e1, m, k);
+				    if (m == 4 && k == 0) storeRows();
+			    });
 			if (pend) {
 				stY = epY;
 				stX = epX;
@@ -1229,12 +1249,18 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 			const unsigned k0 = keepOf(prev, 0), k1 = keepOf(prev, 1);
 			if (q & 1) {
 				const f32x16 e0 = S0[0], e1 = S0[1];
-				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S1, bias, storeRows,
-				    [&](int m, int k) __attribute__((always_inline)) { epiA(e0, e1, prev, k0, k1, m, k); });
+				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S1, bias, noStart,
+				    [&](int m, int k) __attribute__((always_inline)) {
+					    epiA(e0, e1, prev, k0, k1, m, k);
+					    if (m == 4 && k == 0) storeRows();
+				    });
 			} else {
 				const f32x16 e0 = S1[0], e1 = S1[1];
-				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S0, bias, storeRows,
-				    [&](int m, int k) __attribute__((always_inline)) { epiA(e0, e1, prev, k0, k1, m, k); });
+				rbPipeRun<T, false>(ldsBase + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wa, rsrcWb, wLane, wBase, S0, bias, noStart,
+				    [&](int m, int k) __attribute__((always_inline)) {
+					    epiA(e0, e1, prev, k0, k1, m, k);
+					    if (m == 4 && k == 0) storeRows();
+				    });
 			}
 		}
 		RB_STAMP(t3);
@@ -1296,8 +1322,11 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 			const f32x16 e0 = prevAcc[0], e1 = prevAcc[1];
 			const int gyOwn = y0 + 2 * pair;
 			RB_STAMP(tb0);
-			rbPipeRun<T, false>(ldsBase + kRbX + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wb, rsrcWa, wLane, wBase, acc, bias, storeRows,
+			rbPipeRun<T, false>(ldsBase + kRbX + (2 * pair) * (kFbW * 128), colOff, colSwz, hh, wb, rsrcWa, wLane, wBase, acc, bias, noStart,
 			    [&](int m, int k) __attribute__((always_inline)) {
+				    // (the finished pair's stores behind macro-step 4: in front of macro-step 3 they would be in flight
+				    // when the skip values are waited for, and a wait with loads AND stores pending is vmcnt(0))
+				    if (m == 4 && k == 0) storeRows();
 				    if (hasPrev) {
 					    epiB(e0, e1, m, k);
 					    if (m == 11 && k >= 1 && k < 5) loadSkip2(gyOwn, x0, (k - 1) >> 1, ((k - 1) & 1) * 2);
@@ -1328,7 +1357,6 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 		epY = y0 + 2 * (pl + 2 * (nB - 1));
 		epX = x0;
 		epOn = true;
-		bias = loadBias(0);
 	}
 	RB_STAMP(tLoop);
 	// ---- drain: the last tile's last pair ----
