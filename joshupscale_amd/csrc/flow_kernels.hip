@@ -984,9 +984,8 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 #pragma unroll
 		for (int n = 0; n < kXPerWave; ++n) {
 			if (n == kXPerWave - 1) {
-				// the 77th instruction (wave 0's 20th) has 4 pixels left: it fetches the tile's LAST 8 pixels, four
-				// of them a second time -- under a lane mask it sits in a block of its own and the compiler
-				// puts an `s_waitcnt vmcnt(0)` in front of it (LDS-DMA after LDS-DMA it can no longer tell apart)
+				// the 77th instruction has 4 pixels left: every wave's 20th fetches the tile's LAST 8 pixels
+				// instead (four of them a second time) -- no lane mask, no branch
 				const int ql = kXPix - 8 + (lane >> 3);
 				r = ql / kFbW;
 				k = ql - r * kFbW;
@@ -1035,7 +1034,9 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 		const int i = wave + 4 * n;
 		if (n < kXPerWave - 1) {
 			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcIn, (__attribute__((address_space(3))) void *)(smX + i * 1024), 16, xOff[n], so, 0, 0);
-		} else if (i == kXInstr - 1) {
+		} else {
+			// (every wave, the same bytes to the same place: a branch on the wave puts the instruction into
+			// a block of its own, and there the compiler waits vmcnt(0) in front of it)
 			__builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcIn, (__attribute__((address_space(3))) void *)(smX + (kXPix - 8) * 128), 16, xOff[n], so, 0, 0);
 		}
 	};
@@ -1331,7 +1332,9 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 					    epiB(e0, e1, m, k);
 					    if (m == 11 && k >= 1 && k < 5) loadSkip2(gyOwn, x0, (k - 1) >> 1, ((k - 1) & 1) * 2);
 				    } else if (xBehind) {
-					    // (the first conv B pair has no epilogue to run: the next tile's X instead)
+					    // (the first conv B pair has no epilogue to run: the next tile's X instead.  Behind the LAST
+					    // conv B loop instead -- so that no DMA stands in front of the later waits for skip values --
+					    // that loop took 6.2 k cycles and the middle ones were no faster.)
 					    if (k == 2) stageXOne(xSo, m);
 					    else if (k == 5 && m < kXPerWave - 12) stageXOne(xSo, 12 + m);
 				    }
