@@ -1664,8 +1664,8 @@ double Engine::stat(const std::string &key) const {
 	if (key == "registered_pairs") return static_cast<double>(m_RegisteredPairs.size());
 	if (key == "resident_tower") return m_Resident ? 1.0 : 0.0;
 	if (key == "resident_flow") return m_ResidentFlow ? 1.0 : 0.0;
-	if (key == "tower_fast") {  // the generator's resident tower runs the fast schedule (16-bit ReLU models, every region of its shape)
-		return (m_Resident && !m_Fp8Tower && residentTowerFast() && m_Config.genActivation == 0 &&
+	if (key == "tower_fast") {  // the generator's resident tower runs the fast schedule (16-bit models, every region of its shape)
+		return (m_Resident && !m_Fp8Tower && residentTowerFast() && !m_Calibrate &&
 		        residentTowerFastGeometry(m_Config.frameHeight, m_Config.frameWidth, m_ResGX, m_ResGY, m_ResRH)) ? 1.0 : 0.0;
 	}
 	if (key == "fallbacks") return static_cast<double>(m_Fallbacks);

@@ -470,7 +470,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // calibration, the ablation variants) and is what it was.
 template <typename T, int VARIANT, bool HEAD, bool TAIL = false, bool LEAKY = false, bool FAST = false>
 __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p) {
-	static_assert(!FAST || (!LEAKY && (VARIANT == 0 || VARIANT == 4) && (JU_FAST_PRERUN == 2 || JU_FAST_PRERUN == 3)), "the fast schedule is built for the product only");
+	static_assert(!FAST || ((VARIANT == 0 || VARIANT == 4) && (JU_FAST_PRERUN == 2 || JU_FAST_PRERUN == 3)), "the fast schedule is built for the product only");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	// (variants 1 .. 3 are bit masks; 4, 5, 8 are NOT -- round 2 tested `VARIANT & 1` and ran the
 	// calibration build, variant 5, without the halo exchange: its maxima drifted by up to 10 %)
@@ -838,6 +838,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 									dv[k] += static_cast<float>(rvNext[r][g][k]);
 									asm volatile("" : "+v"(dv[k]));  // (keeps the four adds scalar and in their slots)
 								}
+								if constexpr (LEAKY) {
+									// max(x, slope x), slope in [0, 1]; the instruction itself (fmaxf() canonicalises
+									// both operands first: two more instructions in a slot that has room for three)
+									const float t = dv[k] * p.slope;
+									asm volatile("v_max_f32 %0, %1, %2" : "=v"(dv[k]) : "v"(dv[k]), "v"(t));
+								}
 							} else if (k == 4) {
 								const Vec4<T> pk = pack4<T>(dv[0], dv[1], dv[2], dv[3]);
 								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
@@ -847,7 +853,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 								asm volatile("" : "+v"(dlo), "+v"(dhi));
 							} else {
 								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
-								const Vec4<T> o = reluPacked<T>(__builtin_bit_cast(Vec4<T>, u32x2d{dlo, dhi}));
+								const Vec4<T> pk = __builtin_bit_cast(Vec4<T>, u32x2d{dlo, dhi});
+								const Vec4<T> o = LEAKY ? pk : reluPacked<T>(pk);
 								if (lanesValid) *reinterpret_cast<Vec4<T> *>(smem + outOff + (dra + r) * kResRowBytes + outsw[g]) = o;
 							}
 						}
@@ -1506,7 +1513,7 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 		throw std::invalid_argument("resident tower: layer count must be 2*blocks (+1 with a head)");
 	}
 	// the fast schedule where every region has its shape (JU_TOWER_FAST=0: the general one, for A/B runs)
-	const bool fast = residentTowerFast() && !q.leaky && residentTowerFastGeometry(p.H, p.W, p.GX, p.GY, p.RH);
+	const bool fast = residentTowerFast() && residentTowerFastGeometry(p.H, p.W, p.GX, p.GY, p.RH);
 #ifdef JU_TOWER_DEV  // developer builds: the bf16 ReLU instantiations only (compile time)
 	if (q.leaky || dt == kF16 || !p.hasHead) throw std::invalid_argument("resident tower: developer build");
 	if (p.tailW1 != nullptr) {
@@ -1526,14 +1533,22 @@ void launchResidentTower(DType dt, const ResidentTowerParams &q, hipStream_t str
 		if (!(q.slope >= 0.0f && q.slope <= 1.0f)) throw std::invalid_argument("resident tower: negative slope outside [0, 1]");
 		if (p.tailW1 != nullptr) throw std::invalid_argument("resident tower: the fused tail is built for ReLU models");
 		if (!p.hasHead) {
-			if (dt == kF16) launchResidentT<f16, 0, false, false, true>(p, stream);
-			else launchResidentT<bf16, 0, false, false, true>(p, stream);
+			if (fast) {
+				if (dt == kF16) launchResidentT<f16, 0, false, false, true, true>(p, stream);
+				else launchResidentT<bf16, 0, false, false, true, true>(p, stream);
+			} else {
+				if (dt == kF16) launchResidentT<f16, 0, false, false, true>(p, stream);
+				else launchResidentT<bf16, 0, false, false, true>(p, stream);
+			}
 		} else if (g_TowerVariant == 8) {
 			if (dt == kF16) launchResidentT<f16, 8, true, false, true>(p, stream);
 			else launchResidentT<bf16, 8, true, false, true>(p, stream);
 		} else if (g_TowerVariant == 5 && dt == kBF16) {
 			(void)hipMemsetAsync(p.debug, 0, static_cast<std::size_t>(p.nLayers) * sizeof(unsigned), stream);
 			launchResidentT<bf16, 5, true, false, true>(p, stream);
+		} else if (fast && g_TowerVariant == 0) {
+			if (dt == kF16) launchResidentT<f16, 0, true, false, true, true>(p, stream);
+			else launchResidentT<bf16, 0, true, false, true, true>(p, stream);
 		} else {
 			if (dt == kF16) launchResidentT<f16, 0, true, false, true>(p, stream);
 			else launchResidentT<bf16, 0, true, false, true>(p, stream);

@@ -256,7 +256,7 @@ def test_resident_tower_schedule_does_not_change_the_bytes(dtype, monkeypatch):
             outs = {}
             # 0: the product (the FAST instantiation where every region has its shape: epilogues behind the
             # next unit's MFMAs), "general": the general schedule forced, 8: the plain schedule
-            fast_expected = cfg.gen_activation == "relu" and (cfg.frame_height, cfg.frame_width) in ((270, 480), (46, 70))
+            fast_expected = (cfg.frame_height, cfg.frame_width) in ((270, 480), (46, 70))   # (ReLU and LeakyReLU models)
             for variant in (0, "general", 8):
                 lib.ju_debug_set(b"tower_variant", 8 if variant == 8 else 0)
                 lib.ju_debug_set(b"tower_fast", 0 if variant == "general" else 1)
