@@ -905,7 +905,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 		const u64 tu1 = stamp();
 		if constexpr (KIND == 0) prof[7] += tu1 - tu0;
+#ifdef JU_TOWER_SEGPROF  // developer builds: the finish segments one by one (slots 3..6 carry them instead of their usual sums)
+		else if constexpr (KIND == 1 && !DEF) prof[3] += tu1 - tu0;
+		else if constexpr (KIND == 1 && DEF) prof[4] += tu1 - tu0;
+		else if constexpr (KIND == 2 && !streamNext) prof[5] += tu1 - tu0;
+		else prof[6] += tu1 - tu0;
+#else
 		else prof[5] += tu1 - tu0;
+#endif
 		if constexpr (KIND != 0 && EPI) {
 			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
 			// (row ra + r <= rhv always: units are whole pairs, or the odd last row)
@@ -937,7 +944,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				}
 			}
 			const u64 tu2 = stamp();
+#ifndef JU_TOWER_SEGPROF
 			prof[6] += tu2 - tu1;
+#endif
 		}
 	};
 	using R2 = std::integral_constant<int, 2>;
@@ -1009,7 +1018,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 						if (lanesValid) epiStore(outTag, ra + r, g, v);
 					}
 				}
+#ifndef JU_TOWER_SEGPROF
 				prof[6] += stamp() - te0;
+#else
+				(void)te0;
+#endif
 			}
 		} else {
 		auto slot = [&](f32x16(&acc)[2], const int k) __attribute__((always_inline)) {
@@ -1338,8 +1351,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		prof[1] += (VARIANT == 4 && FAST) ? extraPasses * 1000 : t4 - t3;  // (fast schedule: sweep passes beyond the first, x 1000)
 		extraPasses = 0;
 		prof[2] += t1 - t0;
+#ifndef JU_TOWER_SEGPROF
 		prof[3] += t2 - t1;
 		prof[4] += t3 - t2;
+#endif
 		return true;
 	};
 	using No = std::false_type;
