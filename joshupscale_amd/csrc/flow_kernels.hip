@@ -1102,14 +1102,14 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 			stOn = false;
 		}
 	};
-	// skip values of the pair whose first image row is gy0, row r, groups g and g + 1
-	auto loadSkip2 = [&](int gy0, int x0, int r, int g) __attribute__((always_inline)) {
+	// skip values of the pair whose first image row is gy0, row r, groups g and g + 1: the lane's part of the
+	// address (its column, clamped to the image) once per tile, the row scalar -- nothing per load
+	unsigned skipLane = 0;
+	auto loadSkip2 = [&](int gy0, int r, int g) __attribute__((always_inline)) {
 		const int gy = min(gy0 + r, p.H - 1);
-		const int gx = min(x0 + px, p.W - 1);
-		const unsigned vo = static_cast<unsigned>(gx * 64 + cb * 32 + 4 * hh) * 2u;
 		const unsigned so = static_cast<unsigned>(gy * p.inPitch) * 128u;
-		resv[r][g] = __builtin_amdgcn_raw_buffer_load_b64(rsrcIn, vo, so + g * 16, 0);
-		resv[r][g + 1] = __builtin_amdgcn_raw_buffer_load_b64(rsrcIn, vo, so + (g + 1) * 16, 0);
+		resv[r][g] = __builtin_amdgcn_raw_buffer_load_b64(rsrcIn, skipLane, so + g * 16, 0);
+		resv[r][g + 1] = __builtin_amdgcn_raw_buffer_load_b64(rsrcIn, skipLane, so + (g + 1) * 16, 0);
 	};
 	// The epilogues, a group of four values (row r, channel group g) per macro-step, at most three plain VALU
 	// operations behind each MFMA -- what issues in an MFMA's shadow for nothing; more than that, packed-f32
@@ -1286,10 +1286,11 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 		for (int f = 0; f < 36; ++f) asm volatile("" : "+a"(wb[f]));
 		bias = loadBias(1);
 		// the first conv B pair's skip values (the later pairs fetch theirs behind their own last macro-step)
-		loadSkip2(y0 + 2 * pl, x0, 0, 0);
-		loadSkip2(y0 + 2 * pl, x0, 0, 2);
-		loadSkip2(y0 + 2 * pl, x0, 1, 0);
-		loadSkip2(y0 + 2 * pl, x0, 1, 2);
+		skipLane = static_cast<unsigned>(min(x0 + px, p.W - 1) * 64 + cb * 32 + 4 * hh) * 2u;
+		loadSkip2(y0 + 2 * pl, 0, 0);
+		loadSkip2(y0 + 2 * pl, 0, 2);
+		loadSkip2(y0 + 2 * pl, 1, 0);
+		loadSkip2(y0 + 2 * pl, 1, 2);
 		RB_STAMP(t4);
 		RB_ADD(4, t3, t4);
 		__syncthreads();  // T complete, X dead
@@ -1330,7 +1331,7 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 				    if (m == 4 && k == 0) storeRows();
 				    if (hasPrev) {
 					    epiB(e0, e1, m, k);
-					    if (m == 11 && k >= 1 && k < 5) loadSkip2(gyOwn, x0, (k - 1) >> 1, ((k - 1) & 1) * 2);
+					    if (m == 11 && k >= 1 && k < 5) loadSkip2(gyOwn, (k - 1) >> 1, ((k - 1) & 1) * 2);
 				    } else if (xBehind) {
 					    // (the first conv B pair has no epilogue to run: the next tile's X instead.  Behind the LAST
 					    // conv B loop instead -- so that no DMA stands in front of the later waits for skip values --
