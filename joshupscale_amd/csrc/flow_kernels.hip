@@ -807,25 +807,29 @@ __global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
 // ---------------------------------------------------------------------------
 // res_block_pipe_kernel: res_block_kernel with the epilogues in the MFMAs' shadow
 // ---------------------------------------------------------------------------
-// Same tiles, same LDS tiles, same arithmetic per output element as res_block_kernel (its bytes are
-// the reference: JU_RES_BLOCK=plain, tests compare), one wave per SIMD with both convolutions'
-// weights in registers -- but a row pair's epilogue no longer runs between two K loops (the plain
-// kernel: 23.7 of 58 us per block inside the K loops, the rest mostly epilogues at one wave per
-// SIMD).  A 32x32x16 MFMA leaves about three VALU issue slots free while it runs
-// (tools/probes/mfma_valu_overlap.hip), so pair P's epilogue is spread over the macro-steps of pair
-// P + 1's K loop: two accumulator sets alternate, a group of four values (row r, channel group g)
-// per macro-step -- value i behind MFMA i, pack behind MFMA 4, the LDS write behind MFMA 5.
-//   conv A: activation, zero outside the image, into the T tile; only the last pair's epilogue is
-//           exposed (T must be complete at the workgroup barrier).
-//   conv B: + skip, activation, into a per-wave staging tile of two rows (steps 3..10 -- the skip
-//           values are fetched behind the pair's OWN last macro-steps and need the time), read back
-//           transposed behind the last macro-step, and stored as whole 16-byte chunks at the start of
-//           the K loop after that (its `s_waitcnt lgkmcnt(0)` is the only place where the compiler's
-//           conservative wait for the read-back costs nothing).  The last pair of a tile finishes
+// ReLU blocks only (every other activation: res_block_kernel).  Same tiles, same LDS tiles, same values as
+// res_block_kernel up to the sign of zeros in the intermediate tensors (JU_RES_BLOCK=plain keeps that kernel;
+// the tests require equal frames and state), one wave per SIMD with both convolutions' weights in
+// accumulation registers -- but a row pair's epilogue no longer runs between two K loops (the plain kernel:
+// 23.7 of 58 us per block inside the K loops, the rest mostly epilogues at one wave per SIMD).  A 32x32x16
+// MFMA leaves about three VALU issue slots free while it runs (tools/probes/mfma_valu_overlap.hip), so pair
+// P's epilogue is spread over the macro-steps of pair P + 1's K loop: two accumulator sets alternate, a group
+// of four values (row r, channel group g) per macro-step.
+//   conv A: pack -> ReLU on the packed values -> AND mask outside the image -> T tile; only the last pair's
+//           epilogue is exposed (T must be complete at the workgroup barrier).
+//   conv B: + skip (value i behind MFMA i), pack + ReLU behind MFMA 4, into a per-wave staging tile of two
+//           rows behind MFMA 5 (macro-steps 3..10 -- the skip values are fetched behind the pair's OWN last
+//           macro-step and need the time), read back transposed behind macro-step 11, and stored as whole
+//           16-byte chunks behind macro-step 4 of the K loop after that (behind macro-step 3's wait for the skip
+//           values: a wait with loads AND stores pending is vmcnt(0)).  The last pair of a tile finishes
 //           inside the next tile's first K loops.
-//   bias:   64 + 64 floats in LDS, fetched into a 16-register vector behind the previous K loop's
-//           last MFMAs and used as the C operand of the pair's first MFMAs (no accumulator is ever
-//           initialised by moves, no bias registers held for the whole launch).
+//   X tile: an interior tile is 20 table-driven LDS-DMA instructions per wave, issued behind the MFMAs of the
+//           first conv B loop (all four waves issuing them at once stall ~3 k cycles in the CU's vector-memory
+//           queue); an edge tile takes the general path of res_block_kernel, and the edge tiles are dealt to the
+//           workgroups that have a round less to run.
+//   bias:   64 + 64 floats in LDS (by DMA), read into a 16-register vector per phase and used as the C operand
+//           of a pair's first MFMAs (no accumulator is initialised by moves).
+// In-kernel phase sums: -DJU_RB_PROF + tools/rb_pipe_profile.py.
 constexpr int kRpStageRow = kFbOutW * 64;         // one row of 30 px x 32 couts, 16-bit
 constexpr int kRpStageWave = 2 * kRpStageRow;
 constexpr int kRpLds = kRbX + kRbT + 4 * kRpStageWave + 512;
@@ -835,8 +839,8 @@ static_assert(kRpLds <= 160 * 1024, "res block tile (pipelined)");
 // MFMA of each row), `atStart()` behind the opening wait, `behind(m, k)` behind MFMA k of macro-step m.
 // LDS instructions issued by the hooks only make the counted waits stricter (they count what is
 // outstanding, the hooks' instructions are younger than the fragments waited for or complete before them).
-// STREAM: the OTHER convolution's fragments replace this one's as they die (behind each macro-step the three
-// fragments it used), so one set of 36 serves both convolutions: 144 registers instead of 288.
+// STREAM (measured, not used: see the kernel): the OTHER convolution's fragments replace this one's as they
+// die, behind each macro-step the three fragments it used.
 template <typename T, bool STREAM, typename FS, typename FB>
 __device__ __forceinline__ void rbPipeRun(unsigned rowAddr, const unsigned (&colOff)[3], const unsigned (&colSwz)[3], int hh,
     Vec8<T> (&w)[36], const __amdgpu_buffer_rsrc_t nextW, unsigned nextLane, unsigned nextBase, f32x16 (&acc)[2],
