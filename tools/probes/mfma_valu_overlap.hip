@@ -5,6 +5,7 @@
 // are NOT used -- the figure is relative to the N = 0 row).
 //
 //     hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_valu_overlap.hip -o build/mfma_valu_overlap
+//     (-DPROBE_FP8: the same behind v_mfma_scale_f32_32x32x64_f8f6f4, 16 passes)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -39,6 +40,12 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *
 		a[i] = (__bf16)(0.001f * (lane + i));
 		b[i] = (__bf16)(0.002f * (lane - i));
 	}
+	typedef int i32x8p __attribute__((ext_vector_type(8)));
+	i32x8p a8, b8;
+	for (int i = 0; i < 8; ++i) {
+		a8[i] = 0x38383838 + lane;
+		b8[i] = 0x30303030 + i;
+	}
 	f32x16 acc0 = {}, acc1 = {};
 	float x0 = lane, x1 = 2 * lane, x2 = 3, x3 = 4, y2 = 5;
 	unsigned u0 = lane, u1 = lane * 3;
@@ -52,8 +59,13 @@ __global__ __launch_bounds__(256, 1) void probe(float *out, unsigned long long *
 	for (int it = 0; it < iters; ++it) {
 #pragma unroll
 		for (int m = 0; m < 8; ++m) {
+#ifdef PROBE_FP8  // v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 operands, 16 passes) instead of the bf16 instruction
+			if (m & 1) acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc1, 0, 0, 0, 127, 0, 127);
+			else acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc0, 0, 0, 0, 127, 0, 127);
+#else
 			if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
 			else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+#endif
 #pragma unroll
 			for (int n = 0; n < N; ++n) {
 				if constexpr (KIND == kCvtPk) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u0) : "v"(x0), "v"(x1));
@@ -134,7 +146,11 @@ int main() {
 	CHECK(hipMalloc(&g_scratch, 256u << 20));
 	const int iters = 20000;
 	const double base = run<kNone, 0>(out, ticks, iters);
+	#ifdef PROBE_FP8
+	std::printf("one wave per SIMD, v_mfma_scale_f32_32x32x64_f8f6f4 back to back: %.2f ns per MFMA (= 64 cycles at %.2f GHz)\n", base, 64.0 / base);
+#else
 	std::printf("one wave per SIMD, v_mfma_f32_32x32x16_bf16 back to back: %.2f ns per MFMA (= 32 cycles at %.2f GHz)\n", base, 32.0 / base);
+#endif
 	std::printf("time per MFMA relative to that, with N instructions behind every MFMA:\n%-34s %6d %6d %6d %6d %6d %6d %6d\n", "N =", 1, 2, 3, 4, 6, 8, 12);
 	sweep<kCvtPk>(out, ticks, iters, base);
 	sweep<kPkMax>(out, ticks, iters, base);
