@@ -62,6 +62,89 @@ def test_small_models_match_oracle(arch, pad, h, w, blocks, extra, dtype):
     rt.close()
 
 
+# Every hyper-parameter the reference constructors are parametric in (models.py:257-263, 334-339,
+# 364-365, 449-468, 484-491) and the loader admits (csrc/model.cpp validateConfig, model_file.py):
+# generator width, flow auto-encoder depth / widths (odd and even filter lists), flow-resnet width,
+# number of flow inputs.  None of these run on the 64-filter fast kernels; the engine takes its
+# generic per-convolution path (conv_mfma_kernel, conv_tower_kernel, tail_kernel) for them.
+AE7_WIDE = (64, 128, 256, 512, 256, 128, 64)
+WIDTH_CASES = [
+    ("gen32", 30, 48, dict(gen_filters=32)),
+    ("gen96", 30, 48, dict(gen_filters=96)),
+    ("gen128", 30, 48, dict(gen_filters=128)),
+    ("gen256", 17, 33, dict(gen_filters=256, gen_blocks=2)),
+    ("ae3", 30, 48, dict(flow_filters=(32, 64, 32))),
+    ("ae4-even", 30, 48, dict(flow_filters=(32, 64, 64, 32))),
+    ("ae5", 30, 48, dict(flow_filters=(32, 64, 128, 64, 32))),
+    ("ae5-first64", 34, 50, dict(flow_filters=(64, 96, 128, 96, 64))),
+    ("ae7-wide", 30, 48, dict(flow_filters=AE7_WIDE)),
+    ("ae2-even", 17, 33, dict(flow_filters=(32, 32))),
+    ("res32", 34, 50, dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=32, flow_res_blocks=2)),
+    ("res128", 34, 50, dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=128, flow_res_blocks=2)),
+    ("res96-pad8", 30, 48, dict(flow_arch="resnet", flow_pad_factor=8, flow_res_filters=96, flow_res_blocks=1)),
+    ("in1", 30, 48, dict(num_flow_inputs=1)),
+    ("in2", 30, 48, dict(num_flow_inputs=2)),
+    ("in3", 34, 50, dict(num_flow_inputs=3, flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2)),
+    ("in5", 30, 48, dict(num_flow_inputs=5)),
+    ("in5-res128-gen32", 34, 50, dict(num_flow_inputs=5, flow_arch="resnet", flow_pad_factor=0, flow_res_filters=128,
+                                     flow_res_blocks=2, gen_filters=32)),
+    ("gen128-ae5-in2-lrelu", 30, 48, dict(gen_filters=128, flow_filters=(32, 64, 128, 64, 32), num_flow_inputs=2, **LRELU)),
+    ("blocks0", 30, 48, dict(gen_blocks=0)),
+    # mid-size ragged geometry: 135x241 pads to 136x248, several MFMA tiles per row, partial last ones
+    ("mid-gen128", 135, 241, dict(gen_filters=128, gen_blocks=2)),
+    ("mid-gen32-ae5", 135, 241, dict(gen_filters=32, gen_blocks=2, flow_filters=(32, 64, 128, 64, 32))),
+    ("mid-ae7-wide-in3", 135, 241, dict(gen_blocks=2, flow_filters=AE7_WIDE, num_flow_inputs=3)),
+    ("mid-res128-in5", 135, 241, dict(gen_blocks=2, flow_arch="resnet", flow_pad_factor=0, flow_res_filters=128,
+                                      flow_res_blocks=2, num_flow_inputs=5)),
+    ("mid-res32-in2", 135, 241, dict(gen_blocks=2, flow_arch="resnet", flow_pad_factor=0, flow_res_filters=32,
+                                     flow_res_blocks=2, num_flow_inputs=2)),
+]
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
+@pytest.mark.parametrize("name,h,w,kw", WIDTH_CASES, ids=[c[0] for c in WIDTH_CASES])
+def test_nondefault_widths_match_oracle(name, h, w, kw, dtype):
+    """Model shapes the loader accepts beside the 64-filter defaults: 4 recurrent frames against
+    the float64 oracle, u8 output and the internal tensors (flow head, HR state, generator input)."""
+    kw = dict(kw)
+    kw.setdefault("gen_blocks", 3)
+    cfg = small_config(frame_height=h, frame_width=w, **kw)
+    wts, blob, rt = make(cfg, dtype)
+    oc = oracle_config(cfg)
+    sess = O.Session(wts, oc)
+    frames = M.synthetic_frames(4, h, w, seed=7, kind="smooth")
+    worst = dict(flow=0.0, raw=0.0, gen_in=0.0)
+    for t in range(4):
+        trace = {}
+        ref = sess.run(frames[t], trace)
+        out = rt.process_image(frames[t])
+        check_u8(out, ref, dtype, ("widths", name, h, w, t))
+        flow = rt.read_tensor("flow").reshape(oc.padded_height, oc.padded_width, 32)
+        worst["flow"] = max(worst["flow"], err(flow, trace["flow"])["max_abs"])
+        state = rt.read_tensor("state").reshape(4 * h, 4 * w, 4)
+        worst["raw"] = max(worst["raw"], err(state[..., :3], sess.last.output_raw)["max_abs"])
+        gin = gen_in_to_reference(rt.read_tensor("gen_in"), h, w)
+        worst["gen_in"] = max(worst["gen_in"], err(gin, trace["gen_in_ref"])["max_abs"])
+    record(("widths-tensors", name, h, w), dtype, worst)
+    assert worst["flow"] <= TOL[dtype]["flow"] and worst["raw"] <= TOL[dtype]["raw"] and \
+        worst["gen_in"] <= TOL[dtype]["raw"], (name, worst)
+    rt.close()
+
+
+@pytest.mark.parametrize("gen_filters", [32, 128])
+def test_fp8_rejects_generators_that_are_not_64_wide(gen_filters):
+    """JU_DTYPE_FP8 exists for the 64 -> 64 block convolutions only: every other generator width is
+    refused with a message that says so, by ju_create and by the header's compute_dtype alike."""
+    cfg = small_config(gen_filters=gen_filters)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    with pytest.raises(R.JoshUpscaleError, match="fp8 tower needs a 64-filter generator"):
+        R.Runtime(blob, 0, R.DTYPE_FP8)
+    cfg8 = small_config(gen_filters=gen_filters, compute_dtype=M.DTYPE_FP8)
+    blob8 = M.serialize(cfg8, M.make_seeded_weights(cfg8))
+    with pytest.raises(R.JoshUpscaleError, match="fp8 tower needs a 64-filter generator"):
+        R.Runtime(blob8, 0)
+
+
 @pytest.mark.parametrize("name,cfg", [
     ("small_autoencoder", small_config()),
     ("small_resnet", small_config(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2,
