@@ -83,7 +83,11 @@ from joshupscale_amd import runtime as R  # noqa: E402
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0  # HBM3E, same guide
 PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled e4m3 MFMA (same guide: twice the bf16 rate)
-PREROLL_FRAMES = 256  # ~0.15 s of frames before --warmup: the GPU's clocks ramp while the first frames run
+# ~0.13 s of frames in front of --warmup: the GPU's clocks ramp while the first frames run (measured
+# on one box, `--steps 20 --warmup 5`: 1966 / 1972 frames/s with the pre-roll, 1778 / 1763 without --
+# 25 frames are 12 ms).  It is NOT part of the contract's W and is therefore reported at the TOP level
+# of the JSON line (`preroll`, `untimed_frames`), not hidden in `config`; `--preroll 0` gives the bare contract.
+PREROLL_FRAMES = 256
 TRAFFIC_PROFILE = "r03_tower_traffic.json"  # PMC summary of the dominant kernel (tools/pmc_traffic.sh)
 
 
@@ -281,7 +285,8 @@ def main() -> int:
             "metric": "frames/sec 480x270->1920x1080 recurrent SR" if args.preset.startswith("psp")
                       else f"frames/sec {w}x{h}->{4 * w}x{4 * h} recurrent SR",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "warmup": args.warmup, "preroll": args.preroll, "untimed_frames": args.preroll + args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {
@@ -325,6 +330,8 @@ def main() -> int:
                 "launch_ms_how": "HIP events around the kernel's launches inside whole frames on the engine's stream "
                                  "(ju_time_steps tag@frame), mean over %d frames" % args.roofline_iters,
                 "launch_ms_back_to_back": ms_alone,
+                # rounds 1-2 priced `frac` on the back-to-back figure; both are kept side by side
+                "frac_back_to_back": (flops_per_launch * launches / (ms_alone * 1e-3) / 1e12 / peak) if ms_alone > 0 else None,
                 "flops_per_launch": flops_per_launch,
             },
         }

@@ -128,8 +128,12 @@ void validateConfig(const ModelConfig &c) {
 		bad("unknown compute dtype");  // 2 = JU_DTYPE_FP8 (e4m3 block convolutions over fp16)
 	}
 	if (c.flowPadFactor < 0 || c.flowPadFactor > 256) bad("flow_pad_factor must be in 0..256");
-	if (c.genFilters <= 0 || c.genFilters > 1024 || c.genFilters % 32 != 0) {
-		bad("gen_filters must be a multiple of 32 (at most 1024)");
+	// Widths: the reference constructors take any integer (models.py:257-263, 334-339, 484-491); this
+	// engine admits what its GPU parity tests run against the oracle (tests/test_gpu_parity.py
+	// test_nondefault_widths_match_oracle): multiples of the 32-channel MFMA block up to the largest
+	// width tested.  model_file.py validate_config states the same limits with the same messages.
+	if (c.genFilters <= 0 || c.genFilters > 256 || c.genFilters % 32 != 0) {
+		bad("gen_filters must be a multiple of 32 (at most 256)");
 	}
 	if (c.genBlocks < 0 || c.genBlocks > 256) bad("gen_blocks must be in 0..256");
 	if (!(c.bnEps > 0.0f) || !std::isfinite(c.bnEps)) bad("bn_eps must be positive and finite");
@@ -157,11 +161,11 @@ void validateConfig(const ModelConfig &c) {
 			bad("padded frame size must be divisible by 2^(flow depth)");
 		}
 		for (int f : c.flowFilters) {
-			if (f <= 0 || f > 1024 || f % 32 != 0) bad("flow filters must be multiples of 32 (at most 1024)");
+			if (f <= 0 || f > 512 || f % 32 != 0) bad("flow filters must be multiples of 32 (at most 512)");
 		}
 	} else {
-		if (c.flowResFilters <= 0 || c.flowResFilters > 1024 || c.flowResFilters % 32 != 0) {
-			bad("flow filters must be multiples of 32 (at most 1024)");
+		if (c.flowResFilters <= 0 || c.flowResFilters > 256 || c.flowResFilters % 32 != 0) {
+			bad("flow_res_filters must be a multiple of 32 (at most 256)");
 		}
 		if (c.flowResBlocks < 0 || c.flowResBlocks > 256) bad("flow_res_blocks must be in 0..256");
 	}

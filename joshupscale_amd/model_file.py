@@ -214,8 +214,36 @@ def make_seeded_weights(cfg: ModelConfig, seed: int = 42) -> Dict[str, np.ndarra
     return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
 
 
-def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray]) -> bytes:
-    """Build the container bytes."""
+def validate_config(cfg: ModelConfig) -> None:
+    """The width / depth limits of the C++ loader (csrc/model.cpp validateConfig), same messages:
+    the reference constructors take any integer (models.py:257-263, 334-339, 484-491); the
+    engine admits what its GPU parity tests run against the oracle."""
+    def bad(what: str):
+        raise ValueError("Invalid model: " + what)
+    if not 1 <= cfg.num_flow_inputs <= 5:
+        bad("1..5 flow inputs supported")
+    if cfg.gen_filters <= 0 or cfg.gen_filters > 256 or cfg.gen_filters % 32:
+        bad("gen_filters must be a multiple of 32 (at most 256)")
+    if not 0 <= cfg.gen_blocks <= 256:
+        bad("gen_blocks must be in 0..256")
+    if cfg.flow_arch == "autoencoder":
+        nb = len(cfg.flow_filters) // 2
+        if nb < 1 or cfg.padded_height % (1 << nb) or cfg.padded_width % (1 << nb):
+            bad("padded frame size must be divisible by 2^(flow depth)")
+        if any(f <= 0 or f > 512 or f % 32 for f in cfg.flow_filters):
+            bad("flow filters must be multiples of 32 (at most 512)")
+    else:
+        if cfg.flow_res_filters <= 0 or cfg.flow_res_filters > 256 or cfg.flow_res_filters % 32:
+            bad("flow_res_filters must be a multiple of 32 (at most 256)")
+        if not 0 <= cfg.flow_res_blocks <= 256:
+            bad("flow_res_blocks must be in 0..256")
+
+
+def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray], validate: bool = True) -> bytes:
+    """Build the container bytes.  ``validate=False`` writes a header the loader will reject
+    (the loader tests need such files)."""
+    if validate:
+        validate_config(cfg)
     names = list(weights.keys())
     ff = list(cfg.flow_filters) + [0] * (8 - len(cfg.flow_filters))
     if len(cfg.flow_filters) > 8:

@@ -594,8 +594,10 @@ def inference_step(cur_frame_u8: np.ndarray, state: State, wts: Weights,
     output = postprocess(output_raw)                              # :805-807
     if cfg.normalize_brightness:
         output_raw = output_raw - brightness                      # :809-810
+    # :821-823 `[cur_frame_pad] + last_frames[:-1]`; with a single flow input the reference's graph
+    # has no last-frame inputs and emits one state output nothing consumes: keep n-1 frames
     new_state = State(output_raw,
-                      [cur_pad] + list(state.last_frames[:-1]))  # :821-823
+                      ([cur_pad] + list(state.last_frames[:-1]))[:cfg.num_flow_inputs - 1])
     return StepOutputs(output, output_raw, pre_warp, flow, new_state)
 
 

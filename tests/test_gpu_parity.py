@@ -79,8 +79,10 @@ WIDTH_CASES = [
     ("ae5-first64", 34, 50, dict(flow_filters=(64, 96, 128, 96, 64))),
     ("ae7-wide", 30, 48, dict(flow_filters=AE7_WIDE)),
     ("ae2-even", 17, 33, dict(flow_filters=(32, 32))),
+    ("ae8-depth4", 30, 48, dict(flow_filters=(32, 64, 128, 256, 256, 128, 64, 32))),   # 2 x 3 pixels at the deepest level
     ("res32", 34, 50, dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=32, flow_res_blocks=2)),
     ("res128", 34, 50, dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=128, flow_res_blocks=2)),
+    ("res256", 17, 33, dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=256, flow_res_blocks=1)),
     ("res96-pad8", 30, 48, dict(flow_arch="resnet", flow_pad_factor=8, flow_res_filters=96, flow_res_blocks=1)),
     ("in1", 30, 48, dict(num_flow_inputs=1)),
     ("in2", 30, 48, dict(num_flow_inputs=2)),

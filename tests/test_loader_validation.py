@@ -121,3 +121,51 @@ def test_mutated_headers_and_tables_never_crash(hip_library, data):
     lib = hip_library
     rc = lib.ju_validate_model(blob, len(blob))
     assert rc in (0, 1), (rc, lib.ju_last_error())
+
+
+# Widths outside what the GPU parity tests run (test_gpu_parity.py test_nondefault_widths_match_oracle)
+# are refused by BOTH loaders with the SAME message: nothing loads that no test has compared with the oracle.
+BAD_WIDTHS = [
+    (dict(gen_filters=48), "gen_filters must be a multiple of 32 (at most 256)"),
+    (dict(gen_filters=288), "gen_filters must be a multiple of 32 (at most 256)"),
+    (dict(gen_filters=1024), "gen_filters must be a multiple of 32 (at most 256)"),
+    (dict(flow_filters=(32, 40, 32)), "flow filters must be multiples of 32 (at most 512)"),
+    (dict(flow_filters=(64, 128, 256, 1024, 256, 128, 64)), "flow filters must be multiples of 32 (at most 512)"),
+    (dict(flow_filters=(32,)), "padded frame size must be divisible by 2^(flow depth)"),
+    (dict(flow_filters=(32, 64, 128, 256, 256, 128, 64, 32), frame_width=50), "padded frame size must be divisible by 2^(flow depth)"),
+    (dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=48), "flow_res_filters must be a multiple of 32 (at most 256)"),
+    (dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=512), "flow_res_filters must be a multiple of 32 (at most 256)"),
+    (dict(num_flow_inputs=6), "1..5 flow inputs supported"),
+    (dict(num_flow_inputs=0), "1..5 flow inputs supported"),
+]
+
+
+@pytest.mark.parametrize("kw,message", BAD_WIDTHS, ids=[str(sorted(k.items()))[:50] for k, _ in BAD_WIDTHS])
+def test_untested_widths_are_refused_by_both_loaders_with_one_message(hip_library, kw, message):
+    cfg = small_config(gen_blocks=1, **kw)
+    with pytest.raises(ValueError) as py:
+        M.validate_config(cfg)
+    assert str(py.value) == "Invalid model: " + message
+    # the same header through the C++ loader (weights of a valid model: the header is checked first)
+    blob = M.serialize(cfg, WTS, validate=False)
+    with pytest.raises(R.JoshUpscaleError) as cc:
+        R.validate_model(blob)
+    assert cc.value.code == 1 and str(py.value) in str(cc.value), str(cc.value)
+
+
+def test_every_width_the_gpu_suite_runs_is_accepted_by_both_loaders(hip_library):
+    import ast
+    import os
+    src = open(os.path.join(os.path.dirname(__file__), "test_gpu_parity.py")).read()
+    tree = ast.parse(src)
+    ns = {"LRELU": dict(flow_activation="lrelu", gen_activation="lrelu", gen_negative_slope=0.2)}
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") in ("AE7_WIDE", "WIDTH_CASES"):
+            exec(compile(ast.Module([node], []), "widths", "exec"), ns)
+    assert len(ns["WIDTH_CASES"]) >= 20
+    for name, h, w, kw in ns["WIDTH_CASES"]:
+        kw = dict(kw)
+        kw.setdefault("gen_blocks", 1)
+        cfg = small_config(frame_height=h, frame_width=w, **kw)
+        M.validate_config(cfg)
+        R.validate_model(M.serialize(cfg, M.make_seeded_weights(cfg)))

@@ -30,6 +30,37 @@ def test_numpy_oracle_vs_torch_restatement(arch, pad, h, w, extra):
         assert (a[..., 3] == 0).all()
 
 
+# model shapes beside the defaults (the reference constructors are parametric in all of them:
+# models.py:257-263, 334-339, 364-365, 449-468, 484-491): all three restatements must agree there too
+WIDTHS = [
+    dict(gen_filters=32), dict(gen_filters=128), dict(gen_blocks=0),
+    dict(flow_filters=(32, 64, 32)), dict(flow_filters=(32, 64, 64, 32)), dict(flow_filters=(32, 32)),
+    dict(flow_filters=(64, 96, 128, 96, 64), frame_height=34, frame_width=50),
+    dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=32, flow_res_blocks=2, frame_height=34, frame_width=50),
+    dict(flow_arch="resnet", flow_pad_factor=8, flow_res_filters=96, flow_res_blocks=1),
+    dict(num_flow_inputs=1), dict(num_flow_inputs=2), dict(num_flow_inputs=5),
+    dict(num_flow_inputs=1, flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=1),
+    dict(gen_filters=128, flow_filters=(32, 64, 128, 64, 32), num_flow_inputs=2, **LRELU),
+]
+
+
+@pytest.mark.parametrize("kw", WIDTHS, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items())[:60])
+def test_restatements_agree_on_nondefault_widths(kw):
+    from oracle.c_binding import CSession
+    cfg = small_config(**kw)
+    wts = M.make_seeded_weights(cfg)
+    s = O.Session(wts, oracle_config(cfg))
+    ts = TorchSession(wts, oracle_config(cfg))
+    cs = CSession(M.serialize(cfg, wts), cfg.frame_height, cfg.frame_width)
+    for f in M.synthetic_frames(3, cfg.frame_height, cfg.frame_width, seed=7, kind="smooth"):
+        a, b, c = s.run(f), ts.run(f), cs.run(f)
+        raw = ts.output_raw[0].permute(1, 2, 0).numpy()
+        assert np.abs(raw - s.last.output_raw).max() <= 1e-9
+        assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+        assert err(cs.output_raw(), s.last.output_raw)["max_abs"] < 2e-5
+        assert u8_stats(c, a)["max"] <= 1 and (c[..., 3] == 0).all()
+
+
 def test_numpy_oracle_vs_torch_restatement_8bit_tower():
     """The 8-bit tower scheme (csrc/fp8.h) restated twice: the oracle's frexp-based e4m3
     rounding against PyTorch's own float8_e4m3fn conversion, scales derived independently.

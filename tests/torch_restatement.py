@@ -218,7 +218,7 @@ class TorchSession:
         x = (torch.tanh(x) + _up_tf1(cur, 4)).clamp(-0.5, 0.5)
         self.output_raw = x
         self.pre_gen = x
-        self.last = [cur_pad] + self.last[:-1]
+        self.last = ([cur_pad] + self.last[:-1])[:cfg.num_flow_inputs - 1]  # (one flow input: no history)
         out = ((x + 0.5) * 255).to(torch.uint8)[0].permute(1, 2, 0).numpy()
         res = np.zeros(out.shape[:2] + (4,), np.uint8)
         res[..., :3] = out
