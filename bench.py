@@ -331,7 +331,7 @@ def main() -> int:
                                  "(ju_time_steps tag@frame), mean over %d frames" % args.roofline_iters,
                 "launch_ms_back_to_back": ms_alone,
                 # rounds 1-2 priced `frac` on the back-to-back figure; both are kept side by side
-                "frac_back_to_back": (flops_per_launch * launches / (ms_alone * 1e-3) / 1e12 / peak) if ms_alone > 0 else None,
+                "frac_back_to_back": (flops_per_launch / (ms_alone * 1e-3) / 1e12 / peak) if ms_alone > 0 and launches == 1 else None,
                 "flops_per_launch": flops_per_launch,
             },
         }
