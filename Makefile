@@ -10,7 +10,7 @@ CXXFLAGS   := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wall
               -Wno-unused-parameter
 HIPFLAGS   := --offload-arch=$(ARCH) $(CXXFLAGS)
 SRCS_CPP   := model.cpp engine.cpp c_api.cpp core_api.cpp log.cpp comm.cpp graphics.cpp
-SRCS_HIP   := conv_kernels.hip tower_kernels.hip frame_kernels.hip fp8_kernels.hip flow_kernels.hip tower8_kernels.hip
+SRCS_HIP   := conv_kernels.hip tower_kernels.hip frame_kernels.hip fp8_kernels.hip flow_kernels.hip res_block_kernels.hip splitk_kernels.hip tower8_kernels.hip
 OBJS       := $(addprefix $(OBJ)/,$(SRCS_CPP:.cpp=.o)) $(addprefix $(OBJ)/,$(SRCS_HIP:.hip=.o))
 
 all: $(OUT)/libJoshUpscale.so
@@ -19,7 +19,7 @@ all: $(OUT)/libJoshUpscale.so
 # consume every accumulator with VALU ops; in AGPR form each value first costs a
 # v_accvgpr_read (128 per layer and lane in the tower kernel, ~2 % of its time).
 KERNELFLAGS := -mllvm -amdgpu-mfma-vgpr-form
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/kernel_common.h Makefile
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/kernels.h $(CSRC)/kernel_common.h $(CSRC)/flow_block_common.h Makefile
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) $(KERNELFLAGS) -c $< -o $@
 
