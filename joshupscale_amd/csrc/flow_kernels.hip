@@ -47,6 +47,7 @@ struct FlowBlockParams {
 	int act1, act2;   // 0 none, 1 ReLU, 2 LeakyReLU(slope)
 	float slope;
 	int skip;         // timing ablation (JU_FB_SKIP, developer only): 1 staging/expansion, 2 conv A, 4 conv B, 8 stores
+	int prio;         // wave priority scheme (kernel_common.h applyWavePriority)
 	// PACK instantiation (the flow net's first block): the 16-channel input records are built
 	// here from the u8 frame and the previous packed tensor (launchPackFrames' arithmetic) and
 	// written to `packOut` by the tile that owns the pixel; `in` is unused
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6;
+	if constexpr (NW == 8) applyWavePriority(p.prio, wave, NW);
 	const int lane = tid & 63;
 	const int px = lane & 31;
 	const int hh = lane >> 5;
@@ -566,6 +568,7 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.act2 = q.act2;
 	p.slope = q.slope;
 	p.skip = ablationSkipBits();
+	p.prio = wavePriorityMode(0);
 	p.frame = q.packFrame;
 	p.frameStride = q.packFrameStride;
 	p.packPrev = q.packPrev;

@@ -406,6 +406,7 @@ struct Fp8BlockParams {
 	int H, W, pitch;
 	int tilesX, numTiles;
 	int skip;                   // timing ablation (JU_FB_SKIP, developer only)
+	int prio;                   // wave priority scheme (kernel_common.h applyWavePriority)
 };
 
 template <int TH>
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
 	const int cb = wave & 1, pl = wave >> 1;  // cout block; pairs pl, pl + 4, ...
 	unsigned char *stage = smem + G::OFF_STAGE + wave * G::STAGE_WAVE;
+	applyWavePriority(p.prio, wave, 8);
 
 	// conv A's fragments of this wave's cout block: registers, for the whole launch (buffer
 	// loads: ONE lane offset register, the tap offset scalar -- flat loads keep 18 64-bit
@@ -605,7 +607,9 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 					}
 				}
 			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the skip records have landed (this wave's own DMA)
+			// (timing ablation bit 128: WITHOUT this wait -- vmcnt counts stores too, so it also waits for the
+			// previous pair's output stores to be acknowledged and for the next tile's X8 DMA; wrong values)
+			if (!(JU_SKIP(p) & 128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the skip records have landed (this wave's own DMA)
 			if (JU_SKIP(p) & 64) continue;
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
@@ -800,6 +804,7 @@ void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 	k.W = q.W;
 	k.pitch = towerPitch(q.W);
 	k.skip = ablationSkipBits();
+	k.prio = wavePriorityMode(0);
 	const int cus = currentDeviceCUs();
 	// Tile height: a CU works through ceil(tiles / CUs) tiles one after the other, each
 	// costing about (rows + 5) row-times (recompute ring + per-tile fixed work): take the

@@ -116,6 +116,28 @@ inline int ablationSkipBits() {
 inline int ablationSkipBits() { return 0; }
 #endif
 
+// Static wave priority for kernels that run TWO waves per SIMD (8-wave workgroups): both waves of a
+// SIMD execute the same phases, so without help their K loops compete for the matrix pipe and their
+// epilogues for the VALU issue -- nothing overlaps.  A fixed priority for one half (priority outranks
+// age in the issue arbitration, MI355X_MICROARCH.md "Two waves per SIMD") lets that half run its K
+// loop first; from then on one wave's epilogue runs in the shadow of its partner's MFMAs.
+// JU_WAVE_PRIO (developer A/B): 0 none, 1 / 3 = s_setprio 1 / 3 for waves NW/2.., 2 = s_setprio 1 for
+// waves 0 .. NW/2-1.  Timing only: no value changes.  (s_setprio around every K loop was tried in
+// res_block_fp8_kernel: the instruction is a scheduling barrier for hipcc and the kernel ran 2x slower.)
+inline int wavePriorityMode(int fallback) {
+	static const int mode = [] {
+		const char *e = std::getenv("JU_WAVE_PRIO");
+		return e ? std::atoi(e) : -1;
+	}();
+	return mode >= 0 ? mode : fallback;
+}
+__device__ __forceinline__ void applyWavePriority(int mode, int wave, int waves) {
+	const bool upper = wave >= waves / 2;
+	if (mode == 1 && upper) __builtin_amdgcn_s_setprio(1);
+	else if (mode == 3 && upper) __builtin_amdgcn_s_setprio(3);
+	else if (mode == 2 && !upper) __builtin_amdgcn_s_setprio(1);
+}
+
 // CU count of the CURRENT device (a process may drive several GPUs: not a function-local
 // static of whichever device launched first).
 inline int currentDeviceCUs() {

@@ -43,6 +43,7 @@ struct SplitKParams {
 	int act;
 	float slope;
 	int skip;  // timing ablation (JU_FB_SKIP, developer only): 1 weights, 2 staging, 4 K loops, 8 reduction, 16 stores
+	int prio;  // wave priority scheme (kernel_common.h applyWavePriority)
 };
 
 template <int CIN, int CB>
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6;
+	applyWavePriority(p.prio, wave, 8);
 	const int lane = tid & 63;
 	const int px = lane & 31;
 	const int hh = lane >> 5;
@@ -274,6 +276,7 @@ void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStrea
 	p.act = q.relu;
 	p.slope = q.slope;
 	p.skip = ablationSkipBits();
+	p.prio = wavePriorityMode(0);
 	p.tilesX = (q.W + 31) / 32;
 	// Tile height and cout blocks per workgroup: every workgroup pulls its cout blocks'
 	// whole weights (147 KB per block at 256 channels), so the fewest workgroups that still
