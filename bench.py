@@ -88,7 +88,10 @@ PEAK_FP8_TFLOPS = 5000.0  # dense block-scaled e4m3 MFMA (same guide: twice the 
 # 25 frames are 12 ms).  It is NOT part of the contract's W and is therefore reported at the TOP level
 # of the JSON line (`preroll`, `untimed_frames`), not hidden in `config`; `--preroll 0` gives the bare contract.
 PREROLL_FRAMES = 256
-TRAFFIC_PROFILE = "r03_tower_traffic.json"  # PMC summary of the dominant kernel (tools/pmc_traffic.sh)
+# PMC summaries (tools/pmc_all.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes = (2 x FETCH_SIZE +
+# WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md) per (preset, dtype), committed under profiles/;
+# bench.py cannot run rocprofv3 around itself, so `roofline.traffic` quotes the committed figure of the SAME kernel
+PMC_PROFILE = "r04_pmc_per_kernel_{preset}_{dtype}.json"
 
 
 def cpu_baseline(blob: bytes, cfg, frames: np.ndarray, budget_s: float) -> dict:
@@ -275,12 +278,22 @@ def main() -> int:
         # run rocprofv3 around itself); only used when it describes the kernel measured here
         traffic = None
         traffic_source = None
-        tpath = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
-        if launches == 1 and not fp8 and args.preset == "psp-quality" and os.path.exists(tpath):
+        pmc_name = PMC_PROFILE.format(preset=args.preset, dtype=args.dtype)
+        tpath = os.path.join(ROOT, "profiles", pmc_name)
+        if fp8 and launches == 1:
+            pmc_kernel = "tower8_resident_kernel"
+        elif fp8:
+            pmc_kernel = "res_block_fp8_kernel" if launches == cfg.gen_blocks else "conv_tower_fp8_kernel<stream>"
+        else:
+            pmc_kernel = "tower_resident_kernel" if launches == 1 else "res_block_pipe_kernel"
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("bytes_per_launch")
-            traffic_source = (f"committed profile profiles/{TRAFFIC_PROFILE} (rocprofv3 --pmc passes of this "
-                              "kernel, collected separately; NOT measured by this run)")
+                traffic = json.load(f).get(pmc_kernel, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = (f"committed profile profiles/{pmc_name}, kernel {pmc_kernel} (rocprofv3 --pmc passes of "
+                                  "this command line, collected separately; NOT measured by this run)")
+        if fp8_roofline:
+            fp8_roofline["traffic"], fp8_roofline["traffic_source"] = traffic, traffic_source
         result = {
             "metric": "frames/sec 480x270->1920x1080 recurrent SR" if args.preset.startswith("psp")
                       else f"frames/sec {w}x{h}->{4 * w}x{4 * h} recurrent SR",

@@ -19,7 +19,7 @@ import csv, glob, os, collections, json, re
 R=os.environ['GRAFT_REPO_ROOT']
 def short(k):
     k=k.split('(')[0]
-    m=re.search(r'(\d+)(tower8_resident_kernel|tower_resident_kernel|res_block_fp8_kernel|res_block_kernel|flow_block_kernel|conv_splitk_kernel|conv_tower_fp8_kernel|conv_tower_kernel|quantize_tower_kernel|conv_mfma_kernel|tail_fused_kernel|warp_pack_kernel|pack_frames_kernel|upsample2_kernel|maxpool2_kernel)(.*)', k)
+    m=re.search(r'(\d+)(tower8_resident_kernel|tower_resident_kernel|res_block_fp8_kernel|res_block_pipe_kernel|res_block_kernel|flow_block_kernel|conv_splitk_kernel|conv_tower_fp8_kernel|conv_tower_kernel|quantize_tower_kernel|conv_mfma_kernel|tail_fused_kernel|warp_pack_kernel|pack_frames_kernel|upsample2_kernel|maxpool2_kernel)(.*)', k)
     if not m: return None
     name=m.group(2)
     if name=='conv_tower_fp8_kernel':
