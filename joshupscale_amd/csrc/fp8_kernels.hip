@@ -409,33 +409,44 @@ struct Fp8BlockParams {
 	int prio;                   // wave priority scheme (kernel_common.h applyWavePriority)
 };
 
-template <int TH>
+// DUO (round 4): the same block as TWO workgroups of 4 waves per CU instead of one of 8.  The eight waves of one
+// workgroup run the same phases in lockstep -- both waves of a SIMD in their K loops, then both in their epilogues
+// (MFMA ~4.4 us + VALU ~3.4 us + LDS ~4.9 us per tile add up to the measured 11.9 us: nothing overlaps; a static
+// wave priority changes nothing, profiles/r04_wave_priority_ab.txt) -- two independent workgroups are in different
+// phases.  That caps a workgroup at 80 KiB of LDS: conv B's fragments cannot live there, so BOTH convolutions'
+// A fragments are register operands, re-fetched from L2 per tile and convolution (18 KB per wave) behind the
+// previous convolution's last K loop.  Same instruction sequence per output element: same bytes.
+template <int TH, bool DUO = false>
 struct Fp8BlockGeom {
+	static constexpr int NWAVES = DUO ? 4 : 8;
 	static constexpr int XR = TH + 4, TR = TH + 2;
 	static constexpr int XBYTES = (XR * 34 * 64 + 1023) / 1024 * 1024;  // whole 1 KiB DMA writes
 	static constexpr int TBYTES = TR * 34 * 64;
-	static constexpr int WBYTES = 9 * 2 * 64 * 32;  // conv B's fragments (both cout blocks): 36 KiB
+	static constexpr int WBYTES = 9 * 2 * 64 * 32;  // a convolution's fragments (both cout blocks): 36 KiB
+	static constexpr int WLDS = DUO ? 0 : WBYTES;   // conv B's set in LDS (one workgroup per CU only)
 	// per wave: the skip records of a row pair (2 x 32 px x 64 B; the results overwrite them
 	// in place; a row's e4m3 copy is then staged in the same 2 KiB once its stream row has
 	// been read out)
 	static constexpr int STAGE_WAVE = 4096;
 	static constexpr int OFF_T = XBYTES;
 	static constexpr int OFF_W = OFF_T + TBYTES;
-	static constexpr int OFF_STAGE = OFF_W + WBYTES;
-	static constexpr int OFF_BIAS = OFF_STAGE + 8 * STAGE_WAVE;  // 2 x 64 floats
+	static constexpr int OFF_STAGE = OFF_W + WLDS;
+	static constexpr int OFF_BIAS = OFF_STAGE + NWAVES * STAGE_WAVE;  // 2 x 64 floats
 	static constexpr int LDS = OFF_BIAS + 512;
-	static_assert(LDS <= 160 * 1024, "fp8 block tile");
+	static constexpr bool FITS = LDS <= (DUO ? 80 : 160) * 1024;
 };
 
-template <typename T, int TH, bool LEAKY = false>
-__global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p) {
-	using G = Fp8BlockGeom<TH>;
+template <typename T, int TH, bool LEAKY = false, bool DUO = false>
+__global__ __launch_bounds__(DUO ? 256 : 512, 2) void res_block_fp8_kernel(Fp8BlockParams p) {
+	using G = Fp8BlockGeom<TH, DUO>;
+	static_assert(G::FITS, "fp8 block tile");
+	constexpr int NWV = G::NWAVES, PLS = NWV / 2;  // waves; row-pair lanes (pairs pl, pl + PLS, ...)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	unsigned char *smX = smem, *smT = smem + G::OFF_T, *smW = smem + G::OFF_W;
 	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, px = lane & 31, hh = lane >> 5;
-	const int cb = wave & 1, pl = wave >> 1;  // cout block; pairs pl, pl + 4, ...
+	const int cb = wave & 1, pl = wave >> 1;  // cout block; pairs pl, pl + PLS, ...
 	unsigned char *stage = smem + G::OFF_STAGE + wave * G::STAGE_WAVE;
-	applyWavePriority(p.prio, wave, 8);
+	if constexpr (!DUO) applyWavePriority(p.prio, wave, 8);
 
 	// conv A's fragments of this wave's cout block: registers, for the whole launch (buffer
 	// loads: ONE lane offset register, the tap offset scalar -- flat loads keep 18 64-bit
@@ -443,18 +454,22 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 	// in registers do not fit two waves per SIMD).
 	typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 	i32x8 wa[9];
-	{
+	const unsigned wLane = static_cast<unsigned>((cb * 64 + lane) * 32);
+	// (DUO: both convolutions' fragments take turns in these registers)
+	auto loadW = [&](const unsigned char *base) __attribute__((always_inline)) {
 		const __amdgpu_buffer_rsrc_t rsrc =
-		    __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(p.w1), 0, G::WBYTES, 0x00020000);
-		const unsigned wLane = static_cast<unsigned>((cb * 64 + lane) * 32);
+		    __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(base), 0, G::WBYTES, 0x00020000);
 #pragma unroll
 		for (int t = 0; t < 9; ++t) {
 			const u32x4w lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wLane, t * 4096, 0);
 			const u32x4w hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wLane, t * 4096 + 16, 0);
 			wa[t] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 		}
+	};
+	loadW(p.w1);
+	if constexpr (!DUO) {
+		for (int i = wave; i < G::WBYTES / 1024; i += 8) dmaToLds16(p.w2, 0u, static_cast<unsigned>(i * 1024 + lane * 16), smW + i * 1024);
 	}
-	for (int i = wave; i < G::WBYTES / 1024; i += 8) dmaToLds16(p.w2, 0u, static_cast<unsigned>(i * 1024 + lane * 16), smW + i * 1024);
 	const int scA1 = p.scaleA1[cb * 32 + px], scA2 = p.scaleA2[cb * 32 + px];
 	float *smBias = reinterpret_cast<float *>(smem + G::OFF_BIAS);
 	if (tid < 64) smBias[tid] = p.b1[tid];
@@ -471,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 		constexpr int NREC = G::XR * 34;
 		constexpr int NINSTR = (NREC + 15) / 16;
 		const bool border = y0 - 2 < 0 || y0 + TH + 2 > p.H || x0 - 2 < 0 || x0 + 32 > p.W;
-		for (int i = wave; i < NINSTR; i += 8) {
+		for (int i = wave; i < NINSTR; i += NWV) {
 			const int q = i * 16 + (lane >> 2);
 			const int r = q / 34, k = q - r * 34;
 			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
@@ -499,6 +514,37 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 		}
 	};
 
+	// DUO: a row pair's 18 matrix instructions with the fragment reads pinned one tap ahead (left to itself
+	// hipcc sinks every read next to its first use and waits lgkmcnt(0) in front of each instruction pair: nine
+	// exposed LDS round trips per pair).  Tap order 1, 0, 2 and dy inside: the other forms' order, same bytes.
+	auto kLoop = [&](const unsigned char *tileBase, const int pair, f32x16(&acc)[2], const int scA, const int scB)
+	                 __attribute__((always_inline)) {
+		i32x8 fa[4], fb[4];
+		loadFrags(tileBase, pair, 1, fa);
+		loadFrags(tileBase, pair, 0, fb);
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+			for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 1], fa[r + dy], acc[r], 0, 0, 0, scA, 0, scB);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		loadFrags(tileBase, pair, 2, fa);
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+			for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 0], fb[r + dy], acc[r], 0, 0, 0, scA, 0, scB);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+			for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa[dy * 3 + 2], fa[r + dy], acc[r], 0, 0, 0, scA, 0, scB);
+		}
+		__builtin_amdgcn_sched_barrier(0);
+	};
+
 	int tile = blockIdx.x;
 	if (tile < p.numTiles && !(JU_SKIP(p) & 1)) stageX(tile);
 	for (; tile < p.numTiles; tile += gridDim.x) {
@@ -507,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's X8 (first tile: and conv B's weights) landed
 		__syncthreads();                                  // ... for every wave; all are done with T8
 		// ---- conv A: (TH + 2) rows x 32 columns -> ReLU -> e4m3 -> T8, zero outside the image ----
-		for (int pair = pl; pair < G::TR / 2; pair += 4) {
+		for (int pair = pl; pair < G::TR / 2; pair += PLS) {
 			f32x16 acc[2];
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
@@ -520,6 +566,10 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 			// the next tap's fragments travel behind the current tap's 6 instructions
 			i32x8 f0[4], f1[4];
 			if (JU_SKIP(p) & 2) goto epiA;
+			if constexpr (DUO) {
+				kLoop(smX, pair, acc, scA1, p.scaleB1);
+				goto epiA;
+			}
 			loadFrags(smX, pair, 0, f0);
 			loadFrags(smX, pair, 1, f1);
 			// (tap order 1, 0, 2: see tower8_kernels.hip)
@@ -560,12 +610,15 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				}
 			}
 		}
+		if constexpr (DUO) loadW(p.w2);  // conv A's fragments are dead: conv B's travel across the barrier
 		__syncthreads();  // T8 complete, X8 dead
 		if (tile + static_cast<int>(gridDim.x) < p.numTiles && !(JU_SKIP(p) & 1)) stageX(tile + gridDim.x);
 		// ---- conv B: TH rows x 32 columns (30 valid) + skip -> ReLU -> stream, e4m3 copy ----
-		for (int pair = pl; pair < TH / 2; pair += 4) {
+		for (int pair = pl; pair < TH / 2; pair += PLS) {
 			// the pair's skip records (this wave's half: channels 32 cb ..) by LDS-DMA into the
-			// staging slice, pixel pi = r * 32 + px at pi * 64, chunk c at c ^ (pi & 3); they land
+			// staging slice, pixel pi = r * 32 + px at pi * 64, chunk c at c ^ ((pi >> 2) & 3) -- keyed on pi >> 2: the epilogue's
+			// 8-byte accesses of 32 pixels (64-byte stride: pi and pi + 4 share a bank group) then conflict 2 ways, not 8
+			// (PMC, round 4: 45 % of this kernel's LDS cycles were bank conflicts with the key pi & 3); they land
 			// during the K loop, and the results go back into the same places
 			if (!(JU_SKIP(p) & 8)) {
 				const unsigned char *src = static_cast<const unsigned char *>(p.stream);
@@ -573,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				for (int i = 0; i < 4; ++i) {
 					const int pi = i * 16 + (lane >> 2);
 					const int gy = min(y0 + 2 * pair + (pi >> 5), p.H - 1), gx = min(x0 + (pi & 31), p.W - 1);
-					const unsigned c = static_cast<unsigned>(lane & 3) ^ (static_cast<unsigned>(pi) & 3u);
+					const unsigned c = static_cast<unsigned>(lane & 3) ^ ((static_cast<unsigned>(pi) >> 2) & 3u);
 					dmaToLds16(src, 0u, static_cast<unsigned>((((gy + 1) * p.pitch + gx + 1) * 64 + cb * 32) * 2 + c * 16),
 					    stage + i * 1024);
 				}
@@ -588,19 +641,27 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 				}
 			}
 			i32x8 f0[4], f1[4];
-			if (!(JU_SKIP(p) & 4)) {
+			if constexpr (DUO) {
+				if (!(JU_SKIP(p) & 4)) kLoop(smT, pair, acc, scA2, p.scaleB2);
+			}
+			if (!DUO && !(JU_SKIP(p) & 4)) {
 			loadFrags(smT, pair, 0, f0);
 			loadFrags(smT, pair, 1, f1);
 			}
 #pragma unroll
-			for (int t = 0; t < ((JU_SKIP(p) & 4) ? 0 : 3); ++t) {
+			for (int t = 0; t < ((DUO || (JU_SKIP(p) & 4)) ? 0 : 3); ++t) {
 				const int dx = t == 0 ? 1 : (t == 1 ? 0 : 2);
 				if (t == 1) loadFrags(smT, pair, 2, f1);
 #pragma unroll
 				for (int dy = 0; dy < 3; ++dy) {
-					const i32x4 lo = *reinterpret_cast<const i32x4 *>(wbLane + (dy * 3 + dx) * 4096);
-					const i32x4 hi = *reinterpret_cast<const i32x4 *>(wbLane + (dy * 3 + dx) * 4096 + 16);
-					const i32x8 w = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+					i32x8 w;
+					if constexpr (DUO) {
+						w = wa[dy * 3 + dx];
+					} else {
+						const i32x4 lo = *reinterpret_cast<const i32x4 *>(wbLane + (dy * 3 + dx) * 4096);
+						const i32x4 hi = *reinterpret_cast<const i32x4 *>(wbLane + (dy * 3 + dx) * 4096 + 16);
+						w = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+					}
 #pragma unroll
 					for (int r = 0; r < 2; ++r) {
 						acc[r] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, (t == 1 ? f0 : f1)[r + dy], acc[r], 0, 0, 0, scA2, 0, p.scaleB2);
@@ -615,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 			for (int r = 0; r < 2; ++r) {
 				const int pi = r * 32 + px;
 				unsigned char *rec = stage + pi * 64 + hh * 8;
-				const unsigned sw = static_cast<unsigned>(pi) & 3u;
+				const unsigned sw = (static_cast<unsigned>(pi) >> 2) & 3u;
 				Vec4<T> rv[4];
 #pragma unroll
 				for (int g = 0; g < 4; ++g) rv[g] = *reinterpret_cast<const Vec4<T> *>(rec + ((static_cast<unsigned>(g) ^ sw) << 4));
@@ -639,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 			for (int i = 0; i < 4; ++i) {
 				const int pi = i * 16 + (lane >> 2);
 				const unsigned slot = static_cast<unsigned>(lane & 3);
-				const unsigned chunk = slot ^ (static_cast<unsigned>(pi) & 3u);
+				const unsigned chunk = slot ^ ((static_cast<unsigned>(pi) >> 2) & 3u);
 				const i32x4 val = *reinterpret_cast<const i32x4 *>(stage + pi * 64 + (slot << 4));
 				const int gy = y0 + 2 * pair + (pi >> 5), gx = x0 + (pi & 31);
 				if ((pi & 31) < 30 && gy < p.H && gx < p.W && !(JU_SKIP(p) & 16)) {
@@ -678,19 +739,25 @@ __global__ __launch_bounds__(512, 2) void res_block_fp8_kernel(Fp8BlockParams p)
 			// wave complete in order, but the DMA is a memory operation -- wait for them
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		}
+		if constexpr (DUO) {
+			if (tile + static_cast<int>(gridDim.x) < p.numTiles) loadW(p.w1);  // the next tile's conv A
+		}
 	}
 }
 
-template <typename T, int TH, bool LEAKY>
+constexpr bool kFp8BlockDuoDefault = true;  // measured, 640x448: 35.7-36.4 us per block against 38.0-38.5 (profiles/r04_fp8_duo.txt)
+
+template <typename T, int TH, bool LEAKY, bool DUO = false>
 void launchFp8BlockT(Fp8BlockParams k, int cus, hipStream_t stream) {
-	using G = Fp8BlockGeom<TH>;
-	auto kern = res_block_fp8_kernel<T, TH, LEAKY>;
+	using G = Fp8BlockGeom<TH, DUO>;
+	auto kern = res_block_fp8_kernel<T, TH, LEAKY, DUO>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "fp8 block");
 	k.tilesX = (k.W + 29) / 30;
 	k.numTiles = k.tilesX * ((k.H + TH - 1) / TH);
-	const int grid = k.numTiles < cus ? k.numTiles : cus;
-	hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G::LDS, stream, k);
+	const int slots = DUO ? 2 * cus : cus;  // DUO: two workgroups per CU
+	const int grid = k.numTiles < slots ? k.numTiles : slots;
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(DUO ? 256 : 512), G::LDS, stream, k);
 	hipCheckLaunch("res_block_fp8");
 }
 
@@ -811,6 +878,40 @@ void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 	// height with the shortest makespan (480x270: 18 rows, 240 tiles, one each; 640x448: 14
 	// rows, 704 tiles, three rounds -- 18 rows would be three rounds of taller tiles).
 	const long tilesX = (q.W + 29) / 30;
+	// Two workgroups of 4 waves per CU (DUO, above) where the frame has more tiles than one round of the
+	// one-workgroup form can take (640x448: 990 tiles of 10 rows on 512 slots); JU_FP8_BLOCK=solo / duo forces a form.
+	static const int form = [] {
+		const char *e = std::getenv("JU_FP8_BLOCK");
+		return e == nullptr ? 0 : (std::string(e) == "duo" ? 2 : (std::string(e) == "solo" ? 1 : 0));
+	}();
+	const bool duo = form == 2 || (form == 0 && kFp8BlockDuoDefault && tilesX * ((q.H + 17) / 18) > cus);
+	if (duo) {
+		int bestD = 6;
+		long bestCostD = -1;
+		for (int th : {10, 8, 6}) {
+			const long tiles = tilesX * ((q.H + th - 1) / th);
+			const long cost = ((tiles + 2 * cus - 1) / (2 * cus)) * (th + 5);
+			if (bestCostD < 0 || cost < bestCostD) {
+				bestCostD = cost;
+				bestD = th;
+			}
+		}
+#define JU_F8D(TH_)                                                             \
+	if (bestD == TH_) {                                                         \
+		if (q.leaky) {                                                          \
+			if (dt == kF16) launchFp8BlockT<f16, TH_, true, true>(k, cus, stream);  \
+			else launchFp8BlockT<bf16, TH_, true, true>(k, cus, stream);        \
+		} else {                                                                \
+			if (dt == kF16) launchFp8BlockT<f16, TH_, false, true>(k, cus, stream); \
+			else launchFp8BlockT<bf16, TH_, false, true>(k, cus, stream);       \
+		}                                                                       \
+		return;                                                                 \
+	}
+		JU_F8D(10)
+		JU_F8D(8)
+		JU_F8D(6)
+#undef JU_F8D
+	}
 	int best = 6;
 	long bestCost = -1;
 	for (int th : {18, 14, 10, 6}) {
