@@ -269,6 +269,7 @@ int ju_debug_set(const char *key, int value) {
 		else if (k == "resident_fault") ju::setResidentFault(value);
 		else if (k == "tower_fast") ju::setResidentTowerFast(value);
 		else if (k == "res_block_plain") ju::setResBlockPlain(value);
+		else if (k == "fp8_block_form") ju::setFp8BlockForm(value);
 		else throw std::invalid_argument("unknown debug key " + k);
 	});
 }

@@ -61,7 +61,9 @@ const Rccl &rccl() {
 		r.allReduce = reinterpret_cast<decltype(r.allReduce)>(sym("ncclAllReduce"));
 		r.commCount = reinterpret_cast<decltype(r.commCount)>(sym("ncclCommCount"));
 		r.commDestroy = reinterpret_cast<decltype(r.commDestroy)>(sym("ncclCommDestroy"));
-		r.commAbort = reinterpret_cast<decltype(r.commAbort)>(sym("ncclCommAbort"));
+		// optional: an RCCL without it tears a failed communicator down with ncclCommDestroy
+		r.commAbort = reinterpret_cast<decltype(r.commAbort)>(dlsym(r.lib, "ncclCommAbort"));
+		if (r.commAbort == nullptr) r.commAbort = r.commDestroy;
 		r.errorString = reinterpret_cast<decltype(r.errorString)>(sym("ncclGetErrorString"));
 	});
 	if (!failure.empty()) throw std::runtime_error(failure);
@@ -144,10 +146,13 @@ int ju_comm_broadcast(ju_comm *comm, void *bytes, size_t size, int root) {
 		if (comm->comm == nullptr) throw std::runtime_error("ju_comm_broadcast: the communicator was aborted by an earlier failure");
 		if (root < 0 || root >= comm->world) throw std::invalid_argument("ju_comm_broadcast: bad root");
 		ju::DeviceGuard guard(comm->device);
-		// Everything that can fail on THIS rank alone happens before the payload collective:
-		// a rank that threw in front of it would leave its peers blocked inside
-		// ncclBroadcast for ever.  If it does fail here the communicator is aborted, so the
-		// peers' pending collective errors out instead of hanging.
+		// Everything that can fail on THIS rank alone happens before the payload collective, so that
+		// a local failure is at least never left half-way into it.  On such a failure this rank's
+		// communicator is aborted (ncclCommAbort tears down THIS rank only): later calls on it fail
+		// at once instead of entering a collective its peers have given up on.  The peers are NOT
+		// guaranteed to see an error -- a rank blocked in the collective stays blocked until its own
+		// watchdog or the launcher's timeout ends it (torch.distributed.run kills the job when one
+		// rank exits non-zero, which is what bench.py relies on).
 		ju::DeviceBuffer dev, agree;
 		try {
 			dev = ju::DeviceBuffer(size ? size : 1);

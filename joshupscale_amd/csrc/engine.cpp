@@ -1436,23 +1436,29 @@ void Engine::submit(const Frame &in, const Frame &out) {
 	// Device-resident frames: the kernels read the caller's input and write the caller's
 	// output directly (any signed stride), no staging copies.
 	m_DirectIO = directEligible(in, out);
-	std::unique_lock<std::mutex> chain = chainBegin();
+	// The per-device chain lock covers the wait on the previous resident frame, the program's launches
+	// (and an inline graph capture) and the completion record -- NOT the staging copies: a pageable
+	// host-to-device copy blocks its caller, and would block every other runtime of the device with it
+	// (advisor, round 3).  They are ordered by the stream; a copy kernel beside another runtime's
+	// resident tower merely waits for a free CU or delays a workgroup's start by microseconds.
 	if (m_DirectIO) {
 		m_IO.in = static_cast<const std::uint8_t *>(in.ptr);
 		m_IO.inStride = in.stride;
 		m_IO.out = static_cast<std::uint8_t *>(out.ptr);
 		m_IO.outStride = out.stride;
-		runProgram();
 	} else {
 		m_IO.in = m_InStage.as<std::uint8_t>();
 		m_IO.inStride = static_cast<std::ptrdiff_t>(fs.inputWidth) * 4;
 		m_IO.out = m_OutStage.as<std::uint8_t>();
 		m_IO.outStride = static_cast<std::ptrdiff_t>(fs.outputWidth) * 4;
 		stageIn(in);
-		runProgram();
-		stageOut(out);
 	}
-	chainEnd(chain);
+	{
+		std::unique_lock<std::mutex> chain = chainBegin();
+		runProgram();
+		chainEnd(chain);
+	}
+	if (!m_DirectIO) stageOut(out);
 	m_Idx ^= 1;  // state ping-pong (tensorrt_backend.cc:277)
 }
 

@@ -851,6 +851,13 @@ void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
 	}
 }
 
+// 0: by geometry; 1: one 8-wave workgroup per CU; 2: two 4-wave workgroups per CU (JU_FP8_BLOCK=solo / duo, tests)
+static std::atomic<int> g_Fp8BlockForm{[] {
+	const char *e = std::getenv("JU_FP8_BLOCK");
+	return e == nullptr ? 0 : (std::string(e) == "duo" ? 2 : (std::string(e) == "solo" ? 1 : 0));
+}()};
+void setFp8BlockForm(int form) { g_Fp8BlockForm = form; }
+
 void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 	Fp8BlockParams k{};
 	k.in8 = static_cast<const unsigned char *>(q.in8);
@@ -880,10 +887,7 @@ void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 	const long tilesX = (q.W + 29) / 30;
 	// Two workgroups of 4 waves per CU (DUO, above) where the frame has more tiles than one round of the
 	// one-workgroup form can take (640x448: 990 tiles of 10 rows on 512 slots); JU_FP8_BLOCK=solo / duo forces a form.
-	static const int form = [] {
-		const char *e = std::getenv("JU_FP8_BLOCK");
-		return e == nullptr ? 0 : (std::string(e) == "duo" ? 2 : (std::string(e) == "solo" ? 1 : 0));
-	}();
+	const int form = g_Fp8BlockForm.load();
 	const bool duo = form == 2 || (form == 0 && kFp8BlockDuoDefault && tilesX * ((q.H + 17) / 18) > cus);
 	if (duo) {
 		int bestD = 6;

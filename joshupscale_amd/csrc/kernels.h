@@ -241,6 +241,7 @@ bool residentTowerFastGeometry(int H, int W, int GX, int GY, int RH);
 void setResBlockPlain(int on);       // tests / JU_RES_BLOCK=plain: res_block_kernel instead of res_block_pipe_kernel
 bool resBlockPlain();
 void setResidentTowerFast(int on);  // tests / JU_TOWER_FAST=0: the general schedule everywhere
+void setFp8BlockForm(int form);     // tests / JU_FP8_BLOCK: res_block_fp8_kernel as 0 = by geometry, 1 = solo, 2 = duo
 bool residentTowerFast();
 inline std::size_t residentCounterBytes(int GX, int GY) {
 	return (static_cast<std::size_t>(GX) * GY * 2 * sizeof(unsigned) + 63) / 64 * 64;

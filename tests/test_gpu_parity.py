@@ -1064,6 +1064,34 @@ def test_fp8_resident_block_and_per_conv_kernels_give_the_same_bytes(monkeypatch
                 assert np.array_equal(x, y), mode
 
 
+def test_fp8_block_kernel_solo_and_duo_forms_give_the_same_bytes(monkeypatch):
+    """res_block_fp8_kernel runs as ONE workgroup of 8 waves per CU (conv B's fragments in LDS) or as TWO of
+    4 waves (round 4: both convolutions' fragments in registers, shorter tiles; the default at 640x448, where
+    it is 7 % faster).  Same instruction sequence per output element: equal frames and trunk, ReLU and
+    LeakyReLU, at a ragged small size (partial tiles both ways), at 480x270 and at the PS2 size."""
+    lib = R.load_library()
+    monkeypatch.setenv("JU_TOWER", "layers")
+    leaky = dict(gen_activation="lrelu", gen_negative_slope=0.2)
+    try:
+        for cfg, n in [(small_config(frame_height=34, frame_width=70, gen_blocks=3), 3),
+                       (small_config(frame_height=45, frame_width=61, gen_blocks=2, **leaky), 2),
+                       (M.PRESETS["psp-fast"], 2), (M.PRESETS["ps2-quality"], 2)]:
+            blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+            frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=77, kind="noise")
+            runs = {}
+            for form in (1, 2):
+                lib.ju_debug_set(b"fp8_block_form", form)
+                rt = R.Runtime(blob, 0, R.DTYPE_FP8)
+                assert rt.time_steps("tower", 0)[1] == 1 + cfg.gen_blocks
+                runs[form] = ([rt.process_image(f).copy() for f in frames], rt.read_tensor("trunk").copy())
+                rt.close()
+            assert np.array_equal(runs[1][1], runs[2][1])
+            for x, y in zip(runs[1][0], runs[2][0]):
+                assert np.array_equal(x, y)
+    finally:
+        lib.ju_debug_set(b"fp8_block_form", 0)
+
+
 FULL_FP8 = {"psp-quality": ("full_psp_quality_fp8", "full_psp_quality"),
             "ps2-quality": ("full_ps2_quality_fp8", "full_ps2_quality")}
 

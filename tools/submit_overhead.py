@@ -41,5 +41,3 @@ sub.sort()
 print(f"{preset}: synchronous ju_process {sync_us:.1f} us/frame ({1e6 / sync_us:.0f} fps); stream kept full (ju_enqueue) "
       f"{async_us:.1f} us/frame ({1e6 / async_us:.0f} fps); CPU cost of one submission p50 {sub[N // 2] * 1e6:.1f} us, "
       f"p90 {sub[int(N * .9)] * 1e6:.1f} us; gap per synchronous frame {sync_us - async_us:.1f} us")
-for spin in (0, 50, 2000):
-    pass
