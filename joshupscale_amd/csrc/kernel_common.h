@@ -212,14 +212,17 @@ __device__ __forceinline__ void warpQuarter(const f16 *__restrict__ state, const
 		const int y0 = static_cast<int>(fy), x0 = static_cast<int>(fx);
 		const f16 *s0 = state + ((size_t)y0 * WW + x0) * 4;
 		const f16 *s1 = s0 + (size_t)WW * 4;
-		const Vec4<f16> tl = *reinterpret_cast<const Vec4<f16> *>(s0);
-		const Vec4<f16> tr = *reinterpret_cast<const Vec4<f16> *>(s0 + 4);
-		const Vec4<f16> bl = *reinterpret_cast<const Vec4<f16> *>(s1);
-		const Vec4<f16> br = *reinterpret_cast<const Vec4<f16> *>(s1 + 4);
+		// The two corners of a row are neighbours in memory (x0 <= WW - 2): ONE 16-byte load per row instead
+		// of two 8-byte ones (8-byte aligned: legal for global loads).  The gathers are bound by the vector
+		// L1's tag rate, one lookup per instruction and line: half the instructions, and a lookup more only
+		// where the 16 bytes straddle a line.
+		typedef f16 PairH __attribute__((ext_vector_type(8), aligned(8)));
+		const PairH top2 = *reinterpret_cast<const PairH *>(s0);
+		const PairH bot2 = *reinterpret_cast<const PairH *>(s1);
 #pragma unroll
 		for (int c = 0; c < 3; ++c) {
-			const float a = static_cast<float>(tl[c]), b = static_cast<float>(tr[c]);
-			const float d = static_cast<float>(bl[c]), e = static_cast<float>(br[c]);
+			const float a = static_cast<float>(top2[c]), b = static_cast<float>(top2[4 + c]);
+			const float d = static_cast<float>(bot2[c]), e = static_cast<float>(bot2[4 + c]);
 			const float top = ax * (b - a) + a;
 			const float bot = ax * (e - d) + d;
 			const float v = ay * (bot - top) + top + bright;
