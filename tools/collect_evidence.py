@@ -24,14 +24,19 @@ for t in ["final", "lrelu", "fp8_psp", "fp8_ps2", "ps2", "fast"]:
     k = newest(os.path.join(go, f"prof_{tag}_{t}", "*", "*_kernel_stats.csv"))
     if k:
         shutil.copy(k, os.path.join(pr, f"{tag}_{t}_kernel_stats.csv"))
+extra = [os.path.basename(f)[len(tag) + 1:] for f in glob.glob(os.path.join(go, f"{tag}_pmc_per_kernel_*.json"))
+         + glob.glob(os.path.join(go, f"{tag}_pmc_table_*.txt")) + glob.glob(os.path.join(go, f"{tag}_pmc_stall_*.txt"))]
 for f in ["pmc_per_kernel.json", "pmc_per_kernel_fp8.json", "pmc_table.txt", "pmc_table_fp8.txt", "variants.txt",
-          "flow_layers.txt", "quality_psp.json", "quality_ps2.json", "soak.txt"]:
+          "flow_layers.txt", "quality_psp.json", "quality_ps2.json", "soak.txt", "tower_phases.txt",
+          "driver_cmd_bench.json"] + extra:
     src = os.path.join(go, f"{tag}_{f}")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(pr, f"{tag}_{f}"))
 if os.path.exists(os.path.join(go, "parity_stats.json")):
     shutil.copy(os.path.join(go, "parity_stats.json"), os.path.join(pr, f"{tag}_parity_stats.json"))
 pk = os.path.join(pr, f"{tag}_pmc_per_kernel.json")
+if not os.path.exists(pk):  # (round 4 on: one PMC file per preset and dtype)
+    pk = os.path.join(pr, f"{tag}_pmc_per_kernel_psp-quality_bf16.json")
 if os.path.exists(pk):
     t = json.load(open(pk))["tower_resident_kernel"]
     out = {
@@ -41,7 +46,7 @@ if os.path.exists(pk):
         "FETCH_SIZE_kb": t["FETCH_SIZE"], "WRITE_SIZE_kb": t["WRITE_SIZE"],
         "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half the bytes of wide "
                       "coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte stores",
-        "bytes_per_launch": t["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": 36790272,
+        "bytes_per_launch": t["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": 45600000,
         "mfma_busy_frac": t["mfma_busy_frac"],
         "note": "the excess over the algorithmic bytes is the halo exchange by design: 255 regions x ~12.5 KB x 48 layers "
                 "= ~150 MB of write-through (sc1) mailbox stores plus the same amount of L2-bypassing reads, and ~28 MB "
