@@ -539,10 +539,14 @@ void Engine::buildProgram(int set) {
 	// ---- warp + space-to-depth + concat ----
 	{
 		const void *flow = T("flow");
-		void *genIn = T("gen_in");
+		// the generator input lives in the tower layout (zero border = conv_1's padding), so that conv_1 can run
+		// on the tower's per-layer kernel wherever it is a launch of its own (8-bit towers, per-block towers)
+		const Operand genInOp = Op("gen_in");
+		void *genIn = genInOp.ptr;
+		const int genPitch = genInOp.pitch;
 		void *preWarp = c.temporalStrength > 0.0f ? T("pre_warp") : nullptr;
 		prog.push_back({"warp", 0.0, [=](hipStream_t s) {
-			                launchWarpPack(dt, stateIn, flow, io->in, io->inStride, genIn, H, W, PW,
+			                launchWarpPack(dt, stateIn, flow, io->in, io->inStride, genIn, genPitch, H, W, PW,
 			                    padTop, padLeft, sums, preWarp, s);
 		                }});
 	}
@@ -564,8 +568,9 @@ void Engine::buildProgram(int set) {
 		prog.push_back({"calib", 0.0, [=](hipStream_t s) { JU_HIP(hipMemsetAsync(profile, 0, bytes, s)); }});
 	}
 	if (!m_Resident || m_Fp8Tower) {  // (the 16-bit resident tower runs conv_1 as its layer 0)
+		// (64-filter generators: conv_tower_kernel -- 38 instead of 51 us at 640x448; other widths: the generic kernel)
 		addConvStep(&prog, "gen_head", "generator/conv_1", Op("gen_in"), none, Op("trunk_a"), H, W,
-		    true, false);
+		    true, false, c.genFilters == 64 && !m_Calibrate);
 		addCalib(0, "trunk_a");
 	}
 	const char *xs[2] = {"trunk_a", "trunk_b"};
@@ -598,8 +603,8 @@ void Engine::buildProgram(int set) {
 	} else if (m_Resident) {
 		// one launch for the whole tower
 		ResidentTowerParams rp{};
-		rp.in = Op("gen_in").ptr;  // dense [H][W][64]; conv_1 is layer 0 of the launch
-		rp.inPitch = W;
+		rp.in = Op("gen_in").ptr;  // tower layout [..][pitch][64] at image pixel (0, 0); conv_1 is layer 0 of the launch
+		rp.inPitch = Op("gen_in").pitch;
 		rp.hasHead = 1;
 		rp.out = Op("trunk_b").ptr;
 		rp.weights = m_TowerW.get();
@@ -918,7 +923,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		addTensor("flow/t", plr * c.flowResFilters);
 	}
 	addTensor("flow", plr * 32, false, true);  // the flow head: f16 whatever the compute type
-	addTensor("gen_in", lr * 64);
+	addTowerTensor("gen_in", H, W, 64);
 	if (c.temporalStrength > 0.0f) {
 		addTensor("pre_warp", lr * 16 * 4);  // f16 [4H][4W][4]
 		m_TemporalAcc = DeviceBuffer(8 * temporalAccWords(H, W, c.temporalWindow));

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void upsample2_kernel(
 template <typename T>
 __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ state,
     const f16 *__restrict__ flow, const std::uint8_t *__restrict__ frame,
-    std::ptrdiff_t frameStride, T *__restrict__ out, int H, int W, int PW, int padTop,
+    std::ptrdiff_t frameStride, T *__restrict__ out, int outPitch, int H, int W, int PW, int padTop,
     int padLeft, const unsigned *__restrict__ sums, f16 *__restrict__ preWarpOut) {
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= H * W * 4) return;
@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256) void warp_pack_kernel(const f16 *__restrict__ 
 #pragma unroll
 		for (int j = 0; j < 4; ++j) *reinterpret_cast<Vec4<f16> *>(d + 4 * j) = pw[j];
 	}
-	T *dst = out + (size_t)pix * 64 + i * 16;
+	// (out is addressed at image pixel (0, 0) with a row pitch: the generator input lives in the tower layout,
+	// whose zero border is the first convolution's padding and is never written)
+	T *dst = out + ((size_t)h * outPitch + w) * 64 + i * 16;
 	*reinterpret_cast<Vec8<T> *>(dst) = o0;
 	*reinterpret_cast<Vec8<T> *>(dst + 8) = o1;
 }
@@ -646,16 +648,17 @@ void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, h
 }
 
 void launchWarpPack(DType dt, const void *state, const void *flow, const std::uint8_t *frame,
-    std::ptrdiff_t frameStride, void *out, int H, int W, int PW, int padTop, int padLeft,
+    std::ptrdiff_t frameStride, void *out, int outPitch, int H, int W, int PW, int padTop, int padLeft,
     const unsigned *sums, void *preWarpOut, hipStream_t stream) {
+	if (outPitch <= 0) outPitch = W;
 	const unsigned nb = blocksFor((size_t)H * W * 4);
 	if (dt == kF16) {
 		hipLaunchKernelGGL(warp_pack_kernel<f16>, dim3(nb), dim3(256), 0, stream,
-		    static_cast<const f16 *>(state), static_cast<const f16 *>(flow), frame, frameStride, static_cast<f16 *>(out), H,
+		    static_cast<const f16 *>(state), static_cast<const f16 *>(flow), frame, frameStride, static_cast<f16 *>(out), outPitch, H,
 		    W, PW, padTop, padLeft, sums, static_cast<f16 *>(preWarpOut));
 	} else {
 		hipLaunchKernelGGL(warp_pack_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
-		    static_cast<const f16 *>(state), static_cast<const f16 *>(flow), frame, frameStride, static_cast<bf16 *>(out), H,
+		    static_cast<const f16 *>(state), static_cast<const f16 *>(flow), frame, frameStride, static_cast<bf16 *>(out), outPitch, H,
 		    W, PW, padTop, padLeft, sums, static_cast<f16 *>(preWarpOut));
 	}
 	hipCheckLaunch("warp_pack");

@@ -314,8 +314,8 @@ void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C,
 // preWarpOut (may be null): the warped previous output itself, f16 [4H][4W][4], for
 // the temporal filter below.
 void launchWarpPack(DType dt, const void *state, const void *flow,
-    const std::uint8_t *frame, std::ptrdiff_t frameStride, void *out, int H, int W, int PW,
-    int padTop, int padLeft, const unsigned *sums, void *preWarpOut, hipStream_t stream);
+    const std::uint8_t *frame, std::ptrdiff_t frameStride, void *out, int outPitch, int H, int W, int PW,
+    int padTop, int padLeft, const unsigned *sums, void *preWarpOut, hipStream_t stream);  // out at image pixel (0, 0), outPitch in pixels (0: W)
 
 // Temporal moving-average output filter with the scene-cut gate of
 // scripts/inference/onnx/frame_moving_avg.py:146-302, every mode of that script: global or
