@@ -53,6 +53,12 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
     assert res["config"]["timed_region"] == {"replays": 20, "eager": 0, "captures": 0}
     assert res["config"]["submission"]["prepared_captures"] == 32 and res["config"]["submission"]["inline_captures"] == 0
     assert len(res["config"]["per_rank_fps"]["values"]) == 1
+    # what runs before the timed region is disclosed at the TOP level (advisor, round 3): the contract's W and the
+    # fixed clock-warm pre-roll, and the roofline names both timings of the dominant kernel and its PMC traffic
+    assert res["warmup"] == 5 and res["preroll"] == 256 and res["untimed_frames"] == 261
+    rf = res["roofline"]
+    assert 0.0 < rf["frac"] <= 1.0 and 0.0 < rf["frac_back_to_back"] <= 1.0 and rf["launches_per_frame"] == 1
+    assert rf["traffic"] is None or (rf["traffic"] > 1e6 and "profiles/" in rf["traffic_source"])
     assert "how" in res["config"]["affinity"] and res["config"]["model_broadcast"]["seconds"] > 0
     # N = 1 under the launcher measures what a bare N = 1 run measures (the driver computes
     # scaling efficiency from the per-N values: the launcher itself must not cost frames)
