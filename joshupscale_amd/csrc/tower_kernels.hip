@@ -475,7 +475,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// (variants 1 .. 3 are bit masks; 4, 5, 8 are NOT -- round 2 tested `VARIANT & 1` and ran the
 	// calibration build, variant 5, without the halo exchange: its maxima drifted by up to 10 %)
 	constexpr bool kNoMfma = VARIANT == 2 || VARIANT == 3;
+#ifdef JU_NOXCHG_DEV  // developer timing build only (tools/dev_tower_lib.sh x -DJU_NOXCHG_DEV): no halo exchange at all, wrong frames
+	constexpr bool xchg = false;
+#else
 	constexpr bool xchg = !(VARIANT == 1 || VARIANT == 3);
+#endif
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6;
 	const int lane = tid & 63;
