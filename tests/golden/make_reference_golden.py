@@ -109,7 +109,7 @@ def build_reference_model(ref_models, cfg: M.ModelConfig, weights):
     return inference
 
 
-def run_case(ref_models, name: str, only_print: bool = False) -> str:
+def run_case(ref_models, name: str, out_dir: str = HERE) -> str:
     import tensorflow as tf
 
     kw, n_frames, kind = CASES[name]
@@ -140,7 +140,7 @@ def run_case(ref_models, name: str, only_print: bool = False) -> str:
         y0, x0 = (4 * h - CROP) // 2, (4 * w - CROP) // 3
         raw = raw[:, y0:y0 + CROP, x0:x0 + CROP]
         warp = warp[:, y0:y0 + CROP, x0:x0 + CROP]
-    path = os.path.join(HERE, f"ref_{name}.npz")
+    path = os.path.join(out_dir, f"ref_{name}.npz")
     np.savez_compressed(
         path,
         config=json.dumps(kw, sort_keys=True), clip=json.dumps({"kind": kind, "seed": 1234, "frames": n_frames}),
