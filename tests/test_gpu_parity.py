@@ -842,6 +842,20 @@ def test_fp8_tower_matches_its_oracle(h, w, blocks):
     _fp8_case(cfg, M.make_seeded_weights(cfg), M.synthetic_frames(3, h, w, seed=5, kind="smooth"))
 
 
+@pytest.mark.parametrize("kw", [
+    dict(flow_filters=(32, 64, 128, 64, 32), num_flow_inputs=2),
+    dict(flow_filters=(32, 64, 64, 32), num_flow_inputs=5),
+    dict(flow_arch="resnet", flow_pad_factor=0, flow_res_filters=128, flow_res_blocks=2, num_flow_inputs=3),
+    dict(flow_arch="resnet", flow_pad_factor=8, flow_res_filters=32, flow_res_blocks=1, num_flow_inputs=1),
+], ids=["ae5-in2", "ae4-in5", "res128-in3", "res32-pad8-in1"])
+def test_fp8_tower_behind_nondefault_flow_nets(kw):
+    """The 8-bit tower needs the 64-filter generator; the FLOW net in front of it may be any the loaders admit
+    (the warp's output is the tower's input): same three requirements against the 8-bit oracle as with the default
+    flow net."""
+    cfg = small_config(frame_height=34, frame_width=50, gen_blocks=2, **kw)
+    _fp8_case(cfg, M.make_seeded_weights(cfg), M.synthetic_frames(3, 34, 50, seed=13, kind="smooth"))
+
+
 @pytest.mark.parametrize("h,w,blocks,mode", [(30, 48, 3, "resident"), (34, 50, 2, "resident"), (64, 96, 5, "layers"),
                                              (40, 70, 4, "convs")])
 def test_fp8_tower_of_a_leaky_generator_matches_its_oracle(h, w, blocks, mode, monkeypatch):
