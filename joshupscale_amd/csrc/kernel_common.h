@@ -187,7 +187,7 @@ __device__ __forceinline__ float brightnessOf(const unsigned *__restrict__ sums,
 // dense_image_warp of the previous HR output (tfa/dense_image_warp.py:232-245, 116-171) +
 // space_to_depth(4) + concat (models.py:523-530) + pack: 4 warped HR pixels x 3 channels in
 // slots 0..11, the LR frame's pixel in 12..14 of quarter 0, zeros elsewhere.  Shared by
-// warp_pack_kernel and the flow head block (which warps its own tile, flow_kernels.hip).
+// warp_pack_kernel (round 3 also ran it inside the flow head block: built, bit-identical, not kept).
 // f8: the flow head's 8 values (dy, dx) x 4 for this quarter; pw: the same 4 warped pixels as
 // f16 [4] records (the temporal filter's pre_warp).
 template <typename T>

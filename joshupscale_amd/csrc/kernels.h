@@ -142,7 +142,7 @@ bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHea
 void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream);
 
 // One 3x3 convolution of the flow net's coarse levels (cin 128 / 256, a few thousand pixels), the
-// input channels split over the eight waves of a workgroup (flow_kernels.hip, conv_splitk_kernel).
+// input channels split over the eight waves of a workgroup (splitk_kernels.hip, conv_splitk_kernel).
 // Weights: packConvWeights with nb = 1.  `zeros`: >= 16 zero bytes of device memory.
 bool convSplitKSupported(const ConvParams &p);
 void launchConvSplitK(DType dt, const ConvParams &p, const void *zeros, hipStream_t stream);
