@@ -147,3 +147,26 @@ def fake_tensorflow() -> types.ModuleType:
     tf.zeros = lambda shape, dtype=None: np.zeros(shape, np.float32)
     tf.constant = lambda x: np.asarray(x)
     return tf
+
+
+# ---- `create_models` (scripts/training/models.py:1138-1194) for tools/export_jupw_from_keras.py's test ----
+MODELS = {"flow-resnet": get_flow_resnet, "flow-autoencoder": get_flow_autoencoder,
+          "generator-resnet": get_generator_resnet}
+
+
+def create_models(config):
+    """Entries {"name": <model type>, "weights": <file>, **constructor arguments}; `weights` is an .npz of
+    {"<layer>/<index>": array} here (the reference loads a Keras .weights.h5 at this point)."""
+    built = {}
+    for key, args in config.items():
+        kw = {k: v for k, v in args.items() if k not in ("name", "weights", "freeze", "copy_weights", "copy_variables")}
+        if args["name"] not in MODELS:
+            raise ValueError(f"Unknown model type {args['name']}")
+        model = MODELS[args["name"]](name=key, **kw)
+        if "weights" in args:
+            data = np.load(args["weights"])
+            for layer in model.layers:
+                if layer.weights:
+                    layer.set_weights([data[f"{layer.name}/{i}"] for i in range(len(layer.weights))])
+        built[key] = model
+    return built

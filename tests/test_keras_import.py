@@ -1,6 +1,8 @@
 """Keras-variable -> container mapping (joshupscale_amd/keras_import.py): pure numpy,
 no Keras needed.  The Keras-facing shim (tools/export_jupw_from_keras.py) only
 collects ``layer.get_weights()`` by layer name and calls this mapping."""
+import os
+
 import numpy as np
 import pytest
 
@@ -91,3 +93,49 @@ def test_activation_spec_of_the_reference_configs():
     cfg2, _ = K.container_weights(gen, flow, M.ModelConfig(
         frame_height=30, frame_width=48, flow_pad_factor=2, gen_activation="lrelu", gen_negative_slope=0.2))
     assert cfg2 == cfg
+
+
+def test_export_tool_end_to_end_against_a_stand_in_checkout(tmp_path):
+    """tools/export_jupw_from_keras.py had never executed (it imports the reference's `models` under TensorFlow).
+    Here it runs as the user would run it -- its own argument parsing, YAML config, `create_models`, layer walk,
+    `container_weights`, `M.save` -- against a stand-in checkout whose scripts/training/models.py is
+    tests/fake_reference.py (layer lists and shapes of the reference constructors, no TensorFlow, no arithmetic):
+    the container it writes must be byte for byte the one the seeded weights serialise to."""
+    import subprocess
+    import sys
+
+    import yaml
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    training = tmp_path / "ref" / "scripts" / "training"
+    training.mkdir(parents=True)
+    (training / "models.py").write_text(
+        "import sys\nsys.path.insert(0, %r)\nsys.path.insert(0, %r)\nfrom fake_reference import *  # noqa\n"
+        % (os.path.join(root, "tests"), root))
+    cfg = M.ModelConfig(frame_height=34, frame_width=50, flow_pad_factor=0, gen_blocks=2, gen_filters=32,
+                        flow_arch="resnet", flow_res_filters=96, flow_res_blocks=1, num_flow_inputs=3,
+                        gen_activation="lrelu", gen_negative_slope=0.2, compute_dtype=M.DTYPE_F16)
+    wts = M.make_seeded_weights(cfg, seed=5)
+    gen_layers, flow_layers = K.layers_from_container(wts)
+    for name, layers in (("gen", gen_layers), ("flow", flow_layers)):
+        np.savez(tmp_path / f"{name}.npz", **{f"{k}/{i}": v for k, vs in layers.items() for i, v in enumerate(vs)})
+    config = {"models": {
+        "generator": {"name": "generator-resnet", "num_filters": 32, "num_res_blocks": 2,
+                      "activation": {"name": "lrelu", "negative_slope": 0.2}, "weights": str(tmp_path / "gen.npz")},
+        "flow": {"name": "flow-resnet", "num_inputs": 3, "num_filters": 96, "num_res_blocks": 1,
+                 "weights": str(tmp_path / "flow.npz")}}}
+    (tmp_path / "config.yaml").write_text(yaml.safe_dump(config))
+    out = tmp_path / "model.jupw"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "export_jupw_from_keras.py"), str(out),
+                        "--reference", str(tmp_path / "ref"), "--config", str(tmp_path / "config.yaml"),
+                        "--frame-size", "34x50", "--flow-pad", "0", "--fp16"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "flow=resnet" in r.stdout and "generator 32 x 2" in r.stdout
+    cfg2, wts2 = M.load(str(out))
+    # (bn_eps and the slope come back as float32: the bytes are what must agree)
+    assert (cfg2.gen_filters, cfg2.flow_res_filters, cfg2.num_flow_inputs, cfg2.gen_activation) == (32, 96, 3, "lrelu")
+    assert open(out, "rb").read() == M.serialize(cfg, {k: wts[k] for k in wts2})
+    # a missing argument is a usage error, not a traceback from somewhere inside
+    bad = subprocess.run([sys.executable, os.path.join(root, "tools", "export_jupw_from_keras.py"), str(out)],
+                         capture_output=True, text=True)
+    assert bad.returncode == 2 and "--reference" in bad.stderr
