@@ -96,21 +96,25 @@ PMC_PROFILE = "r04_pmc_per_kernel_{preset}_{dtype}.json"
 
 def cpu_baseline(blob: bytes, cfg, frames: np.ndarray, budget_s: float) -> dict:
     """The C restatement of the reference path (oracle/ju_oracle_c.c), timed on
-    this box's host cores on a bounded sample of the same workload."""
+    this box's host cores on a bounded sample of the same workload.  Threads = the CPUs the process may
+    really use (oracle/c_binding.usable_cpus: the affinity mask cut to the cgroup's CPU quota -- OpenMP's own
+    default, one thread per logical CPU of the host, ran 4x slower under the boxes' 16-CPU quota,
+    profiles/r04_cpu_scaling.txt)."""
     from oracle.c_binding import CSession
     sess = CSession(blob, cfg.frame_height, cfg.frame_width)
     t0 = time.perf_counter()
     sess.run(frames[0])
     first = time.perf_counter() - t0
-    n = int(max(1, min(8, budget_s // max(first, 1e-3))))
+    n = int(max(1, min(64, budget_s // max(first, 1e-3))))
     t0 = time.perf_counter()
     for i in range(n):
         sess.run(frames[(i + 1) % len(frames)])
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": sess.threads, "kind": "port",
             "sample": f"{n} frame(s) of the same {cfg.frame_width}x{cfg.frame_height} clip "
-                      f"after 1 warm-up frame, C fp32 restatement with OpenMP "
-                      f"({dt / n:.2f} s/frame, host has {os.cpu_count()} logical CPUs)"}
+                      f"after 1 warm-up frame, C fp32 restatement with OpenMP, {sess.vector_bits}-bit blocks "
+                      f"({dt / n:.2f} s/frame; {sess.threads} threads = the process's CPU quota, "
+                      f"host has {os.cpu_count()} logical CPUs)"}
 
 
 def main() -> int:

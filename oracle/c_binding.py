@@ -19,6 +19,31 @@ def build() -> str:
     return _PATH
 
 
+def usable_cpus() -> int:
+    """CPUs this process may really keep busy: the affinity mask, cut to the cgroup's CPU quota (v2 `cpu.max`, v1
+    `cpu.cfs_quota_us`).  OpenMP's default is the number of logical CPUs it can see; on the GPU boxes that is 256 under a
+    quota of 16, and the oversubscribed run is throttled to a quarter of the 16-thread speed
+    (profiles/r04_cpu_scaling.txt)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = int(f.read()), int(g.read())
+                if q > 0 and period > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
 def load():
     global _LIB
     if _LIB is None:
@@ -34,6 +59,10 @@ def load():
         lib.juo_output_raw.restype = C.POINTER(C.c_float)
         lib.juo_output_raw.argtypes = [C.c_void_p]
         lib.juo_num_threads.restype = C.c_int
+        lib.juo_set_num_threads.argtypes = [C.c_int]
+        lib.juo_vector_bits.restype = C.c_int
+        if "OMP_NUM_THREADS" not in os.environ:
+            lib.juo_set_num_threads(usable_cpus())
         _LIB = lib
     return _LIB
 
@@ -62,6 +91,11 @@ class CSession:
     @property
     def threads(self) -> int:
         return self.lib.juo_num_threads()
+
+    @property
+    def vector_bits(self) -> int:
+        """512 / 256: width of the convolution's blocks on this CPU; 0: the plain form (JUO_VECTOR_BITS=0)."""
+        return self.lib.juo_vector_bits()
 
     def close(self):
         if self.handle:

@@ -10,7 +10,7 @@
  *
  * PARITY UNPINNED: the reference ships no golden vectors and cannot be built or
  * imported in this environment (see oracle/ju_oracle.py); this file is pinned
- * only against that numpy restatement (tests/test_oracle_c.py).
+ * only against that numpy restatement (tests/test_oracle_cross.py, tests/test_golden.py).
  *
  * It follows the reference graph op for op and in the reference's order --
  * Conv2D, then BatchNormalization (NOT folded), then the activation -- in
@@ -25,7 +25,7 @@
  * It reads the same .jupw container as the engine (own parser, shares no code
  * with joshupscale_amd/csrc/model.cpp).
  *
- * Build: gcc -O3 -march=native -fopenmp -shared -fPIC (oracle/Makefile).
+ * Build: gcc -O3 -march=x86-64-v3 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
  */
 #include <math.h>
 #include <stdint.h>
@@ -95,6 +95,17 @@ int juo_num_threads(void) {
 #endif
 }
 
+/* The caller knows how many CPUs the process may really use (a container's CPU quota is invisible to
+ * OpenMP, which counts the host's logical CPUs: 128 threads under a 16-CPU quota ran four times SLOWER
+ * than 16 threads, profiles/r04_cpu_scaling.txt). */
+void juo_set_num_threads(int n) {
+#ifdef _OPENMP
+	if (n >= 1) omp_set_num_threads(n);
+#else
+	(void)n;
+#endif
+}
+
 /* ---- primitives ------------------------------------------------------- */
 
 /* Conv2D(k x k, stride 1, "same"), NHWC, kernel [k][k][cin][cout], optional bias
@@ -126,53 +137,125 @@ static void conv_pixel(const float *x, int H, int W, int cin, const float *k, in
 
 /* layers.Conv2D(strides=1, padding="same"), odd square kernels (models.py:218-225, 300-306, 378-385,
  * 469-475, 531-537): y[h,w,o] = bias[o] + sum_{a,b,c} x[h+a-p, w+b-p, c] * K[a,b,c,o], taps outside
- * the image skipped.  Interior columns are computed FOUR PIXELS x 32 OUTPUT CHANNELS at a time, so
- * that a row of the kernel is loaded once for four pixels instead of once per pixel (the plain form
- * streams the whole kernel, 147 KB for 64 -> 64, through the cache for every pixel: 0.2 TFLOP/s on
- * 128 threads).  Every output element still accumulates bias, then (a, b, c) in that order, with one
- * multiply and one add per term: the results are bit-identical to the plain form (the build sets
- * -ffp-contract=off for that), which the tests check. */
-#define JUO_PB 4
-#define JUO_OB 32
+ * the image skipped.  Interior columns are computed A FEW PIXELS x 16 or 32 OUTPUT CHANNELS at a time, so
+ * that a row of the kernel is loaded once for the block instead of once per pixel (the plain form
+ * streams the whole kernel, 147 KB for 64 -> 64, through the cache for every pixel).  Every output
+ * element still accumulates bias, then (a, b, c) in that order, with one multiply and one add per
+ * term (the build sets -ffp-contract=off; the vector types below are element-wise): the results are
+ * bit-identical to the plain form whatever the block shape and the vector width, which the tests
+ * check.  The library is built for x86-64-v3 (it travels to another host); where the CPU has AVX-512
+ * the 16-wide blocks are picked at run time. */
+typedef float juo_v8 __attribute__((vector_size(32)));
+typedef float juo_v16 __attribute__((vector_size(64)));
+typedef float juo_v8_mem __attribute__((vector_size(32), aligned(4), may_alias));  /* as it lies in a tensor */
+typedef float juo_v16_mem __attribute__((vector_size(64), aligned(4), may_alias));
+
+/* PB pixels (columns w .. w+PB-1 of row h, all of whose taps' columns are inside the image) x TWO vectors of
+ * output channels from `ob`.  The accumulators are named variables, not an array: gcc keeps an array of vectors
+ * in memory and stores every update. */
+#define JUO_REP1(M) M(0)
+#define JUO_REP6(M) M(0) M(1) M(2) M(3) M(4) M(5)
+#define JUO_REP8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define JUO_DECL(q) VT a##q##_0 = b0, a##q##_1 = b1;
+#define JUO_STEP(q)                                  \
+	{                                                \
+		const float xv = xp[(size_t)(q) * cin + c];  \
+		a##q##_0 += xv * k0;                         \
+		a##q##_1 += xv * k1;                         \
+	}
+#define JUO_STORE(q)                                                \
+	{                                                               \
+		float *yp = y + ((size_t)h * W + w + (q)) * cout + ob;      \
+		*(VTM *)yp = a##q##_0;                                      \
+		*(VTM *)(yp + VL) = a##q##_1;                               \
+	}
+#define JUO_DEFINE_BLOCK(NAME, VEC, VECM, VLEN, REP, ATTR)                                              \
+	ATTR static void NAME(const float *x, int H, int W, int cin, const float *k, int ks, int cout,      \
+	    const float *bias, float *y, int h, int w, int ob) {                                             \
+		typedef VEC VT;                                                                                 \
+		typedef VECM VTM;                                                                               \
+		enum { VL = VLEN };                                                                             \
+		const int p = (ks - 1) / 2;                                                                     \
+		VT b0 = {0}, b1 = {0};                                                                          \
+		if (bias) {                                                                                     \
+			b0 = *(const VTM *)(bias + ob);                                                             \
+			b1 = *(const VTM *)(bias + ob + VL);                                                        \
+		}                                                                                               \
+		REP(JUO_DECL)                                                                                   \
+		for (int a = 0; a < ks; ++a) {                                                                  \
+			const int yy = h + a - p;                                                                   \
+			if (yy < 0 || yy >= H) continue;                                                            \
+			for (int b = 0; b < ks; ++b) {                                                              \
+				const float *xp = x + ((size_t)yy * W + (w + b - p)) * cin;                             \
+				const float *kp = k + (size_t)(a * ks + b) * cin * cout + ob;                           \
+				for (int c = 0; c < cin; ++c) {                                                         \
+					const VT k0 = *(const VTM *)(kp + (size_t)c * cout);                                \
+					const VT k1 = *(const VTM *)(kp + (size_t)c * cout + VL);                           \
+					REP(JUO_STEP)                                                                       \
+				}                                                                                       \
+			}                                                                                           \
+		}                                                                                               \
+		REP(JUO_STORE)                                                                                  \
+	}
+
+typedef void (*juo_block_fn)(const float *, int, int, int, const float *, int, int, const float *, float *, int, int, int);
+JUO_DEFINE_BLOCK(conv_block_v8, juo_v8, juo_v8_mem, 8, JUO_REP6, )    /* 6 pixels x 16 channels: 12 + 2 + 1 of 16 registers */
+JUO_DEFINE_BLOCK(conv_block1_v8, juo_v8, juo_v8_mem, 8, JUO_REP1, )
+#if defined(__x86_64__)
+JUO_DEFINE_BLOCK(conv_block_v16, juo_v16, juo_v16_mem, 16, JUO_REP8, __attribute__((target("avx512f"))))  /* 8 x 32 */
+JUO_DEFINE_BLOCK(conv_block1_v16, juo_v16, juo_v16_mem, 16, JUO_REP1, __attribute__((target("avx512f"))))
+#endif
+
+static juo_block_fn g_block = conv_block_v8, g_block1 = conv_block1_v8;
+static int g_block_px = 6, g_block_ch = 16, g_vector_bits = 256;
+
+/* 512, 256 or 0: which form runs.  JUO_VECTOR_BITS=256 forces the narrow blocks, JUO_VECTOR_BITS=0 the plain
+ * form for every pixel: tests/test_oracle_cross.py compares the bytes of the three. */
+int juo_vector_bits(void) {
+	static int chosen;
+	if (!chosen) {
+		chosen = 1;
+		const char *e = getenv("JUO_VECTOR_BITS");
+		if (e && atoi(e) == 0) {
+			g_block_ch = 1 << 30;  /* no channel count is a multiple: conv_row takes the plain form */
+			g_vector_bits = 0;
+			return 0;
+		}
+#if defined(__x86_64__)
+		if (__builtin_cpu_supports("avx512f") && !(e && atoi(e) == 256)) {
+			g_block = conv_block_v16;
+			g_block1 = conv_block1_v16;
+			g_block_px = 8;
+			g_block_ch = 32;
+			g_vector_bits = 512;
+		}
+#endif
+	}
+	return g_vector_bits;
+}
+
+static void conv_row(const float *x, int H, int W, int cin, const float *k, int ks, int cout,
+    const float *bias, float *y, int h) {
+	const int p = (ks - 1) / 2;
+	int w = 0;
+	/* left border columns: taps fall outside the image */
+	for (; w < p && w < W; ++w) conv_pixel(x, H, W, cin, k, ks, cout, bias, h, w, y + ((size_t)h * W + w) * cout);
+	if (cout % g_block_ch == 0 && W - p > w) {
+		for (; w + g_block_px <= W - p; w += g_block_px) {
+			for (int ob = 0; ob < cout; ob += g_block_ch) g_block(x, H, W, cin, k, ks, cout, bias, y, h, w, ob);
+		}
+		for (; w < W - p; ++w) {
+			for (int ob = 0; ob < cout; ob += g_block_ch) g_block1(x, H, W, cin, k, ks, cout, bias, y, h, w, ob);
+		}
+	}
+	for (; w < W; ++w) conv_pixel(x, H, W, cin, k, ks, cout, bias, h, w, y + ((size_t)h * W + w) * cout);
+}
+
 static void conv2d_same(const float *x, int H, int W, int cin, const float *k, int ks, int cout,
     const float *bias, float *y) {
-	const int p = (ks - 1) / 2;
+	juo_vector_bits();
 #pragma omp parallel for schedule(static)
-	for (int h = 0; h < H; ++h) {
-		int w = 0;
-		/* left border columns: taps fall outside the image */
-		for (; w < p && w < W; ++w) conv_pixel(x, H, W, cin, k, ks, cout, bias, h, w, y + ((size_t)h * W + w) * cout);
-		if (cout % JUO_OB == 0) {
-			for (; w + JUO_PB <= W - p; w += JUO_PB) {
-				for (int ob = 0; ob < cout; ob += JUO_OB) {
-					float acc[JUO_PB][JUO_OB];
-					for (int q = 0; q < JUO_PB; ++q) {
-						for (int o = 0; o < JUO_OB; ++o) acc[q][o] = bias ? bias[ob + o] : 0.0f;
-					}
-					for (int a = 0; a < ks; ++a) {
-						const int yy = h + a - p;
-						if (yy < 0 || yy >= H) continue;
-						for (int b = 0; b < ks; ++b) {
-							/* all four pixels' columns w + q + b - p are inside the image here */
-							const float *xp = x + ((size_t)yy * W + (w + b - p)) * cin;
-							const float *kp = k + (size_t)(a * ks + b) * cin * cout + ob;
-							for (int c = 0; c < cin; ++c) {
-								const float *kr = kp + (size_t)c * cout;
-								for (int q = 0; q < JUO_PB; ++q) {
-									const float xv = xp[(size_t)q * cin + c];
-									for (int o = 0; o < JUO_OB; ++o) acc[q][o] += xv * kr[o];
-								}
-							}
-						}
-					}
-					for (int q = 0; q < JUO_PB; ++q) {
-						memcpy(y + ((size_t)h * W + w + q) * cout + ob, acc[q], sizeof(float) * JUO_OB);
-					}
-				}
-			}
-		}
-		for (; w < W; ++w) conv_pixel(x, H, W, cin, k, ks, cout, bias, h, w, y + ((size_t)h * W + w) * cout);
-	}
+	for (int h = 0; h < H; ++h) conv_row(x, H, W, cin, k, ks, cout, bias, y, h);
 }
 
 /* keras ReLU (slope 0) / LeakyReLU(negative_slope) (models.py:24-27) */

@@ -1,5 +1,7 @@
 """The three restatements agree with each other (CPU)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -121,3 +123,42 @@ def test_lrelu_changes_the_result_and_relu_is_the_default():
     assert not np.array_equal(outs["relu"], outs["lrelu"])
     assert not np.array_equal(outs["lrelu"], outs["gen-only"])
     assert oracle_config(small_config()).gen_activation == "relu"
+
+
+_FORMS_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+from helpers import M, small_config
+from oracle.c_binding import CSession
+h = hashlib.sha256()
+bits = None
+for kw in (dict(gen_blocks=2), dict(gen_blocks=1, gen_filters=32, flow_filters=(32, 64, 128, 64, 32)),
+           dict(gen_blocks=1, gen_filters=96, flow_arch="resnet", flow_pad_factor=0, flow_res_filters=32, flow_res_blocks=1),
+           dict(gen_blocks=1, frame_height=17, frame_width=33), dict(gen_blocks=1, frame_height=9, frame_width=7)):
+    cfg = small_config(**kw)
+    cs = CSession(M.serialize(cfg, M.make_seeded_weights(cfg)), cfg.frame_height, cfg.frame_width)
+    bits = cs.vector_bits
+    for f in M.synthetic_frames(2, cfg.frame_height, cfg.frame_width, seed=5, kind="noise"):
+        h.update(cs.run(f).tobytes()); h.update(cs.output_raw().tobytes())
+print(bits, h.hexdigest())
+"""
+
+
+def test_c_restatement_gives_the_same_bytes_in_every_form_of_its_convolution():
+    """oracle/ju_oracle_c.c computes interior pixels in register blocks (6 pixels x 16 channels with AVX2, 8 x 32 where the
+    CPU has AVX-512) and everything else one pixel at a time; every output element accumulates the same terms in the same
+    order with one multiply and one add each, so the frames and the float `output_raw` are EQUAL whichever form ran --
+    the plain form (JUO_VECTOR_BITS=0) is the restatement, the blocks are only its speed."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    seen = {}
+    for want in ("0", "256", "512"):
+        out = subprocess.run([sys.executable, "-c", _FORMS_SCRIPT.format(root=ROOT)], capture_output=True, text=True,
+                             env=dict(os.environ, JUO_VECTOR_BITS=want, OMP_NUM_THREADS="4"))
+        assert out.returncode == 0, out.stderr
+        bits, digest = out.stdout.split()
+        seen[int(bits)] = digest
+        if want != "512":
+            assert int(bits) == int(want)
+    assert {0, 256} <= set(seen) and len(set(seen.values())) == 1, seen
