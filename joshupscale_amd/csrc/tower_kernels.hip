@@ -965,7 +965,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		constexpr int LO = decltype(loTag)::value, HI = decltype(hiTag)::value;
 		auto slot = [&](f32x16(&acc)[2], const int k) __attribute__((always_inline)) {
 			if (k < nPre) {
-				const int nu = (k + 1 < nPre) ? preFirst + 2 * (k + 1) : -1;
+				// (k + 1 < kPreRun folds at compile time: without it the last slot carries a never-taken branch that
+				// primes a successor nobody reads -- four LDS reads into dead registers which the halo loads then
+				// reuse, the one thing tools/lds_wait_check.py found in the built kernels)
+				const int nu = (k + 1 < kPreRun && k + 1 < nPre) ? preFirst + 2 * (k + 1) : -1;
 				unitSeg(R2{}, KPre{}, std::false_type{}, inTag, outTag, acc, layer, preFirst + 2 * k,
 				    (k > 0 || primedFirst) && !kNoMfma, nu, false, std::false_type{}, std::false_type{}, acc, 0, std::true_type{});
 			}
