@@ -3,7 +3,7 @@
 # headline profile once more (boxes differ by +-3 %), and the long soaks.
 R=$GRAFT_REPO_ROOT
 cd $R
-python3 -m pytest tests -m gpu -q --no-header -p no:cacheprovider -x 2>&1 | tail -4 > gpurun_out/r04_final_gputests.log
+python3 -m pytest tests -m gpu -q --no-header -p no:cacheprovider -x 2>&1 | grep -E "passed|failed|error" | tail -4 > gpurun_out/r04_final_gputests.log
 cat gpurun_out/r04_final_gputests.log
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_driver_cmd_bench_b.json 2> gpurun_out/r04_driver_cmd_b.err
