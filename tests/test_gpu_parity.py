@@ -62,6 +62,43 @@ def test_small_models_match_oracle(arch, pad, h, w, blocks, extra, dtype):
     rt.close()
 
 
+# The smallest and the most lopsided frames the loader admits (model.cpp validateConfig: 2 <= H, W <= 8192): a frame
+# smaller than one MFMA tile, one row pair, one column pair, odd sizes below the flow net's padding factor, a strip a
+# single region row high and 65 regions wide.  Both flow architectures; the auto-encoder pads these up to a multiple
+# of 8 (models.py:783-787), so most of its input is padding.
+EXTREME_CASES = [
+    ("autoencoder", 8, 2, 2), ("resnet", 0, 2, 2), ("autoencoder", 8, 2, 3), ("resnet", 0, 3, 2),
+    ("autoencoder", 8, 5, 7), ("resnet", 0, 7, 5), ("autoencoder", 8, 9, 4), ("resnet", 0, 1 + 8, 31),
+    ("autoencoder", 8, 2, 130), ("resnet", 0, 130, 2), ("autoencoder", 8, 131, 3), ("resnet", 0, 3, 131),
+    ("autoencoder", 8, 4, 2050), ("resnet", 0, 33, 31),
+]
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
+@pytest.mark.parametrize("arch,pad,h,w", EXTREME_CASES, ids=[f"{c[0][:3]}-{c[2]}x{c[3]}" for c in EXTREME_CASES])
+def test_extreme_geometries_match_oracle(arch, pad, h, w, dtype):
+    cfg = small_config(frame_height=h, frame_width=w, gen_blocks=2, flow_arch=arch, flow_pad_factor=pad,
+                       flow_res_blocks=1)
+    wts, blob, rt = make(cfg, dtype)
+    sess = O.Session(wts, oracle_config(cfg))
+    oc = oracle_config(cfg)
+    frames = M.synthetic_frames(3, h, w, seed=9, kind="noise")
+    worst = dict(flow=0.0, raw=0.0)
+    for t in range(3):
+        trace = {}
+        ref = sess.run(frames[t], trace)
+        out = rt.process_image(frames[t])
+        check_u8(out, ref, dtype, ("extreme", arch, h, w, t))
+        flow = rt.read_tensor("flow").reshape(oc.padded_height, oc.padded_width, 32)
+        worst["flow"] = max(worst["flow"], err(flow, trace["flow"])["max_abs"])
+        state = rt.read_tensor("state").reshape(4 * h, 4 * w, 4)
+        worst["raw"] = max(worst["raw"], err(state[..., :3], sess.last.output_raw)["max_abs"])
+        assert not state[..., 3].any()
+    record(("extreme-tensors", arch, h, w), dtype, worst)
+    assert worst["flow"] <= TOL[dtype]["flow"] and worst["raw"] <= TOL[dtype]["raw"], worst
+    rt.close()
+
+
 # Every hyper-parameter the reference constructors are parametric in (models.py:257-263, 334-339,
 # 364-365, 449-468, 484-491) and the loader admits (csrc/model.cpp validateConfig, model_file.py):
 # generator width, flow auto-encoder depth / widths (odd and even filter lists), flow-resnet width,
@@ -836,6 +873,10 @@ def _fp8_case(cfg, wts, frames):
     (34, 50, 2),     # 10 tiles, ragged edges: grid rounded up to 16, surplus workgroups idle
     (64, 96, 5),
     (40, 70, 24),    # the full depth
+    # below one tile; strips one pixel pair wide / high.  (Not 2 x 2: the requirements are statistics -- PSNR differences
+    # within 0.5 dB -- and 192 output samples do not carry them: 0.54 dB measured.  The 16-bit engine is held to the
+    # oracle at 2 x 2 sample by sample, test_extreme_geometries_match_oracle.)
+    (3, 131, 2), (130, 2, 2), (5, 7, 3), (4, 1030, 1),
 ])
 def test_fp8_tower_matches_its_oracle(h, w, blocks):
     cfg = small_config(frame_height=h, frame_width=w, gen_blocks=blocks)
