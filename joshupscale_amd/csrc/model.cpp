@@ -1,5 +1,6 @@
 #include "model.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -168,6 +169,30 @@ void validateConfig(const ModelConfig &c) {
 			bad("flow_res_filters must be a multiple of 32 (at most 256)");
 		}
 		if (c.flowResBlocks < 0 || c.flowResBlocks > 256) bad("flow_res_blocks must be in 0..256");
+	}
+	// Size: several kernels address a tensor with 32-bit byte offsets (buffer descriptors, scalar + lane offsets), so
+	// no activation tensor may reach 4 GiB.  The largest is a full-resolution one of the widest layer in the padded
+	// layout ((H rounded up to 8) + 2 rows of (W rounded up to 32) + 2 pixels; the HR state is 128 B per LR pixel like
+	// a 64-channel layer).  64-channel models: 33 M pixels (8192 x 4064, 5760 x 5800); tests/test_gpu_presets.py runs the
+	// engines at that size.  The reference has no such limit -- TensorRT builds an engine for whatever frame it is given.
+	{
+		int widest = std::max(64, c.genFilters);
+		if (c.flowArch == 0) {
+			for (std::size_t i = 0; i < c.flowFilters.size(); ++i) {
+				// (level of unit i: 0, 1, .., nb - 1, bottom, .., 0: a level-k tensor has 4^-k of the pixels)
+				const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+				const int level = static_cast<int>(i) < nb ? static_cast<int>(i) : std::max(0, 2 * nb - 1 - static_cast<int>(i));
+				widest = std::max(widest, c.flowFilters[i] >> (2 * std::min(level, 4)));
+			}
+		} else {
+			widest = std::max(widest, c.flowResFilters);
+		}
+		const unsigned long long rows = static_cast<unsigned long long>((c.paddedHeight() + 7) / 8 * 8 + 2);
+		const unsigned long long pitch = static_cast<unsigned long long>((c.paddedWidth() + 31) / 32 * 32 + 2);
+		if (rows * pitch * 2ull * static_cast<unsigned long long>(widest) > 0xFFC00000ull) {
+			bad("frame too large for this model: an activation tensor would reach 4 GiB (" + std::to_string(widest) +
+			    " channels x " + std::to_string(rows * pitch) + " pixels x 2 bytes)");
+		}
 	}
 }
 

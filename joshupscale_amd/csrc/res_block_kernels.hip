@@ -44,7 +44,14 @@ struct ResBlockParams {
 	float s1, s2;          // activation multipliers (fbActS)
 	int skip;              // timing ablation (JU_FB_SKIP, developer only)
 	unsigned long long *prof;  // developer builds (-DJU_RB_PROF): per-wave cycle sums of workgroup 0
+	// res_block_pipe_kernel: bytes of `in` / `out` from the pointer to the end of image row H - 1 (the range of its
+	// buffer descriptors; everything behind it is zero padding or never touched)
+	unsigned inBytes, outBytes;
 };
+// The pipelined kernel addresses its tensors with 32-bit byte offsets (descriptor + scalar + lane offset) and gets the
+// rows above the image from offsets that wrap below zero, i.e. land just under 4 GiB and out of the descriptor's
+// range: a tensor may reach 4 GiB minus the two rows of the widest frame (2 x 8226 px x 128 B) and a margin.
+constexpr unsigned long long kRpMaxTensorBytes = 0xFFC00000ull;
 
 template <typename T>
 __global__ __launch_bounds__(256, 1) void res_block_kernel(ResBlockParams p) {
@@ -310,11 +317,13 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 	unsigned char *stage = smem + kRbX + kRbT + wave * kRpStageWave;
 	float *biasLds = reinterpret_cast<float *>(smem + kRbX + kRbT + 4 * kRpStageWave);
 	// Global memory through buffer instructions: the lane's part of an address is ONE loop-invariant
-	// 32-bit register, the tile / row / fragment part is scalar (a tensor is < 2 GiB).
+	// 32-bit register, the tile / row / fragment part is scalar (a tensor is < 4 GiB: the launcher checks).
+	// (Until round 4 the descriptors said 2 GiB - 16 and no launcher checked: beyond 16.7 M pixels -- 4096 x 4096 -- the
+	// rows past 2 GiB read as zeros and their stores were dropped; found by tests/test_gpu_presets.py's crop property.)
 	const __amdgpu_buffer_rsrc_t rsrcWa = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w1), 0, 2 * 36 * 1024, 0x00020000);
 	const __amdgpu_buffer_rsrc_t rsrcWb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w2), 0, 2 * 36 * 1024, 0x00020000);
-	const __amdgpu_buffer_rsrc_t rsrcIn = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, 0x7ffffff0, 0x00020000);
-	const __amdgpu_buffer_rsrc_t rsrcOut = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x7ffffff0, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rsrcIn = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.inBytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rsrcOut = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.outBytes, 0x00020000);
 	const unsigned wLane = static_cast<unsigned>(lane) * 16u;
 	const unsigned wBase = static_cast<unsigned>(cb) * (36u * 1024u);
 
@@ -803,7 +812,11 @@ template <typename T>
 void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
 	// the pipelined form (epilogues behind the next pair's MFMAs); JU_RES_BLOCK=plain: the plain kernel (tests, A/B).
 	// A slope outside [0, 1] (no model the container accepts has one) also takes the plain kernel.
-	const bool pipe = !resBlockPlain() && q.act1 == 1 && q.act2 == 1 && ablationSkipBits() == 0;  // (ReLU blocks)
+	const int inPitch = q.inPitch ? q.inPitch : q.W, outPitch = q.outPitch ? q.outPitch : q.W;
+	const unsigned long long inBytes = 128ull * q.H * inPitch, outBytes = 128ull * q.H * outPitch;
+	// (tensors of 4 GiB and more: the plain kernel, which addresses with 64-bit pointers)
+	const bool pipe = !resBlockPlain() && q.act1 == 1 && q.act2 == 1 && ablationSkipBits() == 0 &&  // (ReLU blocks)
+	                  inBytes <= kRpMaxTensorBytes && outBytes <= kRpMaxTensorBytes;
 	auto kern = pipe ? res_block_pipe_kernel<T> : res_block_kernel<T>;
 	const int ldsBytes = pipe ? kRpLds : kRbLds;
 	static std::atomic<std::uint64_t> ldsDone{0}, ldsDonePipe{0};
@@ -818,8 +831,10 @@ void launchResBlockT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.b2 = q.b2;
 	p.H = q.H;
 	p.W = q.W;
-	p.inPitch = q.inPitch ? q.inPitch : q.W;
-	p.outPitch = q.outPitch ? q.outPitch : q.W;
+	p.inPitch = inPitch;
+	p.outPitch = outPitch;
+	p.inBytes = static_cast<unsigned>(inBytes < kRpMaxTensorBytes ? inBytes : kRpMaxTensorBytes);
+	p.outBytes = static_cast<unsigned>(outBytes < kRpMaxTensorBytes ? outBytes : kRpMaxTensorBytes);
 	p.tilesX = (q.W + kFbOutW - 1) / kFbOutW;
 	p.numTiles = p.tilesX * ((q.H + kRbTH - 1) / kRbTH);
 	p.s1 = q.act1 == 1 ? 0.0f : (q.act1 == 2 ? q.slope : 1.0f);

@@ -237,6 +237,20 @@ def validate_config(cfg: ModelConfig) -> None:
             bad("flow_res_filters must be a multiple of 32 (at most 256)")
         if not 0 <= cfg.flow_res_blocks <= 256:
             bad("flow_res_blocks must be in 0..256")
+    # no activation tensor may reach 4 GiB (32-bit byte offsets in several kernels; csrc/model.cpp states the rule)
+    widest = max(64, cfg.gen_filters)
+    if cfg.flow_arch == "autoencoder":
+        nb = len(cfg.flow_filters) // 2
+        for i, f in enumerate(cfg.flow_filters):
+            level = i if i < nb else max(0, 2 * nb - 1 - i)
+            widest = max(widest, f >> (2 * min(level, 4)))
+    else:
+        widest = max(widest, cfg.flow_res_filters)
+    rows = (cfg.padded_height + 7) // 8 * 8 + 2
+    pitch = (cfg.padded_width + 31) // 32 * 32 + 2
+    if rows * pitch * 2 * widest > 0xFFC00000:
+        bad(f"frame too large for this model: an activation tensor would reach 4 GiB ({widest} channels x "
+            f"{rows * pitch} pixels x 2 bytes)")
 
 
 def serialize(cfg: ModelConfig, weights: Dict[str, np.ndarray], validate: bool = True) -> bytes:

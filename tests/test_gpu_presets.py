@@ -619,3 +619,61 @@ def test_fp8_resident_failure_falls_back_to_the_block_kernels(monkeypatch):
     got += [rt.process_image(f).copy() for f in frames[4:]]
     assert all(np.array_equal(a, b) for a, b in zip(want, got))  # every form computes the same bytes
     rt.close()
+
+
+# ---------------------------------------------------------------------------
+# frames far larger than any CPU oracle finishes: a size-independent property
+# ---------------------------------------------------------------------------
+_CROP, _MARGIN = 384, 128
+
+
+def _crop_window(y0, x0, H, W):
+    """rows / columns of a crop (LR) farther than _MARGIN from every border the crop does NOT share with the frame"""
+    return ((0 if y0 == 0 else _MARGIN), (_CROP if y0 + _CROP == H else _CROP - _MARGIN),
+            (0 if x0 == 0 else _MARGIN), (_CROP if x0 + _CROP == W else _CROP - _MARGIN))
+
+
+@pytest.mark.parametrize("h,w,dtype,kw", [
+    (5632, 5888, R.DTYPE_BF16, {}),                       # 4.25 GB tensors, just under the loader's limit: res_block_pipe_kernel
+    (4104, 4104, R.DTYPE_F16, {}),                        # just over 2 GiB (where that kernel's descriptors used to end)
+    (5632, 5888, R.DTYPE_FP8, {}),                        # the 8-bit block kernels' 32-bit offsets near their end
+    (5632, 5888, R.DTYPE_BF16, dict(gen_activation="lrelu", gen_negative_slope=0.2)),   # the plain res_block_kernel
+    (4096, 4000, R.DTYPE_BF16, dict(gen_filters=128)),    # the generic convolution kernels at 4.2 GB
+    (2176, 3840, R.DTYPE_BF16, dict(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=1)),
+], ids=["bf16-33Mpx", "fp16-over-2GiB", "fp8-33Mpx", "lrelu-33Mpx", "gen128-16Mpx", "flowres-8Mpx"])
+def test_large_frames_agree_with_crops_of_themselves(h, w, dtype, kw):
+    """No CPU restatement finishes 33 M-pixel frames, but the network is local: farther than its receptive field (flow
+    auto-encoder + warp + a two-block generator: about 70 LR pixels) from a crop's inner borders, the big frame's output
+    IS the crop's output.  Crops at the top-left corner, the centre and the bottom-right corner -- the highest addresses of
+    every tensor, where a 32-bit offset, a descriptor's range or an int index gives out first.  (It did: until round 4
+    res_block_pipe_kernel's buffer descriptors ended at 2 GiB and frames beyond 4096 x 4096 came out wrong below that
+    line, 20-40 LSB, with no error.)  Two recurrent frames; the second may differ by 1 LSB in a few per cent of the bytes
+    (kernel choice and with it the fp32 summation order of a layer depends on the geometry)."""
+    cfg = M.ModelConfig(frame_height=h, frame_width=w, gen_blocks=2, **kw)
+    wts = M.make_seeded_weights(cfg, seed=42)
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(2, h, w, 4), dtype=np.uint8)
+    spots = {"top-left": (0, 0), "centre": ((h - _CROP) // 2 // 8 * 8, (w - _CROP) // 3 // 8 * 8),
+             "bottom-right": (h - _CROP, w - _CROP)}
+    rt = R.Runtime(M.serialize(cfg, wts), 0, dtype)
+    keep = {k: [] for k in spots}
+    for f in frames:
+        out = rt.process_image(f)
+        assert not out[::97, ::89, 3].any()
+        for k, (y0, x0) in spots.items():
+            ya, yb, xa, xb = _crop_window(y0, x0, h, w)
+            keep[k].append(out[4 * (y0 + ya):4 * (y0 + yb), 4 * (x0 + xa):4 * (x0 + xb), :3].copy())
+        del out
+    rt.close()
+    small = M.ModelConfig(frame_height=_CROP, frame_width=_CROP, gen_blocks=2, **kw)
+    for k, (y0, x0) in spots.items():
+        rs = R.Runtime(M.serialize(small, wts), 0, dtype)
+        ya, yb, xa, xb = _crop_window(y0, x0, h, w)
+        for t, f in enumerate(frames):
+            o = rs.process_image(np.ascontiguousarray(f[y0:y0 + _CROP, x0:x0 + _CROP]))[4 * ya:4 * yb, 4 * xa:4 * xb, :3]
+            d = np.abs(o.astype(np.int16) - keep[k][t].astype(np.int16))
+            assert o.std() > 10.0                                   # (a frame, not a constant)
+            assert d.max() <= (0 if t == 0 else 1), (k, t, int(d.max()), float(np.mean(d > 0)))
+            assert np.mean(d > 0) <= 0.12, (k, t, float(np.mean(d > 0)))
+        rs.close()
+    record(("large-frame crops", h, w, sorted(kw)), dtype, {"crops": 3, "frames": 2, "max_lsb": 1})

@@ -153,6 +153,39 @@ def test_untested_widths_are_refused_by_both_loaders_with_one_message(hip_librar
     assert cc.value.code == 1 and str(py.value) in str(cc.value), str(cc.value)
 
 
+# No activation tensor may reach 4 GiB (csrc/model.cpp validateConfig: several kernels address with 32-bit byte offsets).
+# The GPU suite runs the engines just under the limit (test_gpu_presets.py test_large_frames_agree_with_crops_of_themselves).
+SIZE_CASES = [
+    (dict(frame_height=8192, frame_width=8192), False),
+    (dict(frame_height=8192, frame_width=4064), True),
+    (dict(frame_height=5632, frame_width=5888), True),
+    (dict(frame_height=5800, frame_width=5800), False),
+    (dict(frame_height=4096, frame_width=4096, gen_filters=256), False),
+    (dict(frame_height=2048, frame_width=4000, gen_filters=256), True),
+    (dict(frame_height=4096, frame_width=4000, gen_filters=128), True),
+    (dict(frame_height=2048, frame_width=2048, flow_filters=(512, 64, 32)), False),
+    (dict(frame_height=2048, frame_width=2048, flow_filters=(64, 512, 32)), False),     # the decoder block's output is upsampled to full size
+    (dict(frame_height=2048, frame_width=2048, flow_filters=(64, 128, 512, 128, 32)), True),  # 512 channels at a quarter of the pixels at most
+    (dict(frame_height=4096, frame_width=4096, flow_arch="resnet", flow_pad_factor=0, flow_res_filters=256), False),
+]
+
+
+@pytest.mark.parametrize("kw,ok", SIZE_CASES, ids=[str(sorted(k.items()))[:60] for k, _ in SIZE_CASES])
+def test_frames_whose_tensors_would_reach_4_gib_are_refused_by_both_loaders(hip_library, kw, ok):
+    cfg = small_config(gen_blocks=1, **kw)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg), validate=False)
+    if ok:
+        M.validate_config(cfg)
+        R.validate_model(blob)
+        return
+    with pytest.raises(ValueError) as py:
+        M.validate_config(cfg)
+    assert "frame too large for this model: an activation tensor would reach 4 GiB" in str(py.value)
+    with pytest.raises(R.JoshUpscaleError) as cc:
+        R.validate_model(blob)
+    assert cc.value.code == 1 and str(py.value) in str(cc.value), str(cc.value)
+
+
 def test_every_width_the_gpu_suite_runs_is_accepted_by_both_loaders(hip_library):
     import ast
     import os
