@@ -162,6 +162,32 @@ def test_mid_size_ragged_geometry_against_the_c_restatement(h, w, extra, dtype):
     rt.close()
 
 
+@pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16, R.DTYPE_FP8])
+@pytest.mark.parametrize("h,w", [(16, 8192), (4096, 32), (2, 8192), (4095, 31), (17, 4090), (129, 889), (512, 256), (9, 8161)],
+                         ids=lambda v: str(v))
+def test_resident_tower_at_the_edges_of_its_geometry(h, w, dtype):
+    """The one-launch tower takes any frame of at most 256 regions of 32 x 16 pixels: here the shapes at the edges of
+    that rule -- one row of 256 regions (16 x 8192; 2 x 8192: regions two rows high; 9 x 8161: ragged in both directions),
+    one column of 256 (4096 x 32, 4095 x 31), two rows of 128 (17 x 4090: 9- and 8-row regions), exactly 256 full
+    regions (512 x 256), 9 x 28 ragged (129 x 889) -- whole frames against the C restatement (the 8-bit engine: within
+    the quantisation noise of 8 e4m3 convolutions, 40 dB, and it must take its one-launch tower too)."""
+    from oracle.c_binding import CSession
+    cfg = M.ModelConfig(frame_height=h, frame_width=w, gen_blocks=4)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=11))
+    frames = M.synthetic_frames(3, h, w, seed=5, kind="smooth")
+    cs = CSession(blob, h, w)
+    rt = R.Runtime(blob, 0, dtype)
+    assert rt.stat("resident_tower") == 1
+    for t, f in enumerate(frames):
+        out, ref = rt.process_image(f), cs.run(f)
+        if dtype == R.DTYPE_FP8:
+            st = u8_stats(out, ref)
+            assert st["psnr"] >= 40.0 and not out[..., 3].any(), (h, w, t, st)
+        else:
+            check_u8(out, ref, dtype, ("resident-edge", h, w, t))
+    rt.close()
+
+
 @pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_F16])
 def test_full_size_resident_tower_against_the_per_block_kernels(monkeypatch, dtype):
     """The resident tower and the one-launch-per-block kernels share no exchange code and
