@@ -1239,3 +1239,64 @@ def test_fp8_committed_golden_vectors():
         st = u8_stats(out, g["outputs"][t])
         assert st["psnr"] >= 55.0 and st["max"] <= 6, (t, st)
     rt.close()
+
+
+def _fuzz_configs(n, seed):
+    """Seeded random models inside what the loaders admit: every hyper-parameter drawn independently."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        arch = "autoencoder" if rng.random() < 0.6 else "resnet"
+        kw = dict(frame_height=int(rng.integers(2, 72)), frame_width=int(rng.integers(2, 110)),
+                  gen_filters=int(rng.choice([32, 64, 64, 64, 96, 128])), gen_blocks=int(rng.integers(0, 4)),
+                  num_flow_inputs=int(rng.integers(1, 6)), normalize_brightness=bool(rng.random() < 0.3),
+                  flow_arch=arch)
+        if arch == "autoencoder":
+            depth = int(rng.integers(1, 4))
+            enc = [int(rng.choice([32, 64, 96, 128])) for _ in range(depth)]
+            dec = [int(rng.choice([32, 64, 128, 256])) for _ in range(depth)]
+            head = [32] if rng.random() < 0.7 else ([int(rng.choice([32, 64]))] if rng.random() < 0.5 else [])
+            kw["flow_filters"] = tuple(enc + dec + head)
+            kw["flow_pad_factor"] = int(rng.choice([8, 8, 16, 32]))
+        else:
+            kw["flow_pad_factor"] = int(rng.choice([0, 0, 8]))
+            kw["flow_res_filters"] = int(rng.choice([32, 64, 64, 96]))
+            kw["flow_res_blocks"] = int(rng.integers(0, 3))
+        if rng.random() < 0.4:
+            kw.update(gen_activation="lrelu", gen_negative_slope=float(rng.choice([0.1, 0.2, 0.3])))
+        if rng.random() < 0.4:
+            kw.update(flow_activation="lrelu", flow_negative_slope=float(rng.choice([0.05, 0.2])))
+        cfg = M.ModelConfig(**kw)
+        try:
+            M.validate_config(cfg)
+        except ValueError:
+            continue
+        out.append(kw)
+    return out
+
+
+# (JU_FUZZ_N / JU_FUZZ_SEED: a longer hunt from another seed, by hand -- `JU_FUZZ_N=300 JU_FUZZ_SEED=7 pytest -k random_models`)
+FUZZ = _fuzz_configs(int(os.environ.get("JU_FUZZ_N", "24")), seed=int(os.environ.get("JU_FUZZ_SEED", "20260410")))
+
+
+@pytest.mark.parametrize("k", range(len(FUZZ)), ids=[f"{i}-{c['frame_height']}x{c['frame_width']}-{c['flow_arch'][:3]}" for i, c in enumerate(FUZZ)])
+def test_random_models_match_oracle(k):
+    """24 seeded random models -- geometry, both widths, depth, flow architecture and its filter list / padding factor,
+    number of flow inputs, activations, brightness normalisation all drawn independently -- three recurrent frames each
+    against the float64 oracle, alternating dtypes: the combinations no hand-written case list thinks of."""
+    kw = FUZZ[k]
+    dtype = R.DTYPE_BF16 if k % 2 else R.DTYPE_F16
+    cfg = M.ModelConfig(**kw)
+    wts, blob, rt = make(cfg, dtype)
+    sess = O.Session(wts, oracle_config(cfg))
+    h, w = cfg.frame_height, cfg.frame_width
+    worst = 0.0
+    for t, f in enumerate(M.synthetic_frames(3, h, w, seed=100 + k, kind="smooth" if k % 3 else "noise")):
+        ref = sess.run(f)
+        out = rt.process_image(f)
+        check_u8(out, ref, dtype, ("fuzz", k, t), clip="smooth" if k % 3 else "noise")
+        state = rt.read_tensor("state").reshape(4 * h, 4 * w, 4)
+        worst = max(worst, err(state[..., :3], sess.last.output_raw)["max_abs"])
+    record(("fuzz", k, sorted(kw.items())), dtype, {"raw": worst})
+    assert worst <= TOL[dtype]["raw"], (kw, worst)
+    rt.close()
