@@ -1300,3 +1300,23 @@ def test_random_models_match_oracle(k):
     record(("fuzz", k, sorted(kw.items())), dtype, {"raw": worst})
     assert worst <= TOL[dtype]["raw"], (kw, worst)
     rt.close()
+
+
+def _fuzz_fp8_configs(n, seed):
+    out = []
+    for kw in _fuzz_configs(4 * n + 40, seed):
+        # the 8-bit tower needs the 64-filter generator and at least one block; its requirements are statistics
+        # (PSNR differences within 0.5 dB), which want a few thousand output samples
+        if kw["gen_filters"] == 64 and kw["gen_blocks"] >= 1 and kw["frame_height"] * kw["frame_width"] >= 600:
+            out.append(kw)
+    return out[:n]
+
+
+FUZZ8 = _fuzz_fp8_configs(int(os.environ.get("JU_FUZZ_N", "8")), seed=int(os.environ.get("JU_FUZZ_SEED", "20260411")))
+
+
+@pytest.mark.parametrize("k", range(len(FUZZ8)), ids=[f"{i}-{c['frame_height']}x{c['frame_width']}-{c['flow_arch'][:3]}" for i, c in enumerate(FUZZ8)])
+def test_random_models_on_the_fp8_tower(k):
+    """The 8-bit tower behind seeded random flow nets, geometries and activations: the three requirements of _fp8_case."""
+    cfg = M.ModelConfig(**FUZZ8[k])
+    _fp8_case(cfg, M.make_seeded_weights(cfg), M.synthetic_frames(3, cfg.frame_height, cfg.frame_width, seed=200 + k, kind="smooth"))
