@@ -265,6 +265,38 @@ def test_staging_paths_are_bit_exact():
     rt.close()
 
 
+@pytest.mark.parametrize("off_in,pad_in,off_out,pad_out", [(1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1), (3, 5, 2, 7),
+                                                            (1, 3, 3, 1)])
+def test_device_frames_at_any_byte_alignment(off_in, pad_in, off_out, pad_out):
+    """JU_LOC_DEVICE frames are read and written in place (no staging copy): the caller's base pointers and strides
+    need not be multiples of 4 -- the reference copies such frames with cudaMemcpy2D (cuda.h:310-349), which takes any
+    byte pitch.  Same bytes as the aligned frame, and not one byte written outside the rows."""
+    import torch
+    cfg = small_config()
+    h, w = cfg.frame_height, cfg.frame_width
+    wts, blob, rt = make(cfg, R.DTYPE_BF16)
+    frames = M.synthetic_frames(3, h, w, seed=9, kind="noise")
+    base = [rt.process_image(f).copy() for f in frames]
+    rt.reset()
+    dev = torch.device("cuda", 0)
+    sin, sout = w * 4 + pad_in, 4 * w * 4 + pad_out
+    for t, f in enumerate(frames):
+        buf = np.zeros(off_in + h * sin + 16, np.uint8)
+        for y in range(h):
+            buf[off_in + y * sin:off_in + y * sin + w * 4] = f[y].reshape(-1)
+        d_in = torch.from_numpy(buf).to(dev)
+        d_out = torch.full((off_out + 4 * h * sout + 16,), 0xAB, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        rt.process(rt.device_image(d_in.data_ptr() + off_in, w, h, stride=sin),
+                   rt.device_image(d_out.data_ptr() + off_out, 4 * w, 4 * h, stride=sout))
+        o = d_out.cpu().numpy()
+        rows = o[off_out:off_out + 4 * h * sout].reshape(4 * h, sout)
+        assert np.array_equal(rows[:, :4 * w * 4].reshape(4 * h, 4 * w, 4), base[t]), t
+        assert (rows[:-1, 4 * w * 4:] == 0xAB).all() and (o[:off_out] == 0xAB).all()
+        assert (o[off_out + (4 * h - 1) * sout + 4 * w * 4:] == 0xAB).all()
+    rt.close()
+
+
 def test_reset_recreate_graph_and_isolation_are_bit_exact(monkeypatch):
     cfg = small_config()
     wts, blob, rt = make(cfg, R.DTYPE_BF16)
