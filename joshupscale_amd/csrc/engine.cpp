@@ -226,7 +226,7 @@ void Engine::buildWeights(const ModelFile &model) {
 		const TensorView &b2 = model.tensor("generator/conv_trans_2/bias", {3});
 		m_TailW2 = DeviceBuffer(k2.count * 4);
 		m_TailW2.upload(k2.data, k2.count * 4);
-		m_TailB2 = DeviceBuffer(32);  // convT2 bias (3 f32) + from byte 16: the frame's channel sums
+		m_TailB2 = DeviceBuffer(48);  // convT2 bias (3 f32) + from byte 16: the frame's channel sums (3 x 64 bits)
 		m_TailB2.upload(b2.data, 12);
 		const auto frag = packTailWeights(k2.data, m_DType);
 		m_TailW2Frag = DeviceBuffer(frag.size() * 2);

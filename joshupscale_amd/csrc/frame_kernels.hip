@@ -47,10 +47,13 @@ __global__ __launch_bounds__(1024) void frame_sums_kernel(const std::uint8_t *__
 		part[2][wv] = s2;
 	}
 	__syncthreads();
+	// (a thread's and a wave's sum fit 32 bits for every frame the loader admits -- 67 M pixels / 1024 threads x 255 x 64;
+	// the frame's does not beyond 16.8 M pixels: 64 bits, stored low word first.  Until round 4 it was one 32-bit word.)
 	if (threadIdx.x < 3) {
-		unsigned t = 0;
+		unsigned long long t = 0;
 		for (int k = 0; k < 16; ++k) t += part[threadIdx.x][k];
-		sums[threadIdx.x] = t;
+		sums[2 * threadIdx.x] = static_cast<unsigned>(t);
+		sums[2 * threadIdx.x + 1] = static_cast<unsigned>(t >> 32);
 	}
 }
 

@@ -177,9 +177,12 @@ __device__ __forceinline__ float preprocessU8(unsigned v) {
 // reduction is deterministic).  sums == nullptr: feature off, b = 0.
 __device__ __forceinline__ float brightnessOf(const unsigned *__restrict__ sums, float invN) {
 	if (sums == nullptr) return 0.0f;
-	const float mb = static_cast<float>(sums[0]) * invN / 255.0f - 0.5f;
-	const float mg = static_cast<float>(sums[1]) * invN / 255.0f - 0.5f;
-	const float mr = static_cast<float>(sums[2]) * invN / 255.0f - 0.5f;
+	// (64-bit sums, low word first: frame_sums_kernel; the conversion rounds the exact integer once, as it did when
+	// the sum was one word)
+	auto sum = [&](int c) { return static_cast<float>((static_cast<unsigned long long>(sums[2 * c + 1]) << 32) | sums[2 * c]); };
+	const float mb = sum(0) * invN / 255.0f - 0.5f;
+	const float mg = sum(1) * invN / 255.0f - 0.5f;
+	const float mr = sum(2) * invN / 255.0f - 0.5f;
 	return 0.114f * mb + 0.587f * mg + 0.2989f * mr;
 }
 

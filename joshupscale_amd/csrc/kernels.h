@@ -291,8 +291,8 @@ void launchPackFrames(DType dt, const std::uint8_t *frame, std::ptrdiff_t frameS
     int padLeft, int numInputs, const unsigned *sums, hipStream_t stream);
 
 // normalize_brightness (reference models.py:772-779): exact integer sums of the B, G, R
-// bytes of the frame -> sums[0..2]; the kernels taking `sums` derive the scalar
-// brightness from them (nullptr = feature off).
+// bytes of the frame -> three 64-bit sums as (low, high) word pairs sums[0..5]; the kernels taking
+// `sums` derive the scalar brightness from them (brightnessOf; nullptr = feature off).
 void launchFrameSums(const std::uint8_t *frame, std::ptrdiff_t frameStride, int H, int W,
     unsigned *sums, hipStream_t stream);
 
