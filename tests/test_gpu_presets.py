@@ -670,7 +670,12 @@ def _crop_window(y0, x0, H, W):
     # one tile -- and channel sums of 7.5e9, which one 32-bit word does not hold (frame_sums_kernel's did not, until
     # this test)
     (5760, 5760, R.DTYPE_BF16, dict(normalize_brightness=True)),
-], ids=["bf16-33Mpx", "fp16-over-2GiB", "fp8-33Mpx", "lrelu-33Mpx", "gen128-16Mpx", "flowres-8Mpx", "brightness-33Mpx"])
+    # the temporal filter with a gate that never calls a scene cut (threshold 1): the blend is local, its statistic
+    # (1.6e9 elements into 32.32 fixed point) must not wrap or flip it
+    (5632, 5888, R.DTYPE_F16, dict(temporal_strength=0.6, temporal_threshold=1.0, temporal_norm="L2", temporal_luma=True,
+                                   temporal_limit=True)),
+], ids=["bf16-33Mpx", "fp16-over-2GiB", "fp8-33Mpx", "lrelu-33Mpx", "gen128-16Mpx", "flowres-8Mpx", "brightness-33Mpx",
+        "temporal-33Mpx"])
 def test_large_frames_agree_with_crops_of_themselves(h, w, dtype, kw):
     """No CPU restatement finishes 33 M-pixel frames, but the network is local: farther than its receptive field (flow
     auto-encoder + warp + a two-block generator: about 70 LR pixels) from a crop's inner borders, the big frame's output

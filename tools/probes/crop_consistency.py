@@ -16,7 +16,13 @@ dt = {"bf16": R.DTYPE_BF16, "fp16": R.DTYPE_F16, "fp8": R.DTYPE_FP8}[sys.argv[3]
 kw = dict(gen_blocks=2)
 for a in sys.argv[4:]:
     k, v = a.split("=")
-    kw[k] = v if not v.lstrip("-").isdigit() else int(v)
+    try:
+        kw[k] = int(v)
+    except ValueError:
+        try:
+            kw[k] = float(v)
+        except ValueError:
+            kw[k] = {"True": True, "False": False}.get(v, v)
 CROP, MARGIN = 384, 128
 big = M.ModelConfig(frame_height=H, frame_width=W, **kw)
 wts = M.make_seeded_weights(big, seed=42)
