@@ -723,3 +723,46 @@ def test_large_frames_agree_with_crops_of_themselves(h, w, dtype, kw):
             assert np.mean(d > 0) <= 0.12, (k, t, float(np.mean(d > 0)))
         rs.close()
     record(("large-frame crops", h, w, sorted(kw)), dtype, {"crops": 3, "frames": 2, "max_lsb": 1})
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_BF16, R.DTYPE_FP8])
+def test_creating_and_destroying_runtimes_leaks_nothing(dtype):
+    """The OBS plugin destroys and recreates its Runtime on every model or size change (obs_plugin/src/filter.cc:
+    createRuntime in the update callback): 24 cycles of create -> host frames -> registered device frames (hipGraphs
+    captured and replayed) -> destroy must leave the device's free memory, the process's resident set and its open
+    file descriptors where they were."""
+    import torch
+
+    def rss_mib():
+        with open("/proc/self/statm") as f:
+            return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2 ** 20
+
+    cfg = M.PRESETS["psp-quality"]
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=42))
+    h, w = cfg.frame_height, cfg.frame_width
+    frames = M.synthetic_frames(4, h, w, seed=1, kind="noise")
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(frames).to(dev)
+    d_out = torch.empty((4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+
+    def cycle():
+        rt = R.Runtime(blob, 0, dtype)
+        for f in frames[:2]:
+            rt.process_image(f)
+        ins = [rt.device_image(d_in[t].data_ptr(), w, h) for t in range(4)]
+        out = rt.device_image(d_out.data_ptr(), 4 * w, 4 * h)
+        assert sum(rt.prepare_frames(i, out) for i in ins) > 0
+        for t in range(8):
+            rt.process(ins[t % 4], out)
+        rt.close()
+
+    cycle()
+    cycle()            # (first uses: kernel modules loaded, allocator pools grown)
+    torch.cuda.synchronize()
+    free0, rss0, fds0 = torch.cuda.mem_get_info()[0], rss_mib(), len(os.listdir("/proc/self/fd"))
+    for _ in range(24):
+        cycle()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] <= 8 * 2 ** 20
+    assert rss_mib() - rss0 <= 32.0
+    assert len(os.listdir("/proc/self/fd")) - fds0 <= 2
