@@ -99,6 +99,38 @@ def test_extreme_geometries_match_oracle(arch, pad, h, w, dtype):
     rt.close()
 
 
+def _special_clip(h, w):
+    """Frames at the ends of the value range: white, black, a 0 / 255 checkerboard (the steepest gradients a u8 frame has),
+    a single white pixel, one-pixel stripes in both directions, white again (the recurrent state swings end to end)."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    f = []
+    for img in (np.full((h, w), 255), np.zeros((h, w)), ((yy + xx) & 1) * 255, (yy == h // 2) * (xx == w // 3) * 255,
+                (yy & 1) * 255, (xx & 1) * 255, np.full((h, w), 255)):
+        f.append(np.stack([img, img, img, np.full((h, w), 7)], axis=-1).astype(np.uint8))
+    f[2][..., 1] = 255 - f[2][..., 1]          # (the checkerboard's green in counter-phase)
+    return f
+
+
+@pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
+@pytest.mark.parametrize("kw", [dict(), dict(normalize_brightness=True), dict(flow_arch="resnet", flow_pad_factor=0, flow_res_blocks=2),
+                                dict(gen_activation="lrelu", gen_negative_slope=0.2, normalize_brightness=True)],
+                         ids=["default", "brightness", "flowres", "lrelu-brightness"])
+def test_frames_at_the_ends_of_the_value_range_match_oracle(kw, dtype):
+    """Saturated and maximally steep inputs through seven recurrent frames: the truncating u8 cast and its clip at both
+    ends (models.py:36-60 Postprocess), bilinear weights at exact integers (zero flow), the brightness mean at 0 and 1."""
+    cfg = small_config(frame_height=30, frame_width=48, gen_blocks=3, **kw)
+    wts, blob, rt = make(cfg, dtype)
+    sess = O.Session(wts, oracle_config(cfg))
+    clipped = 0
+    for t, f in enumerate(_special_clip(30, 48)):
+        ref = sess.run(f)
+        out = rt.process_image(f)
+        check_u8(out, ref, dtype, ("value-range", sorted(kw), t))
+        clipped += int((ref[..., :3] == 255).sum() + (ref[..., :3] == 0).sum())
+    assert clipped > 0                       # (the clip at the ends was exercised)
+    rt.close()
+
+
 # Every hyper-parameter the reference constructors are parametric in (models.py:257-263, 334-339,
 # 364-365, 449-468, 484-491) and the loader admits (csrc/model.cpp validateConfig, model_file.py):
 # generator width, flow auto-encoder depth / widths (odd and even filter lists), flow-resnet width,
