@@ -131,6 +131,38 @@ def test_frames_at_the_ends_of_the_value_range_match_oracle(kw, dtype):
     rt.close()
 
 
+@pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
+@pytest.mark.parametrize("scale", [8.0, 40.0])
+def test_large_flows_reach_across_and_beyond_the_frame(scale, dtype):
+    """The seeded flow head keeps |flow| under 4 HR pixels; a trained one does not.  Its last convolution scaled by 8 and
+    by 40: flows up to 14 and 68 HR pixels in a 120 x 192 frame, many of them pointing outside it, so the warp's
+    clamp of the sampling position (dense_image_warp.py:116-171: floor clamped to [0, size - 2], weights to [0, 1]) and
+    its far gathers carry the result.  The flow's own 16-bit error is scaled up with it, so the frames are held to the
+    oracle's within a PSNR bound, and the engine's FLOW to the oracle's relative to its size."""
+    cfg = small_config(frame_height=30, frame_width=48, gen_blocks=2)
+    wts = M.make_seeded_weights(cfg)
+    wts = dict(wts)
+    wts["flow/conv_2/kernel"] = wts["flow/conv_2/kernel"] * np.float32(scale)
+    wts["flow/conv_2/bias"] = wts["flow/conv_2/bias"] * np.float32(scale) + np.float32(scale * 0.5)
+    rt = R.Runtime(M.serialize(cfg, wts), 0, dtype)
+    sess = O.Session(wts, oracle_config(cfg))
+    oc = oracle_config(cfg)
+    far = 0.0
+    for t, f in enumerate(M.synthetic_frames(4, 30, 48, seed=21, kind="smooth")):
+        trace = {}
+        ref = sess.run(f, trace)
+        out = rt.process_image(f)
+        flow = rt.read_tensor("flow").reshape(oc.padded_height, oc.padded_width, 32)
+        far = max(far, float(np.abs(trace["flow"]).max()))
+        assert err(flow, trace["flow"])["rel_to_max"] <= (0.004 if dtype == R.DTYPE_F16 else 0.02)
+        st = u8_stats(out, ref)
+        record(("large-flow", scale, t), dtype, st)
+        # (measured: fp16 62.9-73.5 dB, bf16 55.5-64.4 dB, at most 2 LSB)
+        assert st["psnr"] >= (59.0 if dtype == R.DTYPE_F16 else 52.0) and st["max"] <= 3 and not out[..., 3].any(), (scale, t, st)
+    assert far >= scale                # (HR pixels: 14 and 68 -- the frames really were sampled far away)
+    rt.close()
+
+
 # Every hyper-parameter the reference constructors are parametric in (models.py:257-263, 334-339,
 # 364-365, 449-468, 484-491) and the loader admits (csrc/model.cpp validateConfig, model_file.py):
 # generator width, flow auto-encoder depth / widths (odd and even filter lists), flow-resnet width,
