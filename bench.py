@@ -94,6 +94,55 @@ PREROLL_FRAMES = 256
 PMC_PROFILE = "r04_pmc_per_kernel_{preset}_{dtype}.json"
 
 
+class SclkSampler:
+    """The shader clock of this rank's GPU while the pre-roll runs (amdgpu sysfs `pp_dpm_sclk`, a side thread, every
+    10 ms; stopped BEFORE the warm-up and the timed region).  The MFMA peak is quoted at 2400 MHz; under this load the
+    chip holds about 2250 (profiles/r04_clock_under_load.txt) -- `roofline.peak` stays the guide's figure, this field
+    says what the clock was.  None wherever sysfs is not readable."""
+
+    def __init__(self, device_index: int):
+        import glob
+        import threading
+        self.path, self.samples, self._stop = None, [], threading.Event()
+        try:
+            import torch
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+                if os.path.basename(os.path.realpath(os.path.dirname(f))) == bdf:
+                    self.path = f
+        except Exception:  # noqa: BLE001 -- an optional observation must never break the benchmark
+            self.path = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                for line in open(self.path):
+                    if line.rstrip().endswith("*"):
+                        self.samples.append(int(line.split(":")[1].strip().split("M")[0]))
+            except Exception:  # noqa: BLE001
+                return
+            self._stop.wait(0.01)
+
+    def __enter__(self):
+        if self.path:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.path:
+            self._thread.join(timeout=1.0)
+
+    def result(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)[len(self.samples) // 4:]       # (the first quarter: the ramp from idle)
+        return {"median": v[len(v) // 2], "min": v[0], "max": v[-1], "samples": len(self.samples),
+                "how": "amdgpu sysfs pp_dpm_sclk sampled every 10 ms during the untimed pre-roll only"}
+
+
 def cpu_baseline(blob: bytes, cfg, frames: np.ndarray, budget_s: float) -> dict:
     """The C restatement of the reference path (oracle/ju_oracle_c.c), timed on
     this box's host cores on a bounded sample of the same workload.  Threads = the CPUs the process may
@@ -189,8 +238,9 @@ def main() -> int:
         return {"replays": rt.stat("graph_replays"), "eager": rt.stat("eager_runs"),
                 "captures": rt.stat("graph_captures")}
 
-    for i in range(args.preroll):  # clock-warm, fixed, outside the contract's warm-up
-        step(i)
+    with SclkSampler(local_rank) as sclk:
+        for i in range(args.preroll):  # clock-warm, fixed, outside the contract's warm-up
+            step(i)
     for i in range(args.warmup):
         step(args.preroll + i)
     jdist.barrier()
@@ -319,6 +369,7 @@ def main() -> int:
                 "timed_region": timed_region,
                 "resident_fallbacks": int(rt.stat("fallbacks")),
                 "preroll_frames": args.preroll,
+                "sclk_mhz_during_preroll": sclk.result(),
                 "submission": {"graph_replays": rt.stat("graph_replays"), "eager_runs": rt.stat("eager_runs"),
                                "cached_graphs": rt.stat("direct_graphs"), "prepared_captures": prepared,
                                "inline_captures": rt.stat("graph_captures"),
