@@ -22,6 +22,8 @@
  *   res_block             scripts/training/models.py:193-254
  *   dense_image_warp      scripts/training/tfa/dense_image_warp.py:87-245
  *   UpscaleLayer etc.     scripts/training/keras_layers.py:12-230
+ * normalize_brightness (models.py:772-779, 802-803, 809-810) is followed; the optional temporal output filter is not
+ * (a model that has it is refused).
  * It reads the same .jupw container as the engine (own parser, shares no code
  * with joshupscale_amd/csrc/model.cpp).
  *
@@ -57,6 +59,7 @@ typedef struct {
 	int n_tensors;
 	juo_tensor t[MAX_TENSORS];
 	/* recurrent state (zero-initialised: reference cuda.h:69-72) */
+	int normalize;        /* normalize_brightness (models.py:772-779, 802-803, 809-810) */
 	float *pre_gen;       /* [4H][4W][3] */
 	float *last[8];       /* n_in-1 x [PH][PW][3] */
 	float *output_raw;    /* last output, [4H][4W][3] */
@@ -473,7 +476,8 @@ void *juo_create(const void *blob, size_t size) {
 		if (((acts >> 8) & 0xff) == 1) memcpy(&m->gen_slope, b + 124, 4);
 	}
 	m->n_tensors = (int)rd32(b + 104);
-	if (rd32(b + 40) != 0 || rd32(b + 108) != 0 || m->n_tensors > MAX_TENSORS) { /* normalize_brightness, temporal filter: unsupported */
+	m->normalize = rd32(b + 40) != 0;
+	if (rd32(b + 108) != 0 || m->n_tensors > MAX_TENSORS) { /* temporal filter: unsupported */
 		free(m->blob);
 		free(m);
 		return NULL;
@@ -530,10 +534,23 @@ int juo_run(void *hdl, const uint8_t *frame, uint8_t *out) {
 	for (size_t i = 0; i < (size_t)H * W; ++i) {
 		for (int c = 0; c < 3; ++c) cur[i * 3 + c] = (float)frame[i * 4 + c] / 255.0f - 0.5f;
 	}
+	/* normalize_brightness (models.py:772-779): the frame's luma mean, reduce_mean(cur * BGR_LUMA * 3) over all
+	 * H x W x 3 elements = the luma-weighted mean over the pixels; taken off the FLOW net's input only */
+	float bright = 0.0f;
+	if (m->normalize) {
+		static const double luma[3] = {0.114, 0.587, 0.2989};
+		double acc = 0.0;
+		for (size_t i = 0; i < (size_t)H * W; ++i) {
+			for (int c = 0; c < 3; ++c) acc += (double)cur[i * 3 + c] * luma[c];
+		}
+		bright = (float)(acc / ((double)H * W));
+	}
 	/* ZeroPadding2D (models.py:780-789) */
 	float *cur_pad = (float *)calloc((size_t)PH * PW * 3, sizeof(float));
 	for (int y = 0; y < H; ++y) {
-		memcpy(cur_pad + ((size_t)(y + pt) * PW + pl) * 3, cur + (size_t)y * W * 3, sizeof(float) * W * 3);
+		float *dst = cur_pad + ((size_t)(y + pt) * PW + pl) * 3;
+		const float *src = cur + (size_t)y * W * 3;
+		for (int i = 0; i < W * 3; ++i) dst[i] = src[i] - bright;
 	}
 	/* concat [cur_pad] + last_frames (models.py:373-375, 790) */
 	const int fc = 3 * m->n_in;
@@ -567,7 +584,7 @@ int juo_run(void *hdl, const uint8_t *frame, uint8_t *out) {
 				const float br = m->pre_gen[((size_t)(y0 + 1) * WW + x0 + 1) * 3 + c];
 				const float top = ax * (tr - tl) + tl;
 				const float bot = ax * (br - bl) + bl;
-				pre_warp[((size_t)Y * WW + X) * 3 + c] = ay * (bot - top) + top;
+				pre_warp[((size_t)Y * WW + X) * 3 + c] = ay * (bot - top) + top + bright; /* models.py:802-803 */
 			}
 		}
 	}
@@ -618,6 +635,11 @@ int juo_run(void *hdl, const uint8_t *frame, uint8_t *out) {
 	for (size_t i = 0; i < (size_t)HH * WW; ++i) {
 		for (int ch = 0; ch < 3; ++ch) out[i * 4 + ch] = (uint8_t)((m->output_raw[i * 3 + ch] + 0.5f) * 255.0f);
 		out[i * 4 + 3] = 0;
+	}
+	/* output_raw leaves the graph with the brightness taken off again (models.py:809-810) */
+	if (m->normalize) {
+#pragma omp parallel for schedule(static)
+		for (long i = 0; i < (long)n; ++i) m->output_raw[i] -= bright;
 	}
 	/* state update (models.py:821-823) */
 	memcpy(m->pre_gen, m->output_raw, sizeof(float) * n);

@@ -766,3 +766,52 @@ def test_creating_and_destroying_runtimes_leaks_nothing(dtype):
     assert free0 - torch.cuda.mem_get_info()[0] <= 8 * 2 ** 20
     assert rss_mib() - rss0 <= 32.0
     assert len(os.listdir("/proc/self/fd")) - fds0 <= 2
+
+
+def _mid_fuzz(n, seed):
+    """Seeded random mid-size models (the sizes where the one-launch tower has several rows of regions, the flow blocks
+    take their tall tiles and the coarse levels their split-K kernels): against the C restatement."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        arch = "autoencoder" if rng.random() < 0.7 else "resnet"
+        kw = dict(frame_height=int(rng.integers(64, 300)), frame_width=int(rng.integers(64, 520)),
+                  gen_filters=int(rng.choice([64, 64, 64, 32, 128])), gen_blocks=int(rng.integers(1, 7)),
+                  num_flow_inputs=int(rng.integers(1, 5)), normalize_brightness=bool(rng.random() < 0.25), flow_arch=arch)
+        if arch == "autoencoder":
+            if rng.random() < 0.5:
+                kw["flow_filters"] = tuple(int(x) for x in rng.choice([32, 64, 128], size=int(rng.choice([3, 5, 7]))))
+            kw["flow_pad_factor"] = int(rng.choice([8, 8, 16]))
+        else:
+            kw.update(flow_pad_factor=int(rng.choice([0, 8])), flow_res_filters=int(rng.choice([64, 64, 32])),
+                      flow_res_blocks=int(rng.integers(0, 3)))
+        if rng.random() < 0.3:
+            kw.update(gen_activation="lrelu", gen_negative_slope=0.2)
+        if rng.random() < 0.3:
+            kw.update(flow_activation="lrelu", flow_negative_slope=0.1)
+        try:
+            M.validate_config(M.ModelConfig(**kw))
+        except ValueError:
+            continue
+        out.append(kw)
+    return out
+
+
+MID_FUZZ = _mid_fuzz(int(os.environ.get("JU_FUZZ_N", "6")), seed=int(os.environ.get("JU_FUZZ_SEED", "20260412")))
+
+
+@pytest.mark.parametrize("k", range(len(MID_FUZZ)), ids=[f"{i}-{c['frame_height']}x{c['frame_width']}-{c['flow_arch'][:3]}-g{c['gen_filters']}"
+                                                        for i, c in enumerate(MID_FUZZ)])
+def test_random_mid_size_models_against_the_c_restatement(k):
+    from oracle.c_binding import CSession
+    kw = MID_FUZZ[k]
+    dtype = R.DTYPE_BF16 if k % 2 else R.DTYPE_F16
+    cfg = M.ModelConfig(**kw)
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg, seed=300 + k))
+    h, w = cfg.frame_height, cfg.frame_width
+    cs = CSession(blob, h, w)
+    rt = R.Runtime(blob, 0, dtype)
+    kind = "smooth" if k % 3 else "noise"
+    for t, f in enumerate(M.synthetic_frames(3, h, w, seed=400 + k, kind=kind)):
+        check_u8(rt.process_image(f), cs.run(f), dtype, ("mid-fuzz", k, t), clip=kind)
+    rt.close()

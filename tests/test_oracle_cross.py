@@ -84,7 +84,9 @@ def test_numpy_oracle_vs_torch_restatement_8bit_tower():
 
 
 @pytest.mark.parametrize("arch,pad,extra", [("autoencoder", 8, {}), ("resnet", 0, {}),
-                                            ("autoencoder", 8, LRELU), ("resnet", 0, LRELU)])
+                                            ("autoencoder", 8, LRELU), ("resnet", 0, LRELU),
+                                            ("autoencoder", 8, dict(normalize_brightness=True)),
+                                            ("resnet", 0, dict(normalize_brightness=True, num_flow_inputs=2))])
 def test_c_restatement_vs_numpy_oracle(arch, pad, extra):
     from oracle.c_binding import CSession
     cfg = small_config(flow_arch=arch, flow_pad_factor=pad, flow_res_blocks=2, **extra)
