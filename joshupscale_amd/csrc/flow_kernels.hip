@@ -526,29 +526,62 @@ void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
 	hipCheckLaunch("flow_block");
 }
 
-// Tile height: the tall tile (18 rows: 11 % recompute ring) when the launch then still
-// fills the chip, the short one (6 rows) for small tensors.
-constexpr int kFbTall = 18, kFbMid = 14, kFbShort = 6;
+// Tile height.  A tile costs its fixed part (weights, staging ramp, the recompute ring's two rows) plus its rows, and a
+// launch costs as many of those in series as it has rounds over the CUs (one workgroup per CU by LDS size): the tall
+// tile (18 rows: 11 % ring) wins where the launch still fills the chip, the short one (6 rows) on small tensors, and in
+// between the height that makes the LAST round full -- 640 x 448: 22 x 25 tiles of 18 rows are three rounds on 256 CUs,
+// 22 x 23 of 20 rows are two (measured: profiles/r04_flow_tile_heights.txt).  The bytes do not depend on the choice: an
+// output pixel's terms are added in the same order whatever tile it falls into.  JU_FLOW_TILE=<rows> forces a height
+// (developer switch, for that measurement).
+constexpr int kFbMid = 14;
+constexpr int kFbFixedRows = 8;  // the fixed part of a tile in units of one row's work (fitted to the measurement above)
+
+inline long fbLaunchCost(int H, long tilesX, int TH, int numCUs) {
+	const long tiles = tilesX * ((H + TH - 1) / TH);
+	return (tiles + numCUs - 1) / numCUs * (TH + kFbFixedRows);
+}
+
+inline int fbForcedTile() {
+	static const int forced = [] { const char *e = std::getenv("JU_FLOW_TILE"); return e ? std::atoi(e) : 0; }();
+	return forced;
+}
+
+template <typename T, int CIN, int CMID, bool UPS, bool POOL, int OUTK, bool PACK, int... THS>
+void launchFlowBlockBest(const FlowBlockParams &p, int numCUs, hipStream_t stream) {
+	const long tilesX = (p.W + kFbOutW - 1) / kFbOutW;
+	int best = 0;
+	long bestCost = 0;
+	auto consider = [&](int TH, bool fits) {
+		if (!fits) return;
+		const long c = fbForcedTile() == TH ? -1 : fbLaunchCost(p.H, tilesX, TH, numCUs);
+		if (best == 0 || c < bestCost) {
+			best = TH;
+			bestCost = c;
+		}
+	};
+	(consider(THS, FbGeom<CIN, CMID, THS, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS), ...);
+	bool done = false;
+	auto launch = [&](auto thTag) {
+		constexpr int TH = decltype(thTag)::value;
+		if constexpr (FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS) {
+			if (!done && best == TH) {
+				launchFlowBlockInst<T, CIN, CMID, TH, UPS, POOL, OUTK, PACK>(p, stream);
+				done = true;
+			}
+		}
+	};
+	(launch(std::integral_constant<int, THS>{}), ...);
+	if (!done) throw std::logic_error("flow block: no tile height fits");
+}
 
 template <typename T, int CIN, int CMID, bool UPS, bool POOL, int OUTK, bool PACK = false>
 void launchFlowBlockT(const FlowBlockParams &p, int numCUs, hipStream_t stream) {
-	const long tilesX = (p.W + kFbOutW - 1) / kFbOutW;
-	if constexpr (PACK) {
-		if (tilesX * ((p.H + kFbTall - 1) / kFbTall) * 10 >= 7L * numCUs) {
-			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTK, true>(p, stream);
-		}
-		return launchFlowBlockInst<T, CIN, CMID, kFbShort, UPS, POOL, OUTK, true>(p, stream);
-	} else if constexpr (FbGeom<CIN, CMID, kFbTall, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS) {
-		if (tilesX * ((p.H + kFbTall - 1) / kFbTall) * 10 >= 7L * numCUs) {
-			return launchFlowBlockInst<T, CIN, CMID, kFbTall, UPS, POOL, OUTK>(p, stream);
-		}
-	} else if constexpr (FbGeom<CIN, CMID, kFbMid, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS && OUTK == 2) {
-		// (64 -> 64 -> 64: two 128-byte tiles; 14 rows is what fits)
-		if (tilesX * ((p.H + kFbMid - 1) / kFbMid) * 10 >= 7L * numCUs) {
-			return launchFlowBlockInst<T, CIN, CMID, kFbMid, UPS, POOL, OUTK>(p, stream);
-		}
+	if constexpr (OUTK == 2) {
+		// (64 -> 64 -> 64 residual block, JU_RES_BLOCK=tile only: two 128-byte tiles; 14 rows is what fits)
+		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, kFbMid, 6>(p, numCUs, stream);
+	} else {
+		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 20, 18, 10, 6>(p, numCUs, stream);
 	}
-	launchFlowBlockInst<T, CIN, CMID, kFbShort, UPS, POOL, OUTK>(p, stream);
 }
 
 template <typename T>
