@@ -58,6 +58,8 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
     assert res["warmup"] == 5 and res["preroll"] == 256 and res["untimed_frames"] == 261
     clk = res["config"]["sclk_mhz_during_preroll"]      # (what the clock was: sysfs, sampled outside the timed region)
     assert clk is None or (500 <= clk["min"] <= clk["median"] <= clk["max"] <= 2500 and clk["samples"] >= 1)
+    if clk:
+        assert res["roofline"]["frac"] <= res["roofline"]["frac_at_measured_clock"] <= 1.0
     rf = res["roofline"]
     assert 0.0 < rf["frac"] <= 1.0 and 0.0 < rf["frac_back_to_back"] <= 1.0 and rf["launches_per_frame"] == 1
     assert rf["traffic"] is None or (rf["traffic"] > 1e6 and "profiles/" in rf["traffic_source"])
