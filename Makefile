@@ -13,7 +13,13 @@ SRCS_CPP   := model.cpp engine.cpp c_api.cpp core_api.cpp log.cpp comm.cpp graph
 SRCS_HIP   := conv_kernels.hip tower_kernels.hip frame_kernels.hip fp8_kernels.hip flow_kernels.hip res_block_kernels.hip splitk_kernels.hip tower8_kernels.hip
 OBJS       := $(addprefix $(OBJ)/,$(SRCS_CPP:.cpp=.o)) $(addprefix $(OBJ)/,$(SRCS_HIP:.hip=.o))
 
-all: $(OUT)/libJoshUpscale.so
+# Two libraries from the same objects: the product (exactly the C ABI of include/joshupscale_amd.h + the C++ plugin
+# surface of include/JoshUpscale/core.h) and its test flavour, in which c_api.cpp and graphics.cpp are compiled with
+# -DJU_TEST_HOOKS and additionally export include/joshupscale_amd_test.h (ju_debug_*, ju_read_tensor, ju_time_steps).
+HOOK_CPP   := c_api.cpp graphics.cpp
+OBJS_TEST  := $(filter-out $(addprefix $(OBJ)/,$(HOOK_CPP:.cpp=.o)),$(OBJS)) $(addprefix $(OBJ)/,$(HOOK_CPP:.cpp=_hooks.o))
+
+all: $(OUT)/libJoshUpscale.so $(OUT)/libJoshUpscale_test.so
 
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs.  The epilogues
 # consume every accumulator with VALU ops; in AGPR form each value first costs a
@@ -27,9 +33,17 @@ $(OBJ)/%.o: $(CSRC)/%.cpp Makefile $(wildcard $(CSRC)/*.h) include/joshupscale_a
 	@mkdir -p $(OBJ)
 	$(HIPCC) -x hip $(HIPFLAGS) -c $< -o $@
 
+$(OBJ)/%_hooks.o: $(CSRC)/%.cpp Makefile $(wildcard $(CSRC)/*.h) include/joshupscale_amd.h include/joshupscale_amd_test.h include/JoshUpscale/core.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) -x hip $(HIPFLAGS) -DJU_TEST_HOOKS -c $< -o $@
+
 $(OUT)/libJoshUpscale.so: $(OBJS)
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -Wl,--exclude-libs,ALL -ldl
+
+$(OUT)/libJoshUpscale_test.so: $(OBJS_TEST)
+	@mkdir -p $(OUT)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS_TEST) -Wl,--exclude-libs,ALL -ldl
 
 harness: $(OUT)/libJoshUpscale.so tools/plugin_harness.cpp
 	g++ -O2 -std=c++17 -Iinclude tools/plugin_harness.cpp -o build/plugin_harness \

@@ -91,7 +91,9 @@ PREROLL_FRAMES = 256
 # PMC summaries (tools/pmc_all.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, bytes = (2 x FETCH_SIZE +
 # WRITE_SIZE) x 1024, the gfx950 correction of MI355X_MICROARCH.md) per (preset, dtype), committed under profiles/;
 # bench.py cannot run rocprofv3 around itself, so `roofline.traffic` quotes the committed figure of the SAME kernel
-PMC_PROFILE = "r04_pmc_per_kernel_{preset}_{dtype}.json"
+# -- only while the summary was collected on the kernel source that is being measured (joshupscale_amd/provenance.py:
+# the collector stores a digest of the kernel's .hip + headers; a figure with another digest, or none, is dropped)
+PMC_PROFILE = "r05_pmc_per_kernel_{preset}_{dtype}.json"
 
 
 class SclkSampler:
@@ -209,7 +211,10 @@ def main() -> int:
     blob = jdist.broadcast_model(blob, device)
     broadcast_s = time.perf_counter() - t_b
     dt = {"bf16": R.DTYPE_BF16, "fp16": R.DTYPE_F16, "fp8": R.DTYPE_FP8}[args.dtype]
-    rt = R.Runtime(blob, device=local_rank, dtype=dt)
+    # The frames are timed through the PRODUCT library (libJoshUpscale.so: no test hooks); the per-kernel times of
+    # the roofline come afterwards from a second runtime of its test flavour (libJoshUpscale_test.so: the same
+    # objects + ju_time_steps).  JU_LIBRARY (A/B of developer builds) replaces both.
+    rt = R.Runtime(blob, device=local_rank, dtype=dt, hooks=False)
 
     h, w = cfg.frame_height, cfg.frame_width
     clip = M.synthetic_frames(16, h, w, seed=1234 + rank, kind="noise")
@@ -289,6 +294,14 @@ def main() -> int:
         # dominant kernel: the 3x3 64->64 convolution of the residual tower,
         # timed with HIP events on the engine's own stream
         fp8 = args.dtype == "fp8"
+        # product-side facts first: the measuring runtime below shares the device with `rt` (two resident towers of
+        # different libraries must not run at once: `rt` is idle from here on)
+        product = {"fallbacks": int(rt.stat("fallbacks")), "graph_replays": rt.stat("graph_replays"),
+                   "eager_runs": rt.stat("eager_runs"), "direct_graphs": rt.stat("direct_graphs"),
+                   "graph_captures": rt.stat("graph_captures"), "resident_tower": rt.stat("resident_tower"),
+                   "library": os.path.basename(R.library_path(False))}
+        rt.synchronize()
+        rt_timed, rt = rt, R.Runtime(blob, device=local_rank, dtype=dt, hooks=True)
         # (timed inside whole frames: the kernel in the clock / cache context of the workload --
         # what `rocprofv3 --kernel-trace --stats` of this command averages; the back-to-back
         # figure of the launches alone is reported beside it)
@@ -302,11 +315,27 @@ def main() -> int:
             # the one-launch 8-bit tower: MFMA-bound by arithmetic, priced against the block-scaled e4m3 peak
             peak = PEAK_FP8_TFLOPS
         elif fp8 and launches == 1 + cfg.gen_blocks:
-            # one launch per residual block (more regions than CUs): step 0 is the quantise kernel
+            # one launch per residual block (more regions than CUs): step 0 is the quantise kernel.  The block kernel
+            # is HBM-bound: 2 x 9.55 GFLOP x (H W / 129600) against the fp16 stream in and out + the e4m3 copy in and
+            # out = 384 B per pixel (+ 72 KB of weights): 335 FLOP/B at 640x448, below the 625 FLOP/B ridge of
+            # 5 PFLOP/s over 8 TB/s (round 4 mislabelled it MFMA-bound).  The MFMA fraction is reported beside it.
             ms, _, fl1 = rt.time_steps("tower#1@frame", args.roofline_iters)
             launches, flops_per_launch = cfg.gen_blocks, fl1
             achieved = fl1 / (ms * 1e-3) / 1e12
             peak = PEAK_FP8_TFLOPS
+            bytes_blk = h * w * (128 + 128 + 64 + 64) + 2 * 9 * 64 * 64
+            fp8_roofline = {
+                "kernel": "res_block_fp8_kernel: one residual block (two 3x3 64->64 e4m3 convs) per launch; fp16 stream "
+                          "and e4m3 copy in and out",
+                "bound": "hbm", "achieved": bytes_blk / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": bytes_blk / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                "launch_ms": ms, "launches_per_frame": cfg.gen_blocks, "bytes_per_launch": bytes_blk,
+                "flop_per_byte": fl1 / bytes_blk, "ridge_flop_per_byte": PEAK_FP8_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9),
+                "launch_ms_how": "HIP events around the kernel's launches inside whole frames on the engine's stream "
+                                 "(ju_time_steps tag@frame), mean over %d frames" % args.roofline_iters,
+                "mfma": {"achieved": achieved, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP8_TFLOPS,
+                         "flops_per_launch": fl1},
+            }
         elif fp8:
             # 8-bit tower: step 0 of the stage is the quantise kernel, then per block the first
             # convolution (e4m3 in, e4m3 out: MFMA-bound by arithmetic) and the second (+ the
@@ -341,13 +370,25 @@ def main() -> int:
         else:
             pmc_kernel = "tower_resident_kernel" if launches == 1 else "res_block_pipe_kernel"
         if os.path.exists(tpath):
+            from joshupscale_amd.provenance import kernel_source_digest
             with open(tpath) as f:
-                traffic = json.load(f).get(pmc_kernel, {}).get("hbm_bytes_per_launch")
-            if traffic is not None:
+                entry = json.load(f).get(pmc_kernel, {})
+            traffic = entry.get("hbm_bytes_per_launch")
+            now = kernel_source_digest(pmc_kernel)
+            if traffic is not None and (now is None or entry.get("source_sha256") != now):
+                traffic_source = (f"profiles/{pmc_name} was collected on another version of {pmc_kernel}'s source "
+                                  f"(digest {str(entry.get('source_sha256'))[:12]} there, {str(now)[:12]} now): its byte count is "
+                                  "not quoted; re-run tools/pmc_all.sh")
+                traffic = None
+            elif traffic is not None:
                 traffic_source = (f"committed profile profiles/{pmc_name}, kernel {pmc_kernel} (rocprofv3 --pmc passes of "
-                                  "this command line, collected separately; NOT measured by this run)")
+                                  f"this command line on this kernel source, digest {now[:12]}, collected separately; NOT "
+                                  "measured by this run)")
         if fp8_roofline:
             fp8_roofline["traffic"], fp8_roofline["traffic_source"] = traffic, traffic_source
+            fp8_roofline["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)"
+            if traffic and fp8_roofline.get("launch_ms"):
+                fp8_roofline["frac_of_counted_traffic"] = traffic / (fp8_roofline["launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
         result = {
             "metric": "frames/sec 480x270->1920x1080 recurrent SR" if args.preset.startswith("psp")
                       else f"frames/sec {w}x{h}->{4 * w}x{4 * h} recurrent SR",
@@ -366,17 +407,18 @@ def main() -> int:
                 "per_rank_fps": {"values": rank_fps, "min": min(rank_fps), "max": max(rank_fps)},
                 "affinity": AFFINITY,
                 "boundary": "ju_process (synchronous processImage)",
+                "library": {"timed": product["library"], "kernel_times": os.path.basename(R.library_path(True))},
                 "timed_region": timed_region,
-                "resident_fallbacks": int(rt.stat("fallbacks")),
+                "resident_fallbacks": product["fallbacks"],
                 "preroll_frames": args.preroll,
                 "sclk_mhz_during_preroll": sclk.result(),
-                "submission": {"graph_replays": rt.stat("graph_replays"), "eager_runs": rt.stat("eager_runs"),
-                               "cached_graphs": rt.stat("direct_graphs"), "prepared_captures": prepared,
-                               "inline_captures": rt.stat("graph_captures"),
+                "submission": {"graph_replays": product["graph_replays"], "eager_runs": product["eager_runs"],
+                               "cached_graphs": product["direct_graphs"], "prepared_captures": prepared,
+                               "inline_captures": product["graph_captures"],
                                "how": "one hipGraph per (input, output, binding set) tuple of device frames, "
                                       "captured in set-up by ju_prepare_frames (unregistered pairs: at the "
                                       "tuple's second use), replayed afterwards"},
-                "tower": "resident (one launch)" if rt.stat("resident_tower") else "per-layer launches",
+                "tower": "resident (one launch)" if product["resident_tower"] else "per-layer launches",
                 "latency_ms": {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
                                "max": lat[-1], "frames": len(lat)},
                 "gflop_per_frame": total_flops / 1e9,
@@ -410,13 +452,16 @@ def main() -> int:
                 "activation scales, fp16 residual stream; the gfx950 counterpart of the reference's TensorRT INT8 "
                 "engines, not a restatement of them -- parity is against the oracle's restatement of THIS scheme")
         clk = result["config"]["sclk_mhz_during_preroll"]
-        if clk and clk["median"] > 0:
+        if clk and clk["median"] > 0 and result["roofline"].get("bound") == "mfma":
             # `peak` is the guide's figure, quoted at 2400 MHz; the chip held `median` MHz under this load (power): the
-            # same achieved rate against the peak AT THAT CLOCK, beside `frac`, never instead of it
+            # same achieved rate against the peak AT THAT CLOCK, beside `frac`, never instead of it (an HBM-bound
+            # kernel's fraction does not scale with the shader clock: not emitted there)
             result["roofline"]["frac_at_measured_clock"] = result["roofline"]["frac"] * 2400.0 / clk["median"]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(blob, cfg, clip, args.cpu_seconds)
         print(json.dumps(result), flush=True)
+        rt.close()
+        rt = rt_timed
     jdist.barrier()
     rt.close()
     if torch.distributed.is_initialized():

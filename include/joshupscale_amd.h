@@ -152,13 +152,6 @@ JU_API int ju_get_gl_device_index(int *out_device);
 JU_API int ju_get_gl_image(uint32_t gl_texture, int type, ju_image *out_image);
 JU_API void ju_release_gl_image(ju_image *image);
 
-/* Test double for the graphics path (no GL context exists on a headless GPU box): texture
- * ids defined here resolve to pitched device buffers; device_ptr NULL removes the double
- * again.  Counters: resources registered / currently mapped / map and unmap calls. */
-JU_API int ju_debug_fake_gl_texture(uint32_t gl_texture, void *device_ptr, size_t pitch, size_t width,
-    size_t height, int bytes_per_pixel);
-JU_API void ju_debug_fake_gl_counters(int *registered, int *mapped, int *maps, int *unmaps);
-
 /* ---- multi-GPU start-up (BASELINE.json config 4; no reference counterpart: the reference
  * has no distributed code).  N GPUs = N independent streams, one process per GPU; the ONLY
  * collective is the broadcast of the model container from rank 0, so that one rank reads
@@ -177,31 +170,13 @@ JU_API int ju_comm_allreduce_max(ju_comm *comm, double *value);
 JU_API int ju_comm_count(const ju_comm *comm, int *count);
 JU_API void ju_comm_destroy(ju_comm *comm);
 
-/* ---- introspection (tests and bench.py; no reference counterpart) ---------- */
+/* ---- introspection (no reference counterpart).  The test and measurement hooks (ju_debug_*,
+ * ju_read_tensor, ju_time_steps) are NOT part of this library: they are declared in
+ * joshupscale_amd_test.h and exported only by libJoshUpscale_test.so (built with -DJU_TEST_HOOKS);
+ * the reference exports nothing but its JOSHUPSCALE_EXPORT symbols (core/CMakeLists.txt:29-36). -- */
 
 /* Compute dtype actually in use (JU_DTYPE_F16 / JU_DTYPE_BF16 / JU_DTYPE_FP8). */
 JU_API int ju_get_dtype(const ju_runtime *runtime);
-
-/* Copies a named internal tensor to host memory as float32.  *count receives the
- * element count; dst may be NULL to query it.  Names: "state" (last output_raw,
- * f16 [4H][4W][4]), "flow" (f16 [PH][PW][32], the flow head before depth-to-space), "flow_in", "gen_in", "trunk",
- * "tail_y", and the per-layer flow activations. */
-JU_API int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, size_t capacity,
-    size_t *count);
-
-/* Average device time in milliseconds of ONE kernel launch among the per-frame
- * steps tagged `tag` ("tower" = the 3x3 64->64 convolutions of the generator's
- * residual blocks, "flow", "warp", "gen_head", "tail", "pack", "" = all),
- * measured with HIP events on the runtime's own stream over `iters`
- * repetitions.  *launches = kernel launches per repetition, *flops = their
- * algorithmic FLOPs (2*MAC) per repetition.  "tag#k": only the k-th launch of the tag.
- * "tag@frame" (also "tag#k@frame"): the tagged launches timed INSIDE whole frames -- every step
- * of the frame runs, HIP events bracket the tagged launches -- i.e. the kernel in the clock and
- * cache context of the real workload (what a kernel trace of the benchmark averages).  Timing
- * overwrites scratch tensors and the recurrent state: the state is reset (as by ju_reset)
- * before the call returns. */
-JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_per_launch,
-    int *launches, double *flops);
 
 /* How the runtime has been executing: "graph_replays" / "eager_runs" (per-frame programs
  * submitted as one hipGraph replay / as individual launches so far), "graph_captures"
@@ -210,17 +185,6 @@ JU_API int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double
  * (graphs cached for JU_LOC_DEVICE frame tuples), "resident_tower" / "resident_flow"
  * (1 when the one-launch tower kernel is in use), "launches_per_frame", "tower_variant". */
 JU_API int ju_get_stat(const ju_runtime *runtime, const char *key, double *value);
-
-/* Developer switches (timing ablations and fault injection; never needed by a
- * caller).  Keys: "tower_variant" (0 = product kernel, 4 = phase profile, 5 = per-layer
- * output maxima for quantisation calibration, 8 = the resident tower's plain schedule:
- * same bytes, tests compare it with the product's); "resident_fault" n
- * (launch the resident tower n workgroups short: tests the fallback). */
-JU_API int ju_debug_set(const char *key, int value);
-
-/* The loader's e4m3 quantiser (round to nearest even, saturating at +-448), exposed so
- * that the CPU tests can pin it against the oracle's restatement.  No device needed. */
-JU_API int ju_debug_e4m3(const float *values, unsigned char *codes, size_t count);
 
 /* Library version string, e.g. "joshupscale-amd 0.1 (gfx950)". */
 JU_API const char *ju_version(void);

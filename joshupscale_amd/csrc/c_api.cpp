@@ -3,6 +3,9 @@
 // kept per thread for ju_last_error().
 
 #include "joshupscale_amd.h"
+#ifdef JU_TEST_HOOKS  // libJoshUpscale_test.so only (Makefile): the product library exports none of the hooks
+#include "joshupscale_amd_test.h"
+#endif
 
 #include <cstdio>
 #include <fstream>
@@ -215,6 +218,7 @@ void ju_release_gl_image(ju_image *image) {
 	image->ptr = nullptr;
 }
 
+#ifdef JU_TEST_HOOKS
 int ju_debug_fake_gl_texture(uint32_t gl_texture, void *device_ptr, size_t pitch, size_t width, size_t height,
     int bytes_per_pixel) {
 	return guarded([&] {
@@ -229,12 +233,14 @@ int ju_debug_fake_gl_texture(uint32_t gl_texture, void *device_ptr, size_t pitch
 void ju_debug_fake_gl_counters(int *registered, int *mapped, int *maps, int *unmaps) {
 	ju::fakeGraphicsCounters(registered, mapped, maps, unmaps);
 }
+#endif  // JU_TEST_HOOKS
 
 int ju_get_dtype(const ju_runtime *runtime) {
 	if (runtime == nullptr || !runtime->engine) return -1;
 	return runtime->engine->reportedDtype();
 }
 
+#ifdef JU_TEST_HOOKS
 int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, size_t capacity,
     size_t *count) {
 	return guarded([&] {
@@ -254,6 +260,7 @@ int ju_time_steps(ju_runtime *runtime, const char *tag, int iters, double *ms_pe
 		if (flops) *flops = e.flopsOf(t);
 	});
 }
+#endif  // JU_TEST_HOOKS
 
 int ju_get_stat(const ju_runtime *runtime, const char *key, double *value) {
 	return guarded([&] {
@@ -262,6 +269,7 @@ int ju_get_stat(const ju_runtime *runtime, const char *key, double *value) {
 	});
 }
 
+#ifdef JU_TEST_HOOKS
 int ju_debug_set(const char *key, int value) {
 	return guarded([&] {
 		const std::string k = key ? key : "";
@@ -280,9 +288,14 @@ int ju_debug_e4m3(const float *values, unsigned char *codes, size_t count) {
 		for (size_t i = 0; i < count; ++i) codes[i] = ju::e4m3FromFloat(values[i]);
 	});
 }
+#endif  // JU_TEST_HOOKS
 
 const char *ju_version(void) {
+	#ifdef JU_TEST_HOOKS
+	return "joshupscale-amd 0.1 (gfx950, test hooks)";
+#else
 	return "joshupscale-amd 0.1 (gfx950)";
+#endif
 }
 
 }  // extern "C"

@@ -61,9 +61,10 @@ const Rccl &rccl() {
 		r.allReduce = reinterpret_cast<decltype(r.allReduce)>(sym("ncclAllReduce"));
 		r.commCount = reinterpret_cast<decltype(r.commCount)>(sym("ncclCommCount"));
 		r.commDestroy = reinterpret_cast<decltype(r.commDestroy)>(sym("ncclCommDestroy"));
-		// optional: an RCCL without it tears a failed communicator down with ncclCommDestroy
+		// optional.  An RCCL without it has no way to tear down a communicator whose peers may be stuck in a
+		// collective (ncclCommDestroy may wait for outstanding operations): the failure path then LEAKS the
+		// communicator and throws, so that this rank exits non-zero and the launcher kills the job (advisor, round 4)
 		r.commAbort = reinterpret_cast<decltype(r.commAbort)>(dlsym(r.lib, "ncclCommAbort"));
-		if (r.commAbort == nullptr) r.commAbort = r.commDestroy;
 		r.errorString = reinterpret_cast<decltype(r.errorString)>(sym("ncclGetErrorString"));
 	});
 	if (!failure.empty()) throw std::runtime_error(failure);
@@ -162,7 +163,7 @@ int ju_comm_broadcast(ju_comm *comm, void *bytes, size_t size, int root) {
 				JU_HIP(hipStreamSynchronize(comm->stream));
 			}
 		} catch (...) {
-			(void)ju::rccl().commAbort(comm->comm);
+			if (ju::rccl().commAbort) (void)ju::rccl().commAbort(comm->comm);  // (absent: leaked, see rccl())
 			comm->comm = nullptr;
 			throw;
 		}
@@ -196,7 +197,7 @@ int ju_comm_allreduce_max(ju_comm *comm, double *value) {
 		try {
 			dev = ju::DeviceBuffer(sizeof(double));
 		} catch (...) {  // (peers must not wait for this rank for ever)
-			(void)ju::rccl().commAbort(comm->comm);
+			if (ju::rccl().commAbort) (void)ju::rccl().commAbort(comm->comm);  // (absent: leaked, see rccl())
 			comm->comm = nullptr;
 			throw;
 		}

@@ -58,7 +58,7 @@ constexpr int kF8Lds = 2 * kF8TileBytes + 4 * kF8Slice;  // 77824: two workgroup
 #endif
 #if defined(JU_FP8_MUBUF_LD) || defined(JU_FP8_MUBUF_ST)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t probeBuffer(const void *base) {
-	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffff0, 0x00020000);
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffc00000u, 0x00020000);  // (the loaders admit tensors up to 0xFFC00000 bytes: model.cpp)
 }
 #endif
 __device__ __forceinline__ void dmaToLds16(const unsigned char *base, unsigned uniformOff, unsigned laneOff,
@@ -493,7 +493,8 @@ __global__ __launch_bounds__(DUO ? 256 : 512, 2) void res_block_fp8_kernel(Fp8Bl
 			const int c = (lane & 3) ^ ((k >> 2) & 3);
 			const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
 			if (q < NREC && inside) {
-				dmaToLds16(p.in8, 0u, static_cast<unsigned>(((gy + 1) * p.pitch + gx + 1) * 64 + c * 16), smX + i * 1024);
+				dmaToLds16(p.in8, 0u, (static_cast<unsigned>(gy + 1) * static_cast<unsigned>(p.pitch) + static_cast<unsigned>(gx + 1)) * 64u + static_cast<unsigned>(c) * 16u,
+				    smX + i * 1024);  // (unsigned arithmetic: tensors of 2-4 GiB wrap by definition, not by signed overflow)
 			} else if (border && q < NREC) {
 				*reinterpret_cast<i32x4 *>(smX + i * 1024 + lane * 16) = i32x4{0, 0, 0, 0};
 			}
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(DUO ? 256 : 512, 2) void res_block_fp8_kernel(Fp8Bl
 					const int pi = i * 16 + (lane >> 2);
 					const int gy = min(y0 + 2 * pair + (pi >> 5), p.H - 1), gx = min(x0 + (pi & 31), p.W - 1);
 					const unsigned c = static_cast<unsigned>(lane & 3) ^ ((static_cast<unsigned>(pi) >> 2) & 3u);
-					dmaToLds16(src, 0u, static_cast<unsigned>((((gy + 1) * p.pitch + gx + 1) * 64 + cb * 32) * 2 + c * 16),
+					dmaToLds16(src, 0u, ((static_cast<unsigned>(gy + 1) * static_cast<unsigned>(p.pitch) + static_cast<unsigned>(gx + 1)) * 64u + static_cast<unsigned>(cb) * 32u) * 2u + c * 16u,
 					    stage + i * 1024);
 				}
 			}

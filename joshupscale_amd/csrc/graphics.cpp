@@ -106,6 +106,7 @@ public:
 	}
 };
 
+#ifdef JU_TEST_HOOKS  // libJoshUpscale_test.so only: the product library carries no test double
 // ---------------------------------------------------------------------------
 // test double: a "texture" is a pitched device buffer the test owns
 // ---------------------------------------------------------------------------
@@ -175,19 +176,25 @@ public:
 		return dev;
 	}
 };
+#endif  // JU_TEST_HOOKS
 
+#ifdef JU_TEST_HOOKS
 std::mutex g_Mutex;
 FakeBackend *g_Fake = nullptr;
+#endif
 
 }  // namespace
 
 GraphicsBackend &graphicsBackend() {
+#ifdef JU_TEST_HOOKS
 	std::lock_guard<std::mutex> lock(g_Mutex);
 	if (g_Fake) return *g_Fake;
+#endif
 	static HipGlBackend real;
 	return real;
 }
 
+#ifdef JU_TEST_HOOKS
 void fakeGraphicsDefineTexture(std::uint32_t texture, void *devicePtr, std::size_t pitch, std::size_t width,
     std::size_t height, int bytesPerPixel) {
 	std::lock_guard<std::mutex> lock(g_Mutex);
@@ -208,5 +215,6 @@ void fakeGraphicsCounters(int *registered, int *mapped, int *maps, int *unmaps) 
 	if (maps) *maps = g_Fake ? g_Fake->maps : 0;
 	if (unmaps) *unmaps = g_Fake ? g_Fake->unmaps : 0;
 }
+#endif  // JU_TEST_HOOKS
 
 }  // namespace ju

@@ -52,10 +52,12 @@ struct GraphicsHandle {
 // The HIP-GL backend, or the test double once one is installed.
 GraphicsBackend &graphicsBackend();
 
-// ---- test double (ju_debug_fake_gl_*): "textures" are pitched device buffers ----
+#ifdef JU_TEST_HOOKS
+// ---- test double (ju_debug_fake_gl_*, libJoshUpscale_test.so only): "textures" are pitched device buffers ----
 void fakeGraphicsDefineTexture(std::uint32_t texture, void *devicePtr, std::size_t pitch, std::size_t width,
     std::size_t height, int bytesPerPixel);
 void fakeGraphicsReset();  // back to the HIP-GL backend
 void fakeGraphicsCounters(int *registered, int *mapped, int *maps, int *unmaps);
+#endif
 
 }  // namespace ju

@@ -24,7 +24,10 @@ from typing import Optional, Tuple
 import numpy as np
 
 _LIB_NAME = "libJoshUpscale.so"
-_LIB: Optional[C.CDLL] = None
+# The same objects with the test and measurement hooks of include/joshupscale_amd_test.h compiled in
+# (ju_debug_*, ju_read_tensor, ju_time_steps).  The product library exports none of them.
+_TEST_LIB_NAME = "libJoshUpscale_test.so"
+_LIBS: dict = {}
 
 LOC_CPU, LOC_DEVICE, LOC_GRAPHICS_RESOURCE = 0, 1, 2
 DTYPE_DEFAULT, DTYPE_F16, DTYPE_BF16 = -1, 0, 1
@@ -51,69 +54,100 @@ class JoshUpscaleError(RuntimeError):
         self.message = message
 
 
-def library_path() -> str:
-    """In-tree HIP library; ``JU_LIBRARY`` points at another build of it (A/B timing)."""
+def hooks_default() -> bool:
+    """``JU_TEST_HOOKS=1`` (set by tests/conftest.py and the developer tools): the process works
+    through libJoshUpscale_test.so.  Unset -- every caller of the product -- it is the product library."""
+    return os.environ.get("JU_TEST_HOOKS", "0") == "1"
+
+
+def library_path(hooks: Optional[bool] = None) -> str:
+    """In-tree HIP library (``hooks``: its test flavour); ``JU_LIBRARY`` points at another build
+    (A/B timing: such a build carries the hooks or not as it was linked)."""
     override = os.environ.get("JU_LIBRARY")
     if override:
         return override
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
+    hooks = hooks_default() if hooks is None else hooks
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                        _TEST_LIB_NAME if hooks else _LIB_NAME)
 
 
-def load_library() -> C.CDLL:
-    """Load the HIP library; fails loudly (no fallback) when it is not built."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = library_path()
+_P = C.POINTER
+_PRODUCT_SIGS = {
+    "ju_create": (C.c_int, [C.c_int, C.c_char_p, _P(C.c_void_p)]),
+    "ju_create_from_memory": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, _P(C.c_void_p)]),
+    "ju_validate_model": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "ju_destroy": (None, [C.c_void_p]),
+    "ju_process": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage)]),
+    "ju_enqueue": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage)]),
+    "ju_synchronize": (C.c_int, [C.c_void_p]),
+    "ju_prepare_frames": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), _P(C.c_int)]),
+    "ju_get_size": (C.c_int, [C.c_void_p] + [_P(C.c_size_t)] * 4),
+    "ju_reset": (C.c_int, [C.c_void_p]),
+    "ju_last_error": (C.c_char_p, []),
+    "ju_set_log_callback": (None, [LOG_CALLBACK, C.c_void_p]),
+    "ju_get_gl_device_index": (C.c_int, [_P(C.c_int)]),
+    "ju_get_gl_image": (C.c_int, [C.c_uint32, C.c_int, _P(JuImage)]),
+    "ju_release_gl_image": (None, [_P(JuImage)]),
+    "ju_get_dtype": (C.c_int, [C.c_void_p]),
+    "ju_get_stat": (C.c_int, [C.c_void_p, C.c_char_p, _P(C.c_double)]),
+    "ju_version": (C.c_char_p, []),
+    "ju_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ju_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_void_p)]),
+    "ju_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "ju_comm_allreduce_max": (C.c_int, [C.c_void_p, _P(C.c_double)]),
+    "ju_comm_count": (C.c_int, [C.c_void_p, _P(C.c_int)]),
+    "ju_comm_destroy": (None, [C.c_void_p]),
+}
+# include/joshupscale_amd_test.h
+_HOOK_SIGS = {
+    "ju_debug_fake_gl_texture": (C.c_int, [C.c_uint32, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),
+    "ju_debug_fake_gl_counters": (None, [_P(C.c_int)] * 4),
+    "ju_debug_e4m3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ju_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, _P(C.c_size_t)]),
+    "ju_time_steps": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _P(C.c_double), _P(C.c_int), _P(C.c_double)]),
+    "ju_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
+}
+PRODUCT_SYMBOLS = tuple(sorted(_PRODUCT_SIGS))
+HOOK_SYMBOLS = tuple(sorted(_HOOK_SIGS))
+
+
+def load_library(hooks: Optional[bool] = None) -> C.CDLL:
+    """Load the HIP library; fails loudly (no fallback) when it is not built.  ``hooks`` selects the
+    test flavour (default: ``JU_TEST_HOOKS``); a library that lacks a hook raises when the hook is used."""
+    hooks = hooks_default() if hooks is None else hooks
+    path = library_path(hooks)
+    if path in _LIBS:
+        return _LIBS[path]
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `make` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`). "
             "joshupscale_amd has no CPU fallback.")
     lib = C.CDLL(path)
-    P = C.POINTER
-    sigs = {
-        "ju_create": (C.c_int, [C.c_int, C.c_char_p, P(C.c_void_p)]),
-        "ju_create_from_memory": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int,
-                                            P(C.c_void_p)]),
-        "ju_validate_model": (C.c_int, [C.c_void_p, C.c_size_t]),
-        "ju_destroy": (None, [C.c_void_p]),
-        "ju_process": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage)]),
-        "ju_enqueue": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage)]),
-        "ju_synchronize": (C.c_int, [C.c_void_p]),
-        "ju_prepare_frames": (C.c_int, [C.c_void_p, P(JuImage), P(JuImage), P(C.c_int)]),
-        "ju_get_size": (C.c_int, [C.c_void_p] + [P(C.c_size_t)] * 4),
-        "ju_reset": (C.c_int, [C.c_void_p]),
-        "ju_last_error": (C.c_char_p, []),
-        "ju_set_log_callback": (None, [LOG_CALLBACK, C.c_void_p]),
-        "ju_get_gl_device_index": (C.c_int, [P(C.c_int)]),
-        "ju_get_gl_image": (C.c_int, [C.c_uint32, C.c_int, P(JuImage)]),
-        "ju_release_gl_image": (None, [P(JuImage)]),
-        "ju_debug_fake_gl_texture": (C.c_int, [C.c_uint32, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
-                                               C.c_int]),
-        "ju_debug_fake_gl_counters": (None, [P(C.c_int)] * 4),
-        "ju_get_dtype": (C.c_int, [C.c_void_p]),
-        "ju_debug_e4m3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
-        "ju_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
-                                     P(C.c_size_t)]),
-        "ju_time_steps": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, P(C.c_double),
-                                    P(C.c_int), P(C.c_double)]),
-        "ju_debug_set": (C.c_int, [C.c_char_p, C.c_int]),
-        "ju_get_stat": (C.c_int, [C.c_void_p, C.c_char_p, P(C.c_double)]),
-        "ju_version": (C.c_char_p, []),
-        "ju_comm_unique_id": (C.c_int, [C.c_void_p]),
-        "ju_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, P(C.c_void_p)]),
-        "ju_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
-        "ju_comm_allreduce_max": (C.c_int, [C.c_void_p, P(C.c_double)]),
-        "ju_comm_count": (C.c_int, [C.c_void_p, P(C.c_int)]),
-        "ju_comm_destroy": (None, [C.c_void_p]),
-    }
-    for name, (res, args) in sigs.items():
+    for name, (res, args) in _PRODUCT_SIGS.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _LIB = lib
+    for name, (res, args) in _HOOK_SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if hooks:
+                raise ImportError(f"{path} does not export {name}: not a -DJU_TEST_HOOKS build") from None
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    _LIBS[path] = lib
     return lib
+
+
+def _hook(lib: C.CDLL, name: str):
+    try:
+        return getattr(lib, name)
+    except AttributeError:
+        raise RuntimeError(f"{name} is a test hook (include/joshupscale_amd_test.h): the product library does not "
+                           "export it; set JU_TEST_HOOKS=1 or pass hooks=True to work through "
+                           "libJoshUpscale_test.so") from None
 
 
 def _check(lib: C.CDLL, rc: int) -> None:
@@ -132,9 +166,10 @@ def validate_model(model: bytes) -> None:
 class Runtime:
     """One recurrent SR stream on one GPU (``JoshUpscale::core::Runtime``)."""
 
-    def __init__(self, model, device: int = 0, dtype: int = DTYPE_DEFAULT):
-        """``model``: path of a .jupw file, or its bytes."""
-        self._lib = load_library()
+    def __init__(self, model, device: int = 0, dtype: int = DTYPE_DEFAULT, hooks: Optional[bool] = None):
+        """``model``: path of a .jupw file, or its bytes.  ``hooks``: through libJoshUpscale_test.so
+        (``read_tensor`` / ``time_steps`` need it; default: ``JU_TEST_HOOKS``)."""
+        self._lib = load_library(hooks)
         self._h = C.c_void_p()
         if isinstance(model, (bytes, bytearray, memoryview)):
             buf = bytes(model)
@@ -221,11 +256,10 @@ class Runtime:
     # -- introspection -------------------------------------------------------
     def read_tensor(self, name: str) -> np.ndarray:
         n = C.c_size_t()
-        _check(self._lib, self._lib.ju_read_tensor(self._h, name.encode(), None, 0,
-                                                   C.byref(n)))
+        read = _hook(self._lib, "ju_read_tensor")
+        _check(self._lib, read(self._h, name.encode(), None, 0, C.byref(n)))
         arr = np.empty(n.value, np.float32)
-        _check(self._lib, self._lib.ju_read_tensor(
-            self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.size, C.byref(n)))
+        _check(self._lib, read(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.size, C.byref(n)))
         return arr
 
     def stat(self, key: str) -> float:
@@ -238,7 +272,7 @@ class Runtime:
     def time_steps(self, tag: str, iters: int) -> Tuple[float, int, float]:
         """(ms per launch, launches per repetition, FLOPs per repetition)."""
         ms, n, fl = C.c_double(), C.c_int(), C.c_double()
-        _check(self._lib, self._lib.ju_time_steps(
+        _check(self._lib, _hook(self._lib, "ju_time_steps")(
             self._h, tag.encode(), iters, C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
 
@@ -318,8 +352,8 @@ class Session:
     Accepts ``[H, W, 3]`` BGR (as ``cv2.imread`` yields) or ``[H, W, 4]`` BGRX and
     returns the same number of channels."""
 
-    def __init__(self, model, device: int = 0, dtype: int = DTYPE_DEFAULT):
-        self.runtime = Runtime(model, device, dtype)
+    def __init__(self, model, device: int = 0, dtype: int = DTYPE_DEFAULT, hooks: Optional[bool] = None):
+        self.runtime = Runtime(model, device, dtype, hooks)
 
     def run(self, image: np.ndarray) -> np.ndarray:
         if image.ndim == 4 and image.shape[0] == 1:

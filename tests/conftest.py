@@ -9,6 +9,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# The test session works through libJoshUpscale_test.so: the product library does not export the hooks the
+# tests use (ju_debug_*, ju_read_tensor, ju_time_steps: include/joshupscale_amd_test.h).  The product library
+# itself is held to its symbol list (tests/test_c_abi.py) and to the test flavour's bytes
+# (tests/test_gpu_parity.py::test_product_library_gives_the_test_flavours_bytes).
+os.environ.setdefault("JU_TEST_HOOKS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
@@ -22,10 +29,18 @@ def hip_library():
     import shutil
     import subprocess
     from joshupscale_amd import runtime
-    if "JU_LIBRARY" not in os.environ and not os.path.exists(runtime.library_path()):
+    if "JU_LIBRARY" not in os.environ and not (os.path.exists(runtime.library_path(True)) and
+                                               os.path.exists(runtime.library_path(False))):
         if shutil.which("make") and os.path.exists("/opt/rocm/bin/hipcc"):
             subprocess.check_call(["make", "-s", "-j8", "-C", ROOT])
-    return runtime.load_library()
+    return runtime.load_library(True)
+
+
+@pytest.fixture(scope="session")
+def product_library(hip_library):
+    """The library a plugin host loads: no hooks."""
+    from joshupscale_amd import runtime
+    return runtime.load_library(False)
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -12,6 +12,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from helpers import (M, O, err, gen_in_to_reference, oracle_config, small_config,  # noqa: E402
                      tail_y_to_reference, u8_stats)
+os.environ.setdefault("JU_TEST_HOOKS", "1")  # developer tool: works through libJoshUpscale_test.so (the product library exports no hooks)
 from joshupscale_amd import runtime as R  # noqa: E402
 
 

@@ -12,9 +12,15 @@ from helpers import M, ROOT
 from joshupscale_amd import runtime as R
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "joshupscale_amd.h")).read()
+def declared_functions(header="joshupscale_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     return sorted(set(re.findall(r"JU_API\s+[\w\s\*]+?\b(ju_\w+)\s*\(", text)))
+
+
+def exported(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return [line.split()[-1] for line in out.splitlines() if line.strip()]
 
 
 def test_header_declares_the_expected_surface():
@@ -24,14 +30,47 @@ def test_header_declares_the_expected_surface():
         assert must in names
 
 
-def test_library_exports_every_declared_symbol(hip_library):
+def test_library_exports_every_declared_symbol(hip_library, product_library):
     for name in declared_functions():
+        assert hasattr(product_library, name), name
         assert hasattr(hip_library, name), name
+    for name in declared_functions("joshupscale_amd_test.h"):
+        assert hasattr(hip_library, name), name
+
+
+def test_product_library_exports_exactly_the_declared_surface(product_library):
+    """The shipped library exports the C ABI of include/joshupscale_amd.h and the C++ plugin surface of
+    include/JoshUpscale/core.h -- and no test or developer hook (the reference hides everything that is not
+    JOSHUPSCALE_EXPORT: core/CMakeLists.txt:29-36)."""
+    names = exported(R.library_path(False))
+    c_abi = sorted(n for n in names if n.startswith("ju_"))
+    assert c_abi == declared_functions(), set(c_abi) ^ set(declared_functions())
+    assert tuple(c_abi) == R.PRODUCT_SYMBOLS
+    hooks = declared_functions("joshupscale_amd_test.h")
+    assert sorted(hooks) == list(R.HOOK_SYMBOLS)
+    assert not [n for n in names if "debug" in n.lower() or n in hooks]
+    # the C++ surface: the five non-Windows functions of core.h:28, 60-62, 91-94 (plus weak template / typeinfo
+    # symbols of the standard library, which every C++ shared object carries)
+    strong = subprocess_nm_strong(R.library_path(False))
+    cxx = sorted(n for n in strong if n.startswith("_ZN11JoshUpscale"))
+    assert len(cxx) == 5 and all(re.search(r"core\d+(createRuntime|getExceptionString|setLogSink|getGLImage|getGLDeviceIndex)", n)
+                                 for n in cxx), cxx
+    other = [n for n in strong if not n.startswith(("ju_", "_ZN11JoshUpscale", "__hip_cuid_"))]
+    assert not other, other
+    # the test flavour: the same surface + exactly the hooks
+    tnames = exported(R.library_path(True))
+    assert sorted(n for n in tnames if n.startswith("ju_")) == sorted(declared_functions() + hooks)
+
+
+def subprocess_nm_strong(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return [line.split()[-1] for line in out.splitlines() if line.split()[1] in ("T", "D", "B", "R")]
 
 
 def test_cxx_plugin_surface_is_exported():
     import subprocess
-    out = subprocess.check_output(["nm", "-D", "--defined-only", R.library_path()]).decode()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", R.library_path(False)]).decode()
     for sym in ["createRuntime", "getExceptionString", "setLogSink", "getGLImage",
                 "getGLDeviceIndex"]:
         assert re.search(r"_ZN11JoshUpscale4core\d+" + sym, out), sym
@@ -72,7 +111,14 @@ def test_log_callback_receives_errors(hip_library):
 
 
 def test_missing_library_fails_loudly(monkeypatch):
-    monkeypatch.setattr(R, "_LIB", None)
+    monkeypatch.delenv("JU_LIBRARY", raising=False)
     monkeypatch.setattr(R, "_LIB_NAME", "libDoesNotExist.so")
-    with pytest.raises(ImportError, match="no CPU fallback"):
-        R.load_library()
+    monkeypatch.setattr(R, "_TEST_LIB_NAME", "libDoesNotExist_test.so")
+    for hooks in (False, True):
+        with pytest.raises(ImportError, match="no CPU fallback"):
+            R.load_library(hooks)
+
+
+def test_hooks_are_refused_by_the_product_library(product_library):
+    with pytest.raises(RuntimeError, match="test hook"):
+        R._hook(product_library, "ju_read_tensor")

@@ -58,8 +58,10 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
     assert res["warmup"] == 5 and res["preroll"] == 256 and res["untimed_frames"] == 261
     clk = res["config"]["sclk_mhz_during_preroll"]      # (what the clock was: sysfs, sampled outside the timed region)
     assert clk is None or (500 <= clk["min"] <= clk["median"] <= clk["max"] <= 2500 and clk["samples"] >= 1)
-    if clk:
-        assert res["roofline"]["frac"] <= res["roofline"]["frac_at_measured_clock"] <= 1.0
+    if clk:   # (the relation itself: a box that holds more than 2400 MHz reads frac_at_measured_clock < frac)
+        assert res["roofline"]["frac_at_measured_clock"] == pytest.approx(res["roofline"]["frac"] * 2400.0 / clk["median"], rel=1e-6)
+        assert 0.0 < res["roofline"]["frac_at_measured_clock"] <= 1.0
+    assert res["config"]["library"] == {"timed": "libJoshUpscale.so", "kernel_times": "libJoshUpscale_test.so"}
     rf = res["roofline"]
     assert 0.0 < rf["frac"] <= 1.0 and 0.0 < rf["frac_back_to_back"] <= 1.0 and rf["launches_per_frame"] == 1
     assert rf["traffic"] is None or (rf["traffic"] > 1e6 and "profiles/" in rf["traffic_source"])

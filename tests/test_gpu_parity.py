@@ -557,6 +557,28 @@ def test_cpp_plugin_surface_harness(tmp_path):
     rt.close()
 
 
+def test_product_library_gives_the_test_flavours_bytes():
+    """The test session works through libJoshUpscale_test.so (the hooks); what a plugin host loads is
+    libJoshUpscale.so.  Both are the same objects but for c_api.cpp / graphics.cpp: the product library must
+    produce the test flavour's bytes -- a small model, and the headline geometry with the one-launch tower --
+    export no hook, and refuse the hooks' Python wrappers loudly."""
+    prod = R.load_library(False)
+    assert b"test hooks" not in prod.ju_version() and b"test hooks" in R.load_library(True).ju_version()
+    assert not any(hasattr(prod, n) for n in R.HOOK_SYMBOLS)
+    for cfg, dtype, n in [(small_config(), R.DTYPE_F16, 4), (M.PRESETS["psp-fast"], R.DTYPE_BF16, 3)]:
+        blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+        frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=9, kind="noise")
+        outs = []
+        for hooks in (True, False):
+            with R.Runtime(blob, 0, dtype, hooks=hooks) as rt:
+                outs.append([rt.process_image(frames[k]).copy() for k in range(n)])
+                if not hooks:
+                    with pytest.raises(RuntimeError, match="test hook"):
+                        rt.read_tensor("state")
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [R.DTYPE_F16, R.DTYPE_BF16])
 def test_normalize_brightness_branch(dtype):
     """Optional branch of get_inference_model (reference models.py:772-779, 802-803,

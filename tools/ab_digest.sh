@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # GPU box: do two builds of the library produce the same bytes?  Frame and flow-head digests of three frames per
 # preset / dtype, then interleaved stage timings.   usage: bash tools/ab_digest.sh <libA.so> <libB.so>
 for L in "$1" "$2"; do

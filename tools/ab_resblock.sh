@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # developer tool, GPU box: the pipelined residual-block kernel against the plain one (JU_RES_BLOCK=plain) --
 # frame digests (must be equal) and us per tower (24 launches) at 640x448, bf16 and fp16
 for dt in BF16 F16; do

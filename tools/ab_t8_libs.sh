@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # developer tool, GPU box: interleaved timing of the 8-bit resident tower in several builds of the library
 for r in 1 2 3; do
   for L in "$@"; do

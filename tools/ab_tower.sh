@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # GPU box: interleaved A/B of two builds of libJoshUpscale.so on the tower stage.
 # usage: bash tools/ab_tower.sh <libA.so> <libB.so> [dtype: bf16|fp16|fp8] [preset] [rounds]
 A=$1; B=$2; DT=${3:-bf16}; PRESET=${4:-psp-quality}; N=${5:-3}

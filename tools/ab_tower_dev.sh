@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # developer tool, GPU box: byte check (product schedule against the plain one, bf16 psp-quality frames) and
 # interleaved timing of developer builds of the resident tower (tools/dev_tower_lib.sh)
 # usage: tools/ab_tower_dev.sh <lib.so>...

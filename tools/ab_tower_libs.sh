@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # developer tool, GPU box: interleaved timing of the resident tower in several builds of the library
 # usage: tools/ab_tower_libs.sh <lib.so>... ; prints us per tower launch (min of 3 x 20 launches) per round
 LIBS="$@"

@@ -6,6 +6,7 @@ import sys, os
 os.environ.setdefault("JU_TAIL", "fused")  # the 16-bit engine's trunk tensor is read below: keep the tail a launch of its own
 sys.path.insert(0, os.getcwd())
 import numpy as np
+os.environ.setdefault("JU_TEST_HOOKS", "1")  # developer tool: works through libJoshUpscale_test.so (the product library exports no hooks)
 from joshupscale_amd import model_file as M, runtime as R
 h, w = int(sys.argv[1]), int(sys.argv[2]); blocks = int(sys.argv[3]); nfr = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 cfg = M.ModelConfig(frame_height=h, frame_width=w, gen_blocks=blocks)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # GPU box: res_block_fp8_kernel as one 8-wave workgroup per CU (solo) against two 4-wave workgroups per CU (duo)
 for r in 1 2 3; do
 for f in solo duo; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # GPU box: per-dispatch timeline of one frame (rocprofv3 kernel trace).
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

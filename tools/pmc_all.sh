@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # GPU box: per-kernel evidence table for DESIGN.md -- duration (kernel trace), HBM bytes
 # (FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 correction of MI355X_MICROARCH.md)
 # and chip-level MFMA busy share: SQ_VALU_MFMA_BUSY_CYCLES (summed over SIMDs) /
@@ -55,6 +56,11 @@ for k,v in out.items():
         v['hbm_GBps']=v['hbm_bytes_per_launch']/v['us_per_launch_under_pmc']/1e3
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in v and v.get('GRBM_GUI_ACTIVE'):
         v['mfma_busy_frac']=v['SQ_VALU_MFMA_BUSY_CYCLES']/(1024.0*v['GRBM_GUI_ACTIVE']/8.0)
+import sys
+sys.path.insert(0, R)
+from joshupscale_amd.provenance import kernel_source_digest
+for k,v in out.items():
+    v['source_sha256']=kernel_source_digest(k)   # bench.py quotes a byte count only for the source it was counted on
 json.dump(out, open(R+'/gpurun_out/pmc_per_kernel.json','w'), indent=1, sort_keys=True)
 for k,v in sorted(out.items(), key=lambda kv:-kv[1].get('us_per_launch_under_pmc',0)*kv[1].get('launches',0)):
     print(f"{k:55s} {v.get('launches',0):4d} x {v.get('us_per_launch_under_pmc',0):7.1f} us  hbm {v.get('hbm_bytes_per_launch',0)/1e6:7.1f} MB {v.get('hbm_GBps',0):7.0f} GB/s  mfma busy {100*v.get('mfma_busy_frac',0):5.1f}%")

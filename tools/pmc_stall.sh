@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # GPU box: where does a kernel's time go?  Issue / wait / LDS / VMEM counters of the kernels whose name matches a
 # pattern, one counter group per rocprofv3 pass (--kernel-trace --pmc only), averaged per launch.
 # usage: bash tools/pmc_stall.sh <kernel name pattern[,pattern...]> <tag> [bench.py arguments]

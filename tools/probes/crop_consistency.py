@@ -9,6 +9,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
+import os
+os.environ.setdefault("JU_TEST_HOOKS", "1")  # developer tool: works through libJoshUpscale_test.so (the product library exports no hooks)
 from joshupscale_amd import model_file as M, runtime as R  # noqa: E402
 
 H, W = int(sys.argv[1]), int(sys.argv[2])

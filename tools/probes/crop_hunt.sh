@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # hunt: crop consistency over random mid sizes and engines
 python3 - <<'PY' > /tmp/sizes.txt
 import numpy as np

@@ -1,4 +1,5 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # Is the uniform 3 % slowdown of the block launches behind a conv_1 that also quantises (docs/quant_in_conv1.patch, built
 # as build/ab/lib_quant.so) a CLOCK effect?  Shader clock (amdgpu sysfs, this GPU's pp_dpm_sclk) and socket power sampled
 # beside a long run in each mode of the same library, interleaved.

@@ -20,6 +20,7 @@ def run(h, w, blocks, mode):
         env["JU_TOWER"] = mode
     code = (
         "import sys, numpy as np\n"
+        "import os; os.environ.setdefault('JU_TEST_HOOKS', '1')\n"
         "from joshupscale_amd import model_file as M, runtime as R\n"
         f"cfg = M.ModelConfig(frame_height={h}, frame_width={w}, gen_blocks={blocks})\n"
         "rt = R.Runtime(M.serialize(cfg, M.make_seeded_weights(cfg)), 0, R.DTYPE_BF16)\n"

@@ -7,6 +7,7 @@ if os.environ.get("WITH_TORCH"):
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 from helpers import M, O, oracle_config, small_config
+os.environ.setdefault("JU_TEST_HOOKS", "1")  # developer tool: works through libJoshUpscale_test.so (the product library exports no hooks)
 from joshupscale_amd import runtime as R
 a = M.synthetic_frames(1, 30, 48, seed=21, kind="smooth")
 b = M.synthetic_frames(1, 30, 48, seed=22, kind="noise")

@@ -1,8 +1,9 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # developer tool: timing ablation of res_block_fp8_kernel (JU_FB_SKIP bits: 1 X8 staging, 2 conv A MFMA,
 # 4 conv B MFMA, 8 skip DMA, 16 stores, 32 conv A epilogue, 64 conv B epilogue)
 # needs the probe build: `make ablate` (the product library ignores JU_FB_SKIP)
-export JU_LIBRARY=${JU_LIBRARY:-$PWD/build/ablate/libJoshUpscale.so}
+export JU_LIBRARY=${JU_LIBRARY:-$PWD/build/ablate/libJoshUpscale_test.so}
 for preset in psp-quality ps2-quality; do
 for s in 0 1 2 4 8 16 32 64 6 102 127; do
   JU_FB_SKIP=$s PRESET=$preset python - <<PY

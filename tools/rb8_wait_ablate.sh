@@ -1,8 +1,9 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # GPU box: does res_block_fp8_kernel stall on the ACKNOWLEDGEMENT of its own output stores?  (gfx950's vmcnt
 # counts stores; the wait for a pair's skip records is vmcnt(0).)  JU_FB_SKIP bits: 16 = no stores, 128 = no wait.
 # needs `make ablate`
-export JU_LIBRARY=$PWD/build/ablate/libJoshUpscale.so
+export JU_LIBRARY=$PWD/build/ablate/libJoshUpscale_test.so
 for s in 0 16 128 144 0 128; do
   JU_FB_SKIP=$s python3 - <<PY
 import os, sys

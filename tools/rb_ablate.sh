@@ -1,8 +1,9 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # developer tool: timing ablation of res_block_kernel at 640x448 (JU_FB_SKIP bits: 1 staging, 2 conv A MFMA,
 # 4 conv B MFMA, 8 skip loads, 16 stores, 32 conv A epilogue, 64 conv B epilogue)
 # needs the probe build: `make ablate` (the product library ignores JU_FB_SKIP)
-export JU_LIBRARY=${JU_LIBRARY:-$PWD/build/ablate/libJoshUpscale.so}
+export JU_LIBRARY=${JU_LIBRARY:-$PWD/build/ablate/libJoshUpscale_test.so}
 for s in 0 1 2 4 8 16 32 64 6 102 127; do
   JU_FB_SKIP=$s JU_TOWER=layers python - <<PY
 import os, sys

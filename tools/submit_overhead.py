@@ -9,6 +9,7 @@ import time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch  # noqa: E402
+os.environ.setdefault("JU_TEST_HOOKS", "1")  # developer tool: works through libJoshUpscale_test.so (the product library exports no hooks)
 from joshupscale_amd import model_file as M, runtime as R  # noqa: E402
 
 preset = sys.argv[1] if len(sys.argv) > 1 else "psp-quality"

@@ -1,7 +1,8 @@
 #!/bin/bash
+export JU_TEST_HOOKS=1  # the inline python below uses the hooks of libJoshUpscale_test.so
 # developer tool: timing ablation of tower8_resident_kernel (JU_FB_SKIP bits: 1 halo exchange, 2 K loop, 4 epilogue)
 # needs the probe build: `make ablate` (the product library ignores JU_FB_SKIP)
-export JU_LIBRARY=${JU_LIBRARY:-$PWD/build/ablate/libJoshUpscale.so}
+export JU_LIBRARY=${JU_LIBRARY:-$PWD/build/ablate/libJoshUpscale_test.so}
 for s in 0 1 2 4 3 6 7; do
   JU_FB_SKIP=$s python3 - <<PY
 import os, sys
