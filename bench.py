@@ -302,6 +302,9 @@ def main() -> int:
                    "library": os.path.basename(R.library_path(False))}
         rt.synchronize()
         rt_timed, rt = rt, R.Runtime(blob, device=local_rank, dtype=dt, hooks=True)
+        # the GPU idled while that runtime was set up: the same clock-warm pre-roll as in front of the timed region
+        # (whole frames, eager launches), or the in-frame kernel time below reads the clock ramp (measured: +5 %)
+        rt.time_steps("tower@frame", max(args.preroll // 2, 1))
         # (timed inside whole frames: the kernel in the clock / cache context of the workload --
         # what `rocprofv3 --kernel-trace --stats` of this command averages; the back-to-back
         # figure of the launches alone is reported beside it)

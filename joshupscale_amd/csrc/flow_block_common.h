@@ -28,7 +28,8 @@ __device__ __forceinline__ void fbGlds16(const void *g, void *l) {
 // bank row.
 template <int PB>
 __device__ __forceinline__ unsigned fbSwz(unsigned col) {
-	if constexpr (PB == 128) return (col >> 1) & 7u;
+	if constexpr (PB == 256) return col & 15u;  // (one pixel = one whole bank row: the 16 columns of a group take the 16 slots)
+	else if constexpr (PB == 128) return (col >> 1) & 7u;
 	else if constexpr (PB == 64) return (col >> 2) & 3u;
 	else return (col >> 3) & 1u;
 }

@@ -88,7 +88,8 @@ struct FbGeom {
 	static constexpr int OFF_STAGE = STAGE_IN_X ? OFF_X : OFF_T + TREGION;
 	static constexpr int LDS = OFF_T + TREGION + (STAGE_IN_X ? 0 : NW * STAGE_WAVE);
 	static_assert(CIN == 16 || CIN == 32 || CIN == 64 || CIN == 128, "input channels");
-	static_assert(CMID == 32 || CMID == 64, "block filters");
+	static_assert(CMID == 32 || CMID == 64 || CMID == 128, "block filters");
+	static_assert(NW % NCB == 0, "cout blocks over the waves");
 	static_assert(TH % 2 == 0 && TH >= 2, "row pairs");
 	static constexpr bool FITS = LDS <= 160 * 1024;
 };
@@ -116,9 +117,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 
 	// wave -> jobs: cout block cb (both convs have CMID couts), row pairs pstart, +pstep, ...
 	constexpr int NCB = G::NCB;
-	const int cb = NCB == 2 ? (wave & 1) : 0;
-	const int pstart = NCB == 2 ? (wave >> 1) : wave;
-	constexpr int PSTEP = NCB == 2 ? NW / 2 : NW;
+	const int cb = wave % NCB;
+	const int pstart = wave / NCB;
+	constexpr int PSTEP = NW / NCB;
 	const float s1 = fbActS(p.act1, p.slope), s2 = fbActS(p.act2, p.slope);
 
 	// ---- conv A weights: A fragments of this wave's cout block, straight to registers ----
@@ -390,7 +391,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	{
 		const unsigned char *wsrc = static_cast<const unsigned char *>(p.w2) + (size_t)cb * (9 * G::KS2 * 1024) + lane * 16;
 #pragma unroll
-		for (int f = 0; f < 9 * G::KS2; ++f) wb[f] = *reinterpret_cast<const Vec8<T> *>(wsrc + (size_t)f * 1024);
+		for (int f = 0; f < 9 * G::KS2; ++f) {
+			// fragment f = (tap, k-step); the packed order is [64-channel plane][tap][4 k-steps] (packConvWeights): one
+			// plane for CMID <= 64 (source index = f), two for the 128-filter block
+			constexpr int KSP = G::KS2 > 4 ? 4 : G::KS2;
+			const int tap = f / G::KS2, ks = f % G::KS2;
+			wb[f] = *reinterpret_cast<const Vec8<T> *>(wsrc + (size_t)(((ks / KSP) * 9 + tap) * KSP + ks % KSP) * 1024);
+		}
 #pragma unroll
 		for (int g = 0; g < 4; ++g) biasB[g] = *reinterpret_cast<const f32x4 *>(p.b2 + cb * 32 + 8 * g + 4 * hh);
 	}
@@ -507,15 +514,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 }
 
 // 8 waves where the widest instantiation stays within 256 registers (two 64-channel
-// planes of conv A weights do not)
-template <int CIN>
+// planes of conv A weights do not, nor do the 72 fragments of a 128-channel conv B)
+template <int CIN, int CMID = 32>
 constexpr int fbWaves() {
-	return CIN > 64 ? 4 : 8;
+	return (CIN > 64 || CMID > 64) ? 4 : 8;
 }
 
 template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK, bool PACK = false>
 void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
-	constexpr int NW = fbWaves<CIN>();
+	constexpr int NW = fbWaves<CIN, CMID>();
 	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, NW>;
 	static_assert(G::FITS, "tile does not fit LDS");
 	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTK, NW, PACK>;
@@ -559,11 +566,11 @@ void launchFlowBlockBest(const FlowBlockParams &p, int numCUs, hipStream_t strea
 			bestCost = c;
 		}
 	};
-	(consider(THS, FbGeom<CIN, CMID, THS, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS), ...);
+	(consider(THS, FbGeom<CIN, CMID, THS, UPS, POOL, OUTK, fbWaves<CIN, CMID>()>::FITS), ...);
 	bool done = false;
 	auto launch = [&](auto thTag) {
 		constexpr int TH = decltype(thTag)::value;
-		if constexpr (FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, fbWaves<CIN>()>::FITS) {
+		if constexpr (FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, fbWaves<CIN, CMID>()>::FITS) {
 			if (!done && best == TH) {
 				launchFlowBlockInst<T, CIN, CMID, TH, UPS, POOL, OUTK, PACK>(p, stream);
 				done = true;
@@ -579,6 +586,9 @@ void launchFlowBlockT(const FlowBlockParams &p, int numCUs, hipStream_t stream) 
 	if constexpr (OUTK == 2) {
 		// (64 -> 64 -> 64 residual block, JU_RES_BLOCK=tile only: two 128-byte tiles; 14 rows is what fits)
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, kFbMid, 6>(p, numCUs, stream);
+	} else if constexpr (CMID == 128) {
+		// (the third encoder block, 68 x 120 at 480 x 270: a few thousand pixels -- short tiles, or most of the chip idles)
+		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 6, 4, 2>(p, numCUs, stream);
 	} else {
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 20, 18, 10, 6>(p, numCUs, stream);
 	}
@@ -629,6 +639,7 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	}
 	JU_FB_CASE(16, 32, false, true, 0)   // encoder block 1: 12(16) -> 32 -> 32, pool
 	JU_FB_CASE(32, 64, false, true, 0)   // encoder block 2: 32 -> 64 -> 64, pool
+	JU_FB_CASE(64, 128, false, true, 0)  // encoder block 3: 64 -> 128 -> 128, pool (round 5: four cout blocks on four waves)
 	JU_FB_CASE(128, 64, true, false, 0)  // last decoder block: up(128) -> 64 -> 64
 	JU_FB_CASE(128, 64, false, false, 0)
 	JU_FB_CASE(64, 32, true, false, 1)   // head: up(64) -> 32 -> 32 (f16 flow head)
@@ -644,6 +655,11 @@ bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHea
 	if (cin == 64 && cmid == 64) return false;  // (only as a residual block: FlowBlockLaunch::residual)
 	if (cin == 16 && cmid == 32) return !upsample && pool && !outHead;
 	if (cin == 32 && cmid == 64) return !upsample && pool && !outHead;
+	if (cin == 64 && cmid == 128) {
+		// (round 5; JU_FLOW_WIDE=0 keeps the block's two convolutions as launches of their own: A/B runs)
+		static const bool wide = [] { const char *e = std::getenv("JU_FLOW_WIDE"); return !(e && e[0] == '0'); }();
+		return wide && !upsample && pool && !outHead;
+	}
 	if (cin == 128 && cmid == 64) return !pool && !outHead;
 	if (cin == 64 && cmid == 32) return !pool && outHead;
 	return false;

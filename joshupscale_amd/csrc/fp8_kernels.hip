@@ -879,6 +879,17 @@ void launchResBlockFp8(DType dt, const Fp8BlockLaunch &q, hipStream_t stream) {
 	k.W = q.W;
 	k.pitch = towerPitch(q.W);
 	k.skip = ablationSkipBits();
+#ifdef JU_ABLATE
+	{
+		// JU_FB_SKIP_ALT (probe builds only): every second launch takes these bits instead of JU_FB_SKIP -- the
+		// bytes-only ablation of "two residual blocks per launch" (tools/fp8_pair_ceiling.sh: the first block of
+		// a pair stores nothing, the second stages and fetches nothing: what the pair's halved stream traffic could
+		// buy at best, with none of the fusion's halo recompute)
+		static const int alt = [] { const char *e = std::getenv("JU_FB_SKIP_ALT"); return e ? std::atoi(e) : -1; }();
+		static std::atomic<unsigned> launches{0};
+		if (alt >= 0 && (launches.fetch_add(1) & 1u)) k.skip = alt;
+	}
+#endif
 	k.prio = wavePriorityMode(0);
 	const int cus = currentDeviceCUs();
 	// Tile height: a CU works through ceil(tiles / CUs) tiles one after the other, each

@@ -593,7 +593,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	unsigned colBase[3], colSwz[3];
 #pragma unroll
 	for (int dx = 0; dx < 3; ++dx) {
+#ifdef JU_M16_DEV  // TIMING build (wrong frames): the K loops on v_mfma_f32_16x16x32, see unitSeg
+		const int cq = (lane & 15) + dx;
+#else
 		const int cq = px + dx;
+#endif
 		colBase[dx] = cq * 128;
 		colSwz[dx] = (cq >> 1) & 7;
 	}
@@ -651,8 +655,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// was tried and produced rare wrong values under this kernel's register pressure.  The
 	// determinism soak and the parity suite guard it.)
 	auto issue = [&](unsigned rowAddr, int m, int set, int j) __attribute__((always_inline)) {
+#ifdef JU_M16_DEV
+		// macro-step m = (dx, ks32, pixel half): the fragment of row j is 16 pixels x 32 channels; the second
+		// pixel half is 16 columns = 2048 bytes further (same swizzle: ((c + 16) >> 1) & 7 == (c >> 1) & 7)
+		const int dx = m >> 2, ks32 = (m >> 1) & 1, ph = m & 1;
+		const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks32 * 4 + (lane >> 4)) ^ colSwz[dx]) << 4) + ph * 2048;
+#else
 		const int dx = m >> 2, ks = m & 3;
 		const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
+#endif
 		if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][0]) : "v"(a));
 		else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:4352" : "=v"(fb[set][1]) : "v"(a));
 		else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:8704" : "=v"(fb[set][2]) : "v"(a));
@@ -824,9 +835,24 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 						else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 						__builtin_amdgcn_sched_barrier(0);
 					}
+#ifdef JU_M16_DEV
+					{
+						// the same 12 macro-steps as (dx, ks32, pixel half): two 16x16x32 MFMAs (cout halves) on
+						// quarters (ph, c16) of the row's accumulator; A fragment index ks = ks32 * 2 + c16
+						const int ks32 = (m >> 1) & 1, ph = m & 1;
+						const bool first = KIND != 1 && (pos == P0 || pos == P0 + 1) && dy == 0;
+#pragma unroll
+						for (int c16 = 0; c16 < 2; ++c16) {
+							const int kf = ks32 * 2 + c16, sl = ph * 2 + c16;
+							setAccQuarter(acc[r], sl, mfma16(dx == 1 ? wm[dy * 4 + kf] : ws[dy * 8 + (dx >> 1) * 4 + kf], fb[set][need],
+							    accQuarter(first ? biasVec : acc[r], sl)));
+						}
+					}
+#else
 					// (a unit's first MFMA of each row takes the bias as its C operand)
 					acc[r] = mfma32(dx == 1 ? wm[dy * 4 + ks] : ws[dy * 8 + (dx >> 1) * 4 + ks], fb[set][need],
 					    (KIND != 1 && pos == P0 && dy == 0) ? biasVec : acc[r]);
+#endif
 					if (more && k < NR) issue(rowAddr, kOrder[pos + 1 < 12 ? pos + 1 : 11], set ^ 1, k);
 					if constexpr (DEF) {
 						// group (r, g) = step index, at most three plain VALU instructions behind each MFMA
@@ -882,12 +908,27 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				if constexpr (KIND == 2) {
 					if (streamNext) {
 						if (pos == 0) loadBias(layer + 1);
+#ifdef JU_M16_DEV
+						if (m & 1) {  // both pixel halves of (dx, ks32) are through: its six fragments are dead
+#pragma unroll
+							for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+								for (int c16 = 0; c16 < 2; ++c16) {
+									const int kf = ((m >> 1) & 1) * 2 + c16;
+									const Vec8<T> nf = loadWeightFrag(layer + 1, (dy * 3 + dx) * 4 + kf);
+									if (dx == 1) wm[dy * 4 + kf] = nf;
+									else ws[dy * 8 + (dx >> 1) * 4 + kf] = nf;
+								}
+							}
+						}
+#else
 #pragma unroll
 						for (int dy = 0; dy < 3; ++dy) {
 							const Vec8<T> nf = loadWeightFrag(layer + 1, (dy * 3 + dx) * 4 + ks);
 							if (dx == 1) wm[dy * 4 + ks] = nf;
 							else ws[dy * 8 + (dx >> 1) * 4 + ks] = nf;
 						}
+#endif
 						__builtin_amdgcn_sched_barrier(0);
 					}
 				}
