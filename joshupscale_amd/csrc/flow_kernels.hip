@@ -87,7 +87,13 @@ struct FbGeom {
 	static constexpr bool STAGE_IN_X = NPL * XPLANE >= NW * STAGE_WAVE;  // X is dead once conv A is done
 	static constexpr int OFF_STAGE = STAGE_IN_X ? OFF_X : OFF_T + TREGION;
 	static constexpr int LDS = OFF_T + TREGION + (STAGE_IN_X ? 0 : NW * STAGE_WAVE);
-	static_assert(CIN == 16 || CIN == 32 || CIN == 64 || CIN == 128, "input channels");
+	static_assert(CIN == 16 || CIN == 32 || CIN == 64 || CIN == 128 || CIN == 256, "input channels");
+	// more than two 64-channel planes of conv A weights do not fit the registers at once: they are fetched plane by
+	// plane, the next one behind the current plane's MFMAs (two sets of 36 fragments)
+#ifndef JU_FB_RELOAD_MIN
+#define JU_FB_RELOAD_MIN 3
+#endif
+	static constexpr bool RELOAD = NPL >= JU_FB_RELOAD_MIN;
 	static_assert(CMID == 32 || CMID == 64 || CMID == 128, "block filters");
 	static_assert(NW % NCB == 0, "cout blocks over the waves");
 	static_assert(TH % 2 == 0 && TH >= 2, "row pairs");
@@ -123,17 +129,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	const float s1 = fbActS(p.act1, p.slope), s2 = fbActS(p.act2, p.slope);
 
 	// ---- conv A weights: A fragments of this wave's cout block, straight to registers ----
-	Vec8<T> wa[G::NPL][9 * G::KS1];
-	{
-		const unsigned char *wsrc = static_cast<const unsigned char *>(p.w1) +
-		                            (size_t)cb * G::NPL * (9 * G::KS1 * 1024) + lane * 16;
+	// register sets of conv A fragments: all planes, or (RELOAD) two sets at one wave per SIMD / one set at two (its
+	// SIMD partner computes while a wave waits for its next plane)
+	constexpr int NWA = G::RELOAD ? (NW == 4 ? 2 : 1) : G::NPL;
+	Vec8<T> wa[NWA][9 * G::KS1];
+	const unsigned char *waSrc = static_cast<const unsigned char *>(p.w1) +
+	                             (size_t)cb * G::NPL * (9 * G::KS1 * 1024) + lane * 16;
+	auto loadPlaneA = [&](int set, int pl) __attribute__((always_inline)) {
 #pragma unroll
-		for (int pl = 0; pl < G::NPL; ++pl) {
-#pragma unroll
-			for (int f = 0; f < 9 * G::KS1; ++f) {
-				wa[pl][f] = *reinterpret_cast<const Vec8<T> *>(wsrc + (size_t)(pl * 9 * G::KS1 + f) * 1024);
-			}
+		for (int f = 0; f < 9 * G::KS1; ++f) {
+			wa[set][f] = *reinterpret_cast<const Vec8<T> *>(waSrc + (size_t)(pl * 9 * G::KS1 + f) * 1024);
 		}
+	};
+	// (Measured and dropped, round 5: issuing this fill BEHIND the tile's staging loads, the staging wait counting it
+	// out and a raw barrier in place of __syncthreads() -- whose release fence waits vmcnt(0) -- so that it travels
+	// while the staged patch is expanded.  The ISA showed the intended order; the launches took the same time,
+	// 14.8 against 14.7-15.1 us for the head block: profiles/r05_fb_late_w_ab.txt.)
+	if constexpr (G::RELOAD) {
+		loadPlaneA(0, 0);
+	} else {
+#pragma unroll
+		for (int pl = 0; pl < G::NPL; ++pl) loadPlaneA(pl, pl);
 	}
 
 	// ---- stage the input tile ----
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 		}
 		// (the bias comes in with the weights, once -- not a memory round trip per row pair -- where
 		// 16 more registers do not spill: not beside 144 registers of fragments at two waves per SIMD)
-		constexpr bool kHoistBiasA = G::NPL * 9 * G::KS1 * 4 < 144 || NW == 4;
+		constexpr bool kHoistBiasA = NWA * 9 * G::KS1 * 4 < 144 || NW == 4;
 		f32x4 biasA[4];
 		if constexpr (kHoistBiasA) {
 #pragma unroll
@@ -364,14 +380,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 			for (int s = 0; s < HOLD; ++s) initAcc(acc[s]);
 #pragma unroll
 			for (int pl = 0; pl < G::NPL; ++pl) {
+				// (RELOAD: the next plane's fragments travel behind this plane's MFMAs, into the other register set)
+				if constexpr (G::RELOAD && NWA == 2) {
+					if (pl + 1 < G::NPL) loadPlaneA((pl + 1) & 1, pl + 1);
+				}
 #pragma unroll
 				for (int s = 0; s < HOLD; ++s) {
 					const int pair = pstart + s * PSTEP;
 					if (pair < NPAIR) {
 						FbPair<T, G::KS1, G::PBX>::run(
 						    ldsBase + G::OFF_X + pl * G::XPLANE + (2 * pair) * (kFbW * G::PBX), colOffA, colSwzA, hh,
-						    wa[pl], acc[s]);
+						    wa[G::RELOAD ? (pl & (NWA - 1)) : pl], acc[s]);
 					}
+				}
+				if constexpr (G::RELOAD && NWA == 1) {
+					if (pl + 1 < G::NPL) loadPlaneA(0, pl + 1);  // (behind the plane's last MFMAs: the set is free)
 				}
 			}
 #pragma unroll
@@ -517,6 +540,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 // planes of conv A weights do not, nor do the 72 fragments of a 128-channel conv B)
 template <int CIN, int CMID = 32>
 constexpr int fbWaves() {
+#if JU_FB_RELOAD_MIN <= 2
+	if (CIN == 128 && CMID <= 64) return 8;  // (A/B build: the 128-channel decoder block with plane-by-plane weights at two waves per SIMD)
+#endif
 	return (CIN > 64 || CMID > 64) ? 4 : 8;
 }
 
@@ -587,8 +613,9 @@ void launchFlowBlockT(const FlowBlockParams &p, int numCUs, hipStream_t stream) 
 		// (64 -> 64 -> 64 residual block, JU_RES_BLOCK=tile only: two 128-byte tiles; 14 rows is what fits)
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, kFbMid, 6>(p, numCUs, stream);
 	} else if constexpr (CMID == 128) {
-		// (the third encoder block, 68 x 120 at 480 x 270: a few thousand pixels -- short tiles, or most of the chip idles)
-		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 6, 4, 2>(p, numCUs, stream);
+		// (the 128-filter blocks, 68 x 120 at 480 x 270: a few thousand pixels -- short tiles, or most of the chip idles;
+		// measured for the encoder block: 2 rows 11.7 us, 4 rows 16.0, 6 rows 19.9)
+		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 2>(p, numCUs, stream);
 	} else {
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 20, 18, 10, 6>(p, numCUs, stream);
 	}
@@ -640,6 +667,8 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	JU_FB_CASE(16, 32, false, true, 0)   // encoder block 1: 12(16) -> 32 -> 32, pool
 	JU_FB_CASE(32, 64, false, true, 0)   // encoder block 2: 32 -> 64 -> 64, pool
 	JU_FB_CASE(64, 128, false, true, 0)  // encoder block 3: 64 -> 128 -> 128, pool (round 5: four cout blocks on four waves)
+	JU_FB_CASE(256, 128, true, false, 0)  // decoder block 5: up(256) -> 128 -> 128 (round 5: conv A's weights plane by plane)
+	JU_FB_CASE(256, 128, false, false, 0)
 	JU_FB_CASE(128, 64, true, false, 0)  // last decoder block: up(128) -> 64 -> 64
 	JU_FB_CASE(128, 64, false, false, 0)
 	JU_FB_CASE(64, 32, true, false, 1)   // head: up(64) -> 32 -> 32 (f16 flow head)
@@ -655,10 +684,13 @@ bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHea
 	if (cin == 64 && cmid == 64) return false;  // (only as a residual block: FlowBlockLaunch::residual)
 	if (cin == 16 && cmid == 32) return !upsample && pool && !outHead;
 	if (cin == 32 && cmid == 64) return !upsample && pool && !outHead;
-	if (cin == 64 && cmid == 128) {
-		// (round 5; JU_FLOW_WIDE=0 keeps the block's two convolutions as launches of their own: A/B runs)
-		static const bool wide = [] { const char *e = std::getenv("JU_FLOW_WIDE"); return !(e && e[0] == '0'); }();
-		return wide && !upsample && pool && !outHead;
+	if (cmid == 128) {
+		// (round 5; JU_FLOW_WIDE=0 keeps the blocks' convolutions as launches of their own, 1 fuses the encoder block
+		// only: A/B runs)
+		static const int wide = [] { const char *e = std::getenv("JU_FLOW_WIDE"); return e ? std::atoi(e) : 2; }();
+		if (cin == 64) return wide >= 1 && !upsample && pool && !outHead;
+		if (cin == 256) return wide >= 2 && !pool && !outHead;
+		return false;
 	}
 	if (cin == 128 && cmid == 64) return !pool && !outHead;
 	if (cin == 64 && cmid == 32) return !pool && outHead;

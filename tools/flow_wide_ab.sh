@@ -1,5 +1,6 @@
+#!/bin/bash
+# developer tool, GPU box: the flow net's 128-filter blocks as launches of their own (JU_FLOW_WIDE=0), the encoder block fused
+# (1), both fused (2 = default), interleaved; per-launch times of tools/flow_layers.py
 for r in 1 2; do
-  echo "== JU_FLOW_WIDE=0"; JU_FLOW_WIDE=0 python3 tools/flow_layers.py | head -14
-  for th in 2 4 6; do echo "== wide, JU_FLOW_TILE=$th"; JU_FLOW_TILE=$th python3 tools/flow_layers.py | head -12; done
-  echo "== wide, default tile"; python3 tools/flow_layers.py | head -14
+  for wide in 0 1 2; do echo "== JU_FLOW_WIDE=$wide"; JU_FLOW_WIDE=$wide python3 tools/flow_layers.py | head -14; done
 done
