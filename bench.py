@@ -302,9 +302,17 @@ def main() -> int:
                    "library": os.path.basename(R.library_path(False))}
         rt.synchronize()
         rt_timed, rt = rt, R.Runtime(blob, device=local_rank, dtype=dt, hooks=True)
-        # the GPU idled while that runtime was set up: the same clock-warm pre-roll as in front of the timed region
-        # (whole frames, eager launches), or the in-frame kernel time below reads the clock ramp (measured: +5 %)
-        rt.time_steps("tower@frame", max(args.preroll // 2, 1))
+        # The GPU idled while that runtime was set up, and ju_time_steps runs its frames on the runtime's own staging
+        # buffer: the measuring runtime first goes through exactly what the timed one had gone through by the end of its
+        # timed region -- the SAME frames through ju_process -- so that the kernel is timed in the same power state and
+        # on live recurrent data.  (Measured, round 5: a pre-roll of ju_time_steps frames instead -- a constant, zero
+        # input frame, the state decays -- read 325 us in-frame for a kernel that takes ~350 in the timed frames: MFMAs
+        # on degenerate data draw less power and the chip clocks higher, tools/probes/two_runtimes2.py.)
+        if args.location == "device" and not args.no_prepare:
+            for i in range(len(ins)):
+                rt.prepare_frames(ins[i], outs[i])
+        for i in range(args.preroll + args.warmup + args.steps):
+            rt.process(ins[i % len(ins)], outs[i % len(outs)])
         # (timed inside whole frames: the kernel in the clock / cache context of the workload --
         # what `rocprofv3 --kernel-trace --stats` of this command averages; the back-to-back
         # figure of the launches alone is reported beside it)
