@@ -812,11 +812,16 @@ def test_flow_blocks_fused_and_per_layer_paths_agree(monkeypatch, dtype):
         blob = M.serialize(cfg, M.make_seeded_weights(cfg))
         frames = M.synthetic_frames(n, cfg.frame_height, cfg.frame_width, seed=61, kind="smooth")
         runs = {}
-        for mode in ("fused", "generic"):
+        # "narrow" (round 5): JU_FLOW_WIDE=0 keeps the two 128-filter blocks as launches of their own
+        # (conv_splitk_kernel / conv_mfma_kernel / upsample2_kernel: the path of rounds 2-4, still what odd
+        # geometries take) -- a third summation order, the same tolerance
+        for mode in ("fused", "narrow", "generic"):
+            monkeypatch.delenv("JU_FLOW_CONV", raising=False)
+            monkeypatch.delenv("JU_FLOW_WIDE", raising=False)
             if mode == "generic":
                 monkeypatch.setenv("JU_FLOW_CONV", "generic")
-            else:
-                monkeypatch.delenv("JU_FLOW_CONV", raising=False)
+            elif mode == "narrow":
+                monkeypatch.setenv("JU_FLOW_WIDE", "0")
             rt = R.Runtime(blob, 0, dtype)
             outs, flows = [], []
             for f in frames:
@@ -825,14 +830,18 @@ def test_flow_blocks_fused_and_per_layer_paths_agree(monkeypatch, dtype):
             runs[mode] = (outs, flows, rt.stat("launches_per_frame"))
             rt.close()
         monkeypatch.delenv("JU_FLOW_CONV", raising=False)
-        assert runs["fused"][2] < runs["generic"][2]          # fewer launches per frame
-        for a, b in zip(runs["fused"][0], runs["generic"][0]):
-            assert u8_stats(a, b)["max"] <= 1
-        for a, b in zip(runs["fused"][1], runs["generic"][1]):
-            # (each path is within TOL of the oracle; a 16-bit rounding that flips between the two
-            # summation orders propagates through the 14 layers, so their distance is of that order)
-            e = err(a, b)
-            assert e["max_abs"] <= TOL[dtype]["flow"] and e["rms"] <= 0.2 * TOL[dtype]["flow"], e
+        monkeypatch.delenv("JU_FLOW_WIDE", raising=False)
+        assert runs["fused"][2] <= runs["narrow"][2] < runs["generic"][2]          # fewer launches per frame
+        if len(cfg.flow_filters) >= 6 and cfg.flow_filters[2] == 128:
+            assert runs["fused"][2] < runs["narrow"][2]
+        for other in ("narrow", "generic"):
+            for a, b in zip(runs["fused"][0], runs[other][0]):
+                assert u8_stats(a, b)["max"] <= 1
+            for a, b in zip(runs["fused"][1], runs[other][1]):
+                # (each path is within TOL of the oracle; a 16-bit rounding that flips between the two
+                # summation orders propagates through the 14 layers, so their distance is of that order)
+                e = err(a, b)
+                assert e["max_abs"] <= TOL[dtype]["flow"] and e["rms"] <= 0.2 * TOL[dtype]["flow"], (other, e)
 
 
 def test_graphics_resource_frames_through_the_test_double():
