@@ -108,9 +108,9 @@ void Engine::planFlowUnits() {
 		FlowUnit &u = m_FlowUnits[i];
 		const bool even = h % 2 == 0 && w % 2 == 0;
 		if ((!pool || (m_FusedPool && even)) && (!prevUps || even)) {
-			if (prevUps && flowBlockSupported(padTo16(cin), f, true, pool, false)) {
+			if (prevUps && flowBlockSupported(padTo16(cin), f, true, pool, false, h, w)) {
 				u.fused = u.upsIn = true;
-			} else if (flowBlockSupported(padTo16(cin), f, false, pool, false)) {
+			} else if (flowBlockSupported(padTo16(cin), f, false, pool, false, h, w)) {
 				u.fused = true;
 			}
 		}
@@ -197,19 +197,29 @@ Engine::ConvWeights &Engine::addConv(const std::string &name, const FoldedConv &
 		dev.scaleA.upload(q.scaleA.data(), q.scaleA.size() * 4);
 		m_Fp8Convs.emplace(name, std::move(dev));
 	}
-	if (towerLayer) {  // tower layers, in execution order
+	// the resident tower's own copy of its layers' weights, in the fragment order of ITS MFMA shape (the per-block and
+	// per-convolution kernels keep reading cw.w / cw.wBlock)
+	auto residentPack = [&](const std::vector<int> &map64) {
+		return residentTowerM16() ? packTowerWeightsM16(f, map64, m_DType) : packConvWeights(f, map64, 2, m_DType);
+	};
+	if (towerLayer && f.cout == 64 && cinMap.size() == 64) {  // tower layers, in execution order
+		const auto w = residentPack(cinMap);
+		m_TowerHostW.insert(m_TowerHostW.end(), w.begin(), w.end());
+		m_TowerHostB.insert(m_TowerHostB.end(), f.bias.begin(), f.bias.end());
+	} else if (towerLayer) {  // (other generator widths never run the resident kernel; kept for the layer count)
 		m_TowerHostW.insert(m_TowerHostW.end(), packed.begin(), packed.end());
 		m_TowerHostB.insert(m_TowerHostB.end(), f.bias.begin(), f.bias.end());
 	}
 	if (flowBlock) {
-		m_FlowTowerHostW.insert(m_FlowTowerHostW.end(), packed.begin(), packed.end());
+		const auto w = residentPack(cinMap);
+		m_FlowTowerHostW.insert(m_FlowTowerHostW.end(), w.begin(), w.end());
 		m_FlowTowerHostB.insert(m_FlowTowerHostB.end(), f.bias.begin(), f.bias.end());
 	} else if (flowTower && name == "flow/conv_1") {
 		// layer 0 of the flow tower reads 64-channel records: same kernel, input
 		// channels 12.. are zero (the per-layer path keeps its own 16-channel packing)
 		std::vector<int> map64(64, -1);
 		for (int k = 0; k < f.cin && k < 64; ++k) map64[k] = k;
-		const auto head = packConvWeights(f, map64, 2, m_DType);
+		const auto head = residentPack(map64);
 		m_FlowTowerHostW.insert(m_FlowTowerHostW.end(), head.begin(), head.end());
 		m_FlowTowerHostB.insert(m_FlowTowerHostB.end(), f.bias.begin(), f.bias.end());
 	}

@@ -680,16 +680,23 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 
 }  // namespace
 
-bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHead) {
+bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHead, int H, int W) {
 	if (cin == 64 && cmid == 64) return false;  // (only as a residual block: FlowBlockLaunch::residual)
 	if (cin == 16 && cmid == 32) return !upsample && pool && !outHead;
 	if (cin == 32 && cmid == 64) return !upsample && pool && !outHead;
 	if (cmid == 128) {
-		// (round 5; JU_FLOW_WIDE=0 keeps the blocks' convolutions as launches of their own, 1 fuses the encoder block
-		// only: A/B runs)
-		static const int wide = [] { const char *e = std::getenv("JU_FLOW_WIDE"); return e ? std::atoi(e) : 2; }();
-		if (cin == 64) return wide >= 1 && !upsample && pool && !outHead;
-		if (cin == 256) return wide >= 2 && !pool && !outHead;
+		// Round 5.  These blocks run 2-row tiles (conv B's 72 fragments leave one wave per SIMD: no taller tile pays), so
+		// they are one launch only where those tiles are ONE round of the chip -- 480 x 270: 4 x 34 = 136 tiles at the
+		// 68 x 120 level, 15.1 -> 11.7 us (block 3) and 24.1 -> 23.3 us with three launches fewer (block 5); at 640 x 448
+		// (6 x 56 = 336 tiles, two rounds) block 3 is equal and block 5 loses 9 us to the launches of their own
+		// (profiles/r05_flow_layers_ps2.txt), which stay.  JU_FLOW_WIDE=0 keeps the launches of their own everywhere,
+		// 1 fuses the encoder block only, 3 fuses whatever the tile count: A/B runs.
+		const char *wideEnv = std::getenv("JU_FLOW_WIDE");  // (read per call: only engine construction asks, and the tests switch it)
+		const int wide = wideEnv ? std::atoi(wideEnv) : 2;
+		const bool oneRound = H <= 0 || W <= 0 || wide >= 3 ||
+		                      static_cast<long>((W + kFbOutW - 1) / kFbOutW) * ((H + 1) / 2) <= currentDeviceCUs();
+		if (cin == 64) return wide >= 1 && oneRound && !upsample && pool && !outHead;
+		if (cin == 256) return wide >= 2 && oneRound && !pool && !outHead;
 		return false;
 	}
 	if (cin == 128 && cmid == 64) return !pool && !outHead;

@@ -138,7 +138,9 @@ struct FlowBlockLaunch {
 	int frameH, frameW, padTop, padLeft, numInputs;
 	const unsigned *sums;
 };
-bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHead);
+// H x W: the block's resolution (the 128-filter blocks run as one launch only where their 2-row tiles are ONE round of the
+// chip: flow_kernels.hip); 0 = shape only
+bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHead, int H = 0, int W = 0);
 void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream);
 
 // One 3x3 convolution of the flow net's coarse levels (cin 128 / 256, a few thousand pixels), the
@@ -249,6 +251,8 @@ inline std::size_t residentCounterBytes(int GX, int GY) {
 void launchResidentTower(DType dt, const ResidentTowerParams &p, hipStream_t stream);
 
 // Timing-only ablation switch of the tower kernel (0 = product kernel).
+// the resident tower's K loops run v_mfma_f32_16x16x32 (weights packed by packTowerWeights(..., true)) or 32x32x16
+bool residentTowerM16();
 void setTowerVariant(int variant);
 int towerVariant();
 // Test hook: launch the resident tower `n` workgroups short, so that the bounded

@@ -483,4 +483,33 @@ std::vector<std::uint16_t> packConvWeights(
 	return out;
 }
 
+std::vector<std::uint16_t> packTowerWeightsM16(const FoldedConv &c, const std::vector<int> &cinMap, DType dt) {
+	if (cinMap.size() != 64 || c.cout != 64 || c.taps != 9) {
+		throw std::invalid_argument("packTowerWeightsM16: a 3x3 convolution of 64 (padded) input and 64 output channels");
+	}
+	std::vector<std::uint16_t> out(static_cast<std::size_t>(9) * 64 * 64);
+	std::size_t idx = 0;
+	for (int tap = 0; tap < 9; ++tap) {
+		for (int ks32 = 0; ks32 < 2; ++ks32) {
+			for (int c16 = 0; c16 < 2; ++c16) {
+				for (int ch = 0; ch < 2; ++ch) {
+					for (int l = 0; l < 64; ++l) {
+						const int co = ch * 32 + c16 * 16 + (l & 15);
+						for (int j = 0; j < 8; ++j) {
+							const int src = cinMap[ks32 * 32 + 8 * (l >> 4) + j];
+							float v = 0.f;
+							if (src >= 0) {
+								if (src >= c.cin) throw std::out_of_range("packTowerWeightsM16: cinMap");
+								v = c.w[(static_cast<std::size_t>(tap) * c.cin + src) * c.cout + co];
+							}
+							out[idx++] = dt == kF16 ? floatToF16(v) : floatToBF16(v);
+						}
+					}
+				}
+			}
+		}
+	}
+	return out;
+}
+
 }  // namespace ju

@@ -123,6 +123,12 @@ std::vector<ConvSpec> foldModel(const ModelFile &m);
 std::vector<std::uint16_t> packConvWeights(
     const FoldedConv &c, const std::vector<int> &cinMap, int nb, DType dt);
 
+// A 3x3 convolution of 64 (padded) input and 64 output channels as the resident tower's A fragments in the
+// v_mfma_f32_16x16x32 shape (tower_kernels.hip, JU_TOWER_M16): [tap 9][ks32 2][c16 2][ch 2][lane 64][8] --
+// lane l of fragment (tap, ks32, c16) of wave half ch holds output channel ch * 32 + c16 * 16 + (l & 15), packed input
+// channels ks32 * 32 + 8 (l >> 4) .. + 7.  Same element count and per-layer size as packConvWeights(nb = 2).
+std::vector<std::uint16_t> packTowerWeightsM16(const FoldedConv &c, const std::vector<int> &cinMap, DType dt);
+
 // convT2 (keras kernel [2][2][3][32]) as MFMA A fragments for tail_fused_kernel:
 // A[m][k], m = 4*(a'*2+b') + c (c < 3, other rows zero), k = input channel;
 // [2 k-steps][64 lanes][8]: lane l holds A[l & 31][16 ks + 8 (l >> 5) + j].

@@ -373,6 +373,15 @@ void launchTowerT(const ConvParams &p, hipStream_t stream) {
 // Nothing depends on dispatch order or XCD placement; all workgroups must be
 // co-resident (grid <= #CUs, one workgroup per CU by LDS size); every wait is
 // bounded in time and reports through *error.
+// The MFMA shape of the resident tower's K loops.  1 (round 5): v_mfma_f32_16x16x32 -- per (dx, 32-channel k-step,
+// pixel half) macro-step the same four row fragments (16 pixels x 32 channels each: the same LDS bytes per FLOP) feed
+// twelve 16-cycle MFMAs on quarters (pixel half, cout quarter) of the row accumulators.  The shape draws less power per
+// FLOP (a dense loop of this kernel's form holds 2.0 GHz instead of 1.74 on random data, tools/probes/mfma_shape.hip),
+// and the tower runs against the socket's power limit: +0.9 % frames/s at equal cycles (profiles/r05_m16b_tower_ab.txt).
+// 0: v_mfma_f32_32x32x16 (rounds 1-4; A/B builds).  The weights are packed for the shape (packTowerWeights, model.cpp).
+#ifndef JU_TOWER_M16
+#define JU_TOWER_M16 1
+#endif
 constexpr int kResRW = 32;                                          // region width = one MFMA block
 constexpr int kResMaxRH = 16;                                       // 8 row pairs, 4 per wave group
 constexpr int kResPitch = kResRW + 2;                               // LDS row: 32 px + halo column each side
@@ -546,7 +555,13 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 	const __amdgpu_buffer_rsrc_t wRsrc = __builtin_amdgcn_make_buffer_rsrc(
 	    const_cast<void *>(p.weights), 0, p.nLayers * 73728, 0x00020000);
+#if JU_TOWER_M16
+	// fragment f = (tap, kf = ks32 * 2 + c16): 16 output channels ch * 32 + c16 * 16 + (lane & 15) x 32 input channels
+	// ks32 * 32 + 8 (lane >> 4) .. + 7; packed [tap][ks32][c16][ch][lane][8] (packTowerWeights)
+	const unsigned wLaneOff = (unsigned)((ch * 64 + lane) * 16);
+#else
 	const unsigned wLaneOff = (unsigned)((hh * 64 + ch * 32 + px) * 16);
+#endif
 	auto loadWeightFrag = [&](int layer, int f) __attribute__((always_inline)) -> Vec8<T> {
 		const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(wRsrc, wLaneOff, layer * 73728 + f * 2048, 0);
 		return __builtin_bit_cast(Vec8<T>, v);
@@ -578,12 +593,25 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	    const_cast<float *>(p.bias), 0, p.nLayers * 256, 0x00020000);
 	f32x16 biasVec;
 	auto loadBias = [&](int layer) __attribute__((always_inline)) {
+#if JU_TOWER_M16
+		// quarter g = (pixel half, cout quarter c16 = g & 1) of a row accumulator: channels ch * 32 + c16 * 16 + 4 (lane >> 4) + i
+#pragma unroll
+		for (int c16 = 0; c16 < 2; ++c16) {
+			const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(biasRsrc, (unsigned)((ch * 32 + c16 * 16 + 4 * (lane >> 4)) * 4), layer * 256, 0);
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				biasVec[4 * c16 + i] = __uint_as_float(v[i]);
+				biasVec[8 + 4 * c16 + i] = __uint_as_float(v[i]);
+			}
+		}
+#else
 #pragma unroll
 		for (int g = 0; g < 4; ++g) {
 			const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(biasRsrc, (unsigned)((ch * 32 + 4 * hh + 8 * g) * 4), layer * 256, 0);
 #pragma unroll
 			for (int i = 0; i < 4; ++i) biasVec[4 * g + i] = __uint_as_float(v[i]);  // (bit_cast of a vector element reads element 0)
 		}
+#endif
 	};
 	loadBias(0);
 
@@ -593,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	unsigned colBase[3], colSwz[3];
 #pragma unroll
 	for (int dx = 0; dx < 3; ++dx) {
-#ifdef JU_M16_DEV  // TIMING build (wrong frames): the K loops on v_mfma_f32_16x16x32, see unitSeg
+#if JU_TOWER_M16  // a B fragment is 16 pixels x 32 channels: the lane's pixel is lane & 15
 		const int cq = (lane & 15) + dx;
 #else
 		const int cq = px + dx;
@@ -604,8 +632,15 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	unsigned outsw[4];  // [g]: byte offset of this lane's 4 output channels inside a row
 #pragma unroll
 	for (int g = 0; g < 4; ++g) {
+#if JU_TOWER_M16
+		// accumulator quarter g = (pixel half g >> 1, cout quarter g & 1): pixel (g >> 1) * 16 + (lane & 15), channels
+		// ch * 32 + (g & 1) * 16 + 4 (lane >> 4) .. + 3 = chunk ch * 4 + (g & 1) * 2 + (lane >> 5), 8-byte half (lane >> 4) & 1
+		const int cq = (g >> 1) * 16 + (lane & 15) + 1;
+		outsw[g] = cq * 128 + (((ch * 4 + (g & 1) * 2 + (lane >> 5)) ^ ((cq >> 1) & 7)) << 4) + ((lane >> 4) & 1) * 8;
+#else
 		const int cq = px + 1;
 		outsw[g] = cq * 128 + (((ch * 4 + g) ^ ((cq >> 1) & 7)) << 4) + hh * 8;
+#endif
 	}
 
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -655,11 +690,18 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// was tried and produced rare wrong values under this kernel's register pressure.  The
 	// determinism soak and the parity suite guard it.)
 	auto issue = [&](unsigned rowAddr, int m, int set, int j) __attribute__((always_inline)) {
-#ifdef JU_M16_DEV
+#if JU_TOWER_M16
 		// macro-step m = (dx, ks32, pixel half): the fragment of row j is 16 pixels x 32 channels; the second
 		// pixel half is 16 columns = 2048 bytes further (same swizzle: ((c + 16) >> 1) & 7 == (c >> 1) & 7)
 		const int dx = m >> 2, ks32 = (m >> 1) & 1, ph = m & 1;
-		const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks32 * 4 + (lane >> 4)) ^ colSwz[dx]) << 4) + ph * 2048;
+		const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks32 * 4 + (lane >> 4)) ^ colSwz[dx]) << 4);
+		if (ph) {  // (the pixel half as the instruction's immediate offset: no address arithmetic)
+			if (j == 0) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fb[set][0]) : "v"(a));
+			else if (j == 1) asm volatile("ds_read_b128 %0, %1 offset:6400" : "=v"(fb[set][1]) : "v"(a));
+			else if (j == 2) asm volatile("ds_read_b128 %0, %1 offset:10752" : "=v"(fb[set][2]) : "v"(a));
+			else asm volatile("ds_read_b128 %0, %1 offset:15104" : "=v"(fb[set][3]) : "v"(a));
+			return;
+		}
 #else
 		const int dx = m >> 2, ks = m & 3;
 		const unsigned a = rowAddr + colBase[dx] + (((unsigned)(ks * 2 + hh) ^ colSwz[dx]) << 4);
@@ -715,7 +757,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// unit's MFMAs (VALU and the LDS write issue while the matrix pipe works on the macro-step's
 	// last two MFMAs), instead of as ~560 exposed cycles between the units.  Same arithmetic, same
 	// order per element.  EPI false: this unit leaves its own epilogue to its successor.
+	// is this lane's pixel of accumulator group g inside the region (ragged right edge)?
+#if JU_TOWER_M16
+	const bool validLo = (lane & 15) < rwv, validHi = 16 + (lane & 15) < rwv;
+	auto groupValid = [&](const int g) __attribute__((always_inline)) { return (g >> 1) ? validHi : validLo; };
+#else
 	const bool lanesValid = px < rwv;
+	auto groupValid = [&](const int) __attribute__((always_inline)) { return lanesValid; };
+#endif
 	typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 	const __amdgpu_buffer_rsrc_t mailRsrc = __builtin_amdgcn_make_buffer_rsrc(
 	    (void *)p.mail, 0, (int)((size_t)p.GX * p.GY * 2 * (LEAKY ? 2 : 1) * kResMailSlots * 16), 0x00020000);
@@ -734,8 +783,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[i]);
 		}
 		if constexpr (VARIANT == 5 && !LEAKY) {  // calibration build: range of the layer's output
+			if (groupValid(g)) {
 #pragma unroll
-			for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, v[i]);  // (= max of the ReLU'd values)
+				for (int i = 0; i < 4; ++i) calibMax = fmaxf(calibMax, v[i]);  // (= max of the ReLU'd values)
+			}
 		}
 	};
 	auto epiStore = [&](auto outTag, const int row, const int g, float(&v)[4]) __attribute__((always_inline)) {
@@ -835,7 +886,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 						else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 						__builtin_amdgcn_sched_barrier(0);
 					}
-#ifdef JU_M16_DEV
+#if JU_TOWER_M16
 					{
 						// the same 12 macro-steps as (dx, ks32, pixel half): two 16x16x32 MFMAs (cout halves) on
 						// quarters (ph, c16) of the row's accumulator; A fragment index ks = ks32 * 2 + c16
@@ -885,7 +936,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
 								const Vec4<T> pk = __builtin_bit_cast(Vec4<T>, u32x2d{dlo, dhi});
 								const Vec4<T> o = LEAKY ? pk : reluPacked<T>(pk);
-								if (lanesValid) *reinterpret_cast<Vec4<T> *>(smem + outOff + (dra + r) * kResRowBytes + outsw[g]) = o;
+								if (groupValid(g)) *reinterpret_cast<Vec4<T> *>(smem + outOff + (dra + r) * kResRowBytes + outsw[g]) = o;
 							}
 						}
 					}
@@ -907,8 +958,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				// x 36 KB through the CU's 64 B/clk address path: ~2.4k cycles of issue).
 				if constexpr (KIND == 2) {
 					if (streamNext) {
+#if JU_TOWER_M16
+						if (pos == 1) loadBias(layer + 1);  // (the bias is the C operand of the first TWO steps: one per pixel half)
+#else
 						if (pos == 0) loadBias(layer + 1);
-#ifdef JU_M16_DEV
+#endif
+#if JU_TOWER_M16
 						if (m & 1) {  // both pixel halves of (dx, ks32) are through: its six fragments are dead
 #pragma unroll
 							for (int dy = 0; dy < 3; ++dy) {
@@ -961,11 +1016,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		if constexpr (KIND != 0 && EPI) {
 			// ---- epilogue: (+residual) ReLU, 16-bit, into the output buffer interior ----
 			// (row ra + r <= rhv always: units are whole pairs, or the odd last row)
-			if (px < rwv) {
+			{
 				// The residual is read-modify-write in place.  All reads of the unit
 				// first, then the arithmetic and the writes: left to the compiler every
 				// group is read -> wait -> write -> next read (it cannot prove the groups
-				// do not alias), i.e. 8 exposed LDS round trips per unit.
+				// do not alias), i.e. 8 exposed LDS round trips per unit.  (Lanes whose pixel lies beyond a
+				// ragged right edge read inside the buffer and store nothing.)
 				Vec4<T> rv[ROWS][4];
 				if (residual) {
 #pragma unroll
@@ -984,7 +1040,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					for (int g = 0; g < 4; ++g) {
 						float v[4];
 						epiValue(resTag, acc[r], g, rv[r][g], v);
-						epiStore(outTag, ra + r, g, v);
+						if (groupValid(g)) epiStore(outTag, ra + r, g, v);
 					}
 				}
 			}
@@ -1063,7 +1119,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					for (int g = 0; g < 4; ++g) {
 						float v[4];
 						epiValue(resTag, accPre0[r], g, rvNext[r][g], v);
-						if (lanesValid) epiStore(outTag, ra + r, g, v);
+						if (groupValid(g)) epiStore(outTag, ra + r, g, v);
 					}
 				}
 #ifndef JU_TOWER_SEGPROF
@@ -1527,6 +1583,7 @@ void launchConvTower(DType dt, const ConvParams &p, hipStream_t stream) {
 	}
 }
 
+bool residentTowerM16() { return JU_TOWER_M16 != 0; }
 void setTowerVariant(int v) { g_TowerVariant = v; }
 // the fast schedule where the geometry allows it (default); 0 (JU_TOWER_FAST=0 or the tests' switch): the
 // general schedule everywhere

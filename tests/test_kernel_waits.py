@@ -60,6 +60,34 @@ buffer_load_dwordx4 v[54:57], v212, s[68:71], 0 offen sc1
 """
     v, _ = t.check_kernel(_lines(reused))
     assert len(v) == 1
+    # the two sides of an if / else on EXEC run on disjoint lanes (registers are per lane): the else side may reuse
+    # a register whose read is in flight on the then side -- but not one whose read is in flight on its OWN side,
+    # and after the join every read of both sides counts again
+    if_else = """
+s_and_b64 s[4:5], s[2:3], s[6:7]
+s_xor_b64 s[34:35], s[4:5], s[2:3]
+s_mov_b64 exec, s[4:5]
+s_cbranch_execz 10
+ds_read_b128 v[86:89], v74 offset:8704
+ds_read_b128 v[74:77], v74 offset:13056
+s_andn2_saveexec_b64 s[34:35], s[34:35]
+s_cbranch_execz 21
+v_accvgpr_read_b32 v86, a133
+ds_read_b128 v[94:97], v86
+ds_read_b128 v[86:89], v86 offset:8704
+s_or_b64 exec, exec, s[34:35]
+s_waitcnt lgkmcnt(0)
+v_mfma_f32_32x32x16_bf16 v[32:47], a[0:3], v[86:89], v[32:47]
+"""
+    v, stats = t.check_kernel(_lines(if_else))
+    assert v == [] and stats["ds"] == 4
+    own_side = if_else.replace("v_accvgpr_read_b32 v86, a133\nds_read_b128 v[94:97], v86",
+                               "v_accvgpr_read_b32 v86, a133\nds_read_b128 v[94:97], v86\nv_mov_b32_e32 v94, 0")
+    v, _ = t.check_kernel(_lines(own_side))
+    assert len(v) == 1 and ("v", 94) in v[0][2]
+    after_join = if_else.replace("s_waitcnt lgkmcnt(0)\n", "")
+    v, _ = t.check_kernel(_lines(after_join))
+    assert len(v) == 1 and ("v", 86) in v[0][2]
     # scalar memory returns out of order: a counted wait proves nothing while one is outstanding
     smem = """
 s_load_dwordx2 s[4:5], s[0:1], 0x0

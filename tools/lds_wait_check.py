@@ -85,10 +85,29 @@ def regs(text: str):
 
 def check_kernel(lines):
     """`lines`: (address text, mnemonic, operand text) of one kernel in address order -> (violations, stats)."""
-    queue = []          # outstanding LGKM operations, oldest first: (in_order, destination registers, text)
+    queue = []          # outstanding LGKM operations, oldest first: (in_order, destination registers, text, serial number)
     violations = []
     stats = {"ds": 0, "counted_waits": 0, "max_outstanding": 0, "out_of_order_under_counted_wait": 0}
+    # The two sides of an if / else on EXEC run on disjoint lanes, and registers are per lane: a read issued on the
+    # `then` side is in flight in the then-lanes only, so the else side may overwrite or use "its" register (hipcc
+    # does, when it parks an address in an AGPR and reads it back into a fragment register that the else side's own
+    # read refills anyway).  The wave's LGKM counter still counts every operation: the queue is unchanged, only the
+    # hazard test skips the then-side's entries between `s_andn2_saveexec_b64 D, X` (else: X = the mask an `s_xor_b64 X`
+    # computed in front of the then side) and the join `s_or_b64 exec, exec, D`.
+    serial = 0
+    xor_marks = {}      # SGPR pair text -> serial number at the s_xor_b64 that wrote it
+    other_lanes = {}    # join register text -> (first, last) serial numbers issued on the other side
     for addr, mn, ops in lines:
+        if mn == "s_xor_b64":
+            xor_marks[ops.split(",")[0].strip()] = serial
+        elif mn in ("s_andn2_saveexec_b64", "s_or_saveexec_b64"):
+            parts = [o.strip() for o in ops.split(",")]
+            if len(parts) == 2 and parts[1] in xor_marks:
+                other_lanes[parts[0]] = (xor_marks.pop(parts[1]), serial)
+        elif mn == "s_or_b64":
+            parts = [o.strip() for o in ops.split(",")]
+            if len(parts) == 3 and parts[0] == "exec" and parts[1] == "exec":
+                other_lanes.pop(parts[2], None)
         if mn == "s_waitcnt":
             m = _LGKM.search(ops)
             if m is None and ops.strip().isdigit():  # (raw immediate: lgkmcnt is bits 11:8)
@@ -110,22 +129,27 @@ def check_kernel(lines):
             # what follows is reached by jumps only, with a state this walk does not know: start afresh (the
             # compiler's own loops, whose loads it waits for itself, are where this happens)
             queue.clear()
+            other_lanes.clear()
             continue
         operands = [o.strip() for o in ops.split(",")] if ops else []
         is_ds = mn.startswith("ds_")
         is_ooo = bool(_OUT_OF_ORDER.match(mn))
         has_dst = is_ds and bool(_DS_WITH_DST.match(mn))
         used = regs(", ".join(operands[1:] if has_dst else operands)) if (is_ds or is_ooo) else regs(ops)
-        pending = set().union(*(e[1] for e in queue)) if queue else set()
+        def mine(e):   # (not issued on the other side of an if / else this instruction is inside)
+            return not any(lo <= e[3] < hi for lo, hi in other_lanes.values())
+        pending = set().union(*(e[1] for e in queue if mine(e))) if queue else set()
         hit = used & pending
         if hit:
-            who = [e[2] for e in queue if e[1] & hit]
+            who = [e[2] for e in queue if e[1] & hit and mine(e)]
             violations.append((addr, f"{mn} {ops}", sorted(hit)[:4], who[:2], len(queue)))
         if is_ds:
             stats["ds"] += 1
-            queue.append((True, regs(operands[0]) if has_dst and operands else set(), f"{addr} {mn} {ops}"))
+            queue.append((True, regs(operands[0]) if has_dst and operands else set(), f"{addr} {mn} {ops}", serial))
+            serial += 1
         elif is_ooo:
-            queue.append((False, set(), f"{addr} {mn} {ops}"))
+            queue.append((False, set(), f"{addr} {mn} {ops}", serial))
+            serial += 1
         stats["max_outstanding"] = max(stats["max_outstanding"], len(queue))
     return violations, stats
 
