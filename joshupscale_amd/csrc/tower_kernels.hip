@@ -382,6 +382,20 @@ void launchTowerT(const ConvParams &p, hipStream_t stream) {
 #ifndef JU_TOWER_M16
 #define JU_TOWER_M16 1
 #endif
+// A unit row's 16 accumulator values per lane.  16x16x32 form: FOUR independent 4-register tuples (pixel half, cout
+// quarter), each the C / D operand of its own MFMAs -- as quarters of one 16-register vector hipcc renamed every MFMA's
+// destination and reused the freed quarters for the epilogue's temporaries, a hazard s_nop in front of each.
+#if JU_TOWER_M16
+struct TowerAcc {
+	f32x4 q[4];
+};
+__device__ __forceinline__ float accElem(const TowerAcc &a, const int i) { return a.q[i >> 2][i & 3]; }
+__device__ __forceinline__ void setAccElem(TowerAcc &a, const int i, const float v) { a.q[i >> 2][i & 3] = v; }
+#else
+typedef f32x16 TowerAcc;
+__device__ __forceinline__ float accElem(const TowerAcc &a, const int i) { return a[i]; }
+__device__ __forceinline__ void setAccElem(TowerAcc &a, const int i, const float v) { a[i] = v; }
+#endif
 constexpr int kResRW = 32;                                          // region width = one MFMA block
 constexpr int kResMaxRH = 16;                                       // 8 row pairs, 4 per wave group
 constexpr int kResPitch = kResRW + 2;                               // LDS row: 32 px + halo column each side
@@ -418,6 +432,11 @@ constexpr unsigned long long kResTimeoutTicks = 20000000ull;        // 0.2 s of 
 // the last row 14 high), 12-row ones too.
 __host__ __device__ inline bool residentFastShape(int rhv, int rwv) {
 	if ((rhv & 1) || rwv < 2) return false;
+#if JU_TOWER_M16
+	// (16x16x32 form: full-width regions only -- the fast schedule then writes its groups without a lane mask; a frame
+	// with a ragged last column of regions runs the general schedule)
+	if (rwv != 32) return false;
+#endif
 	const int np2 = rhv >> 1;
 	for (int par = 0; par < 2; ++par) {
 		const int first = par ? 1 : 2;
@@ -591,7 +610,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// ever initialised by moves.  Fetched at the head of the weight stream.
 	const __amdgpu_buffer_rsrc_t biasRsrc = __builtin_amdgcn_make_buffer_rsrc(
 	    const_cast<float *>(p.bias), 0, p.nLayers * 256, 0x00020000);
-	f32x16 biasVec;
+	TowerAcc biasVec;
 	auto loadBias = [&](int layer) __attribute__((always_inline)) {
 #if JU_TOWER_M16
 		// quarter g = (pixel half, cout quarter c16 = g & 1) of a row accumulator: channels ch * 32 + c16 * 16 + 4 (lane >> 4) + i
@@ -600,8 +619,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(biasRsrc, (unsigned)((ch * 32 + c16 * 16 + 4 * (lane >> 4)) * 4), layer * 256, 0);
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
-				biasVec[4 * c16 + i] = __uint_as_float(v[i]);
-				biasVec[8 + 4 * c16 + i] = __uint_as_float(v[i]);
+				setAccElem(biasVec, 4 * c16 + i, __uint_as_float(v[i]));
+				setAccElem(biasVec, 8 + 4 * c16 + i, __uint_as_float(v[i]));
 			}
 		}
 #else
@@ -609,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		for (int g = 0; g < 4; ++g) {
 			const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(biasRsrc, (unsigned)((ch * 32 + 4 * hh + 8 * g) * 4), layer * 256, 0);
 #pragma unroll
-			for (int i = 0; i < 4; ++i) biasVec[4 * g + i] = __uint_as_float(v[i]);  // (bit_cast of a vector element reads element 0)
+			for (int i = 0; i < 4; ++i) setAccElem(biasVec, 4 * g + i, __uint_as_float(v[i]));  // (bit_cast of a vector element reads element 0)
 		}
 #endif
 	};
@@ -680,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	constexpr bool kPlain = VARIANT == 8;
 	constexpr int kPreRun = kPlain ? 0 : FAST ? JU_FAST_PRERUN : JU_PRERUN;
 	constexpr int kPreBefore = kPlain ? 0 : JU_PREBEFORE;  // how many of them run BEFORE the halo loads are issued
-	f32x16 accPre0[2], accPre1[2], accPre2[2];  // (separate objects: an array indexed by the slot would live in scratch)
+	TowerAcc accPre0[2], accPre1[2], accPre2[2];  // (separate objects: an array indexed by the slot would live in scratch)
 	static_assert(kPreRun >= 0 && kPreRun <= 3, "at most three interior units per wave");
 	Vec8<T> fb[2][4];
 	// (The reads are asm so that they can be issued a macro-step ahead with counted waits.  To the
@@ -760,7 +779,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// is this lane's pixel of accumulator group g inside the region (ragged right edge)?
 #if JU_TOWER_M16
 	const bool validLo = (lane & 15) < rwv, validHi = 16 + (lane & 15) < rwv;
-	auto groupValid = [&](const int g) __attribute__((always_inline)) { return (g >> 1) ? validHi : validLo; };
+	auto groupValid = [&](const int g) __attribute__((always_inline)) { return FAST || ((g >> 1) ? validHi : validLo); };
 #else
 	const bool lanesValid = px < rwv;
 	auto groupValid = [&](const int) __attribute__((always_inline)) { return lanesValid; };
@@ -775,9 +794,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// (tools/probes/mfma_valu_overlap.hip: the chip accepts ~13 such instructions per clock), and the
 	// epilogues need 36 per wave and layer where the cooperative publish needs 4 dense ones.)
 	Vec4<T> rvNext[2][4];  // residual of the unit whose epilogue is pending
-	auto epiValue = [&](auto resTag, const f32x16 &a, const int g, const Vec4<T> &rv, float(&v)[4]) __attribute__((always_inline)) {
+	auto epiValue = [&](auto resTag, const TowerAcc &a, const int g, const Vec4<T> &rv, float(&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
-		for (int i = 0; i < 4; ++i) v[i] = a[4 * g + i];
+		for (int i = 0; i < 4; ++i) v[i] = accElem(a, 4 * g + i);
 		if constexpr (decltype(resTag)::value) {
 #pragma unroll
 			for (int i = 0; i < 4; ++i) v[i] += static_cast<float>(rv[i]);
@@ -805,9 +824,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			    reluPacked<T>(pack4<T>(v[0], v[1], v[2], v[3]));
 		}
 	};
-	auto unitSeg = [&](auto rowsTag, auto kindTag, auto resTag, auto inTag, auto outTag, f32x16(&acc)[2],
+	auto unitSeg = [&](auto rowsTag, auto kindTag, auto resTag, auto inTag, auto outTag, TowerAcc(&acc)[2],
 	                   const int layer, const int unit, const bool primed, const int nextUnit,
-	                   const bool nextFinish, auto streamTag, auto defTag, f32x16(&dacc)[2], const int dunit,
+	                   const bool nextFinish, auto streamTag, auto defTag, TowerAcc(&dacc)[2], const int dunit,
 	                   auto epiTag) __attribute__((always_inline)) {
 		constexpr bool streamNext = decltype(streamTag)::value;  // (compile-time: no branch per macro-step)
 		constexpr bool DEF = decltype(defTag)::value;   // (a deferring segment is always primed and deferred units are row pairs)
@@ -839,9 +858,59 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		const int dra = 1 + 2 * dunit;
 		// (by value, constant indices: an element read of `dacc[j >> 2]` is a dynamic index until the loops
 		// are unrolled, by when the loads had been merged into partial vectors and the array stayed in scratch)
-		const f32x16 dacc0 = dacc[0], dacc1 = dacc[1];
+		const TowerAcc dacc0 = dacc[0], dacc1 = dacc[1];
 		float dv[4];
 		unsigned dlo = 0, dhi = 0;
+		// The deferred epilogue's slot behind MFMA group k of macro-step `pos` (DEF segments): the previous unit's group
+		// (r, g) = step index -- MFMA groups 0..3 value i = accumulator (+ residual), 4 convert, 5 ReLU + write.
+		// `part` (16x16x32 form): 0 = the slot between the group's two MFMAs, 1 = behind the second one (the LDS write of
+		// the last group only: with its lane mask it does not fit the 8 cycles between two 16-cycle MFMAs)
+		auto defSlot = [&](const int pos, const int k, const int part = -1) __attribute__((always_inline)) {
+					if constexpr (DEF) {
+						// group (r, g) = step index, at most three plain VALU instructions behind each MFMA
+						// (tools/probes/mfma_valu_overlap.hip: that many issue in an MFMA's shadow for
+						// free, a fourth and every packed-f32 one cost their full issue time):
+						// MFMA 0..3 value i = accumulator (+ residual), 4 convert, 5 ReLU + write
+						const int j = pos - P0;
+						if (j < 8) {
+							const int r = j >> 2, g = j & 3;
+							if (k < 5 && part == 1) {
+							} else if (k < 4) {
+								dv[k] = accElem(r ? dacc1 : dacc0, 4 * g + k);
+								if constexpr (residual) {
+									dv[k] += static_cast<float>(rvNext[r][g][k]);
+									asm volatile("" : "+v"(dv[k]));  // (keeps the four adds scalar and in their slots)
+								}
+								if constexpr (LEAKY) {
+									// max(x, slope x), slope in [0, 1]; the instruction itself (fmaxf() canonicalises
+									// both operands first: two more instructions in a slot that has room for three)
+									const float t = dv[k] * p.slope;
+									asm volatile("v_max_f32 %0, %1, %2" : "=v"(dv[k]) : "v"(dv[k]), "v"(t));
+								}
+							} else if (k == 4) {
+								const Vec4<T> pk = pack4<T>(dv[0], dv[1], dv[2], dv[3]);
+								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
+								const u32x2d w = __builtin_bit_cast(u32x2d, pk);
+								dlo = w[0];
+								dhi = w[1];
+								asm volatile("" : "+v"(dlo), "+v"(dhi));
+							} else {
+								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
+								if (part != 1) {
+									const Vec4<T> pk = __builtin_bit_cast(Vec4<T>, u32x2d{dlo, dhi});
+									const u32x2d w = __builtin_bit_cast(u32x2d, LEAKY ? pk : reluPacked<T>(pk));
+									dlo = w[0];
+									dhi = w[1];
+									if (part == 0) asm volatile("" : "+v"(dlo), "+v"(dhi));
+								}
+								if (part != 0) {
+									const Vec4<T> o = __builtin_bit_cast(Vec4<T>, u32x2d{dlo, dhi});
+									if (groupValid(g)) *reinterpret_cast<Vec4<T> *>(smem + outOff + (dra + r) * kResRowBytes + outsw[g]) = o;
+								}
+							}
+						}
+					}
+		};
 		if (!kNoMfma) {
 			if (!primed) {
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -895,8 +964,30 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #pragma unroll
 						for (int c16 = 0; c16 < 2; ++c16) {
 							const int kf = ks32 * 2 + c16, sl = ph * 2 + c16;
-							setAccQuarter(acc[r], sl, mfma16(dx == 1 ? wm[dy * 4 + kf] : ws[dy * 8 + (dx >> 1) * 4 + kf], fb[set][need],
-							    accQuarter(first ? biasVec : acc[r], sl)));
+							acc[r].q[sl] = mfma16(dx == 1 ? wm[dy * 4 + kf] : ws[dy * 8 + (dx >> 1) * 4 + kf], fb[set][need],
+							    first ? biasVec.q[sl] : acc[r].q[sl]);
+							if (c16 == 0) {
+								// (the deferred epilogue's slot goes BETWEEN the group's two MFMAs: a 16-cycle MFMA leaves 8 cycles
+								// of issue, and behind the second one come the next fragment read and the next group's wait)
+								defSlot(pos, k, 0);
+								__builtin_amdgcn_sched_barrier(0);
+							}
+						}
+						defSlot(pos, k, 1);
+						if constexpr (KIND == 2) {
+							// The wave's LAST unit of the layer, second pixel half of (dx, ks32): vertical tap dy's two fragments
+							// have fed their last MFMA (group k = 2 dy + 1) -- the next layer's go into the same registers now,
+							// two loads behind this group instead of six in a row behind the step
+							if (streamNext && (m & 1) && (ROWS == 2 ? (k & 1) : true)) {
+								const int sdy = ROWS == 2 ? (k >> 1) : k;
+#pragma unroll
+								for (int c16 = 0; c16 < 2; ++c16) {
+									const int kf = ks32 * 2 + c16;
+									const Vec8<T> nf = loadWeightFrag(layer + 1, (sdy * 3 + dx) * 4 + kf);
+									if (dx == 1) wm[sdy * 4 + kf] = nf;
+									else ws[sdy * 8 + (dx >> 1) * 4 + kf] = nf;
+								}
+							}
 						}
 					}
 #else
@@ -905,41 +996,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					    (KIND != 1 && pos == P0 && dy == 0) ? biasVec : acc[r]);
 #endif
 					if (more && k < NR) issue(rowAddr, kOrder[pos + 1 < 12 ? pos + 1 : 11], set ^ 1, k);
-					if constexpr (DEF) {
-						// group (r, g) = step index, at most three plain VALU instructions behind each MFMA
-						// (tools/probes/mfma_valu_overlap.hip: that many issue in an MFMA's shadow for
-						// free, a fourth and every packed-f32 one cost their full issue time):
-						// MFMA 0..3 value i = accumulator (+ residual), 4 convert, 5 ReLU + write
-						const int j = pos - P0;
-						if (j < 8) {
-							const int r = j >> 2, g = j & 3;
-							if (k < 4) {
-								dv[k] = (r ? dacc1 : dacc0)[4 * g + k];
-								if constexpr (residual) {
-									dv[k] += static_cast<float>(rvNext[r][g][k]);
-									asm volatile("" : "+v"(dv[k]));  // (keeps the four adds scalar and in their slots)
-								}
-								if constexpr (LEAKY) {
-									// max(x, slope x), slope in [0, 1]; the instruction itself (fmaxf() canonicalises
-									// both operands first: two more instructions in a slot that has room for three)
-									const float t = dv[k] * p.slope;
-									asm volatile("v_max_f32 %0, %1, %2" : "=v"(dv[k]) : "v"(dv[k]), "v"(t));
-								}
-							} else if (k == 4) {
-								const Vec4<T> pk = pack4<T>(dv[0], dv[1], dv[2], dv[3]);
-								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
-								const u32x2d w = __builtin_bit_cast(u32x2d, pk);
-								dlo = w[0];
-								dhi = w[1];
-								asm volatile("" : "+v"(dlo), "+v"(dhi));
-							} else {
-								typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
-								const Vec4<T> pk = __builtin_bit_cast(Vec4<T>, u32x2d{dlo, dhi});
-								const Vec4<T> o = LEAKY ? pk : reluPacked<T>(pk);
-								if (groupValid(g)) *reinterpret_cast<Vec4<T> *>(smem + outOff + (dra + r) * kResRowBytes + outsw[g]) = o;
-							}
-						}
-					}
+#if !JU_TOWER_M16
+					defSlot(pos, k);
+#endif
 					if constexpr (kFetchRes) {
 						if (pos == P1 - 1 && k < 4) {
 							const int ra0 = 1 + 2 * unit;
@@ -964,18 +1023,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 						if (pos == 0) loadBias(layer + 1);
 #endif
 #if JU_TOWER_M16
-						if (m & 1) {  // both pixel halves of (dx, ks32) are through: its six fragments are dead
-#pragma unroll
-							for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-								for (int c16 = 0; c16 < 2; ++c16) {
-									const int kf = ((m >> 1) & 1) * 2 + c16;
-									const Vec8<T> nf = loadWeightFrag(layer + 1, (dy * 3 + dx) * 4 + kf);
-									if (dx == 1) wm[dy * 4 + kf] = nf;
-									else ws[dy * 8 + (dx >> 1) * 4 + kf] = nf;
-								}
-							}
-						}
+						// (the six fragments of (dx, ks32) go out from INSIDE the second pixel half's step, two behind each
+						// vertical tap's last MFMA group -- above, in the k loop -- not as six loads in a row here)
 #else
 #pragma unroll
 						for (int dy = 0; dy < 3; ++dy) {
@@ -1060,7 +1109,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	auto preRun = [&](auto inTag, auto outTag, auto loTag, auto hiTag, const int layer, const bool primedFirst)
 	                  __attribute__((always_inline)) {
 		constexpr int LO = decltype(loTag)::value, HI = decltype(hiTag)::value;
-		auto slot = [&](f32x16(&acc)[2], const int k) __attribute__((always_inline)) {
+		auto slot = [&](TowerAcc(&acc)[2], const int k) __attribute__((always_inline)) {
 			if (k < nPre) {
 				// (k + 1 < kPreRun folds at compile time: without it the last slot carries a never-taken branch that
 				// primes a successor nobody reads -- four LDS reads into dead registers which the halo loads then
@@ -1129,7 +1178,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 #endif
 			}
 		} else {
-		auto slot = [&](f32x16(&acc)[2], const int k) __attribute__((always_inline)) {
+		auto slot = [&](TowerAcc(&acc)[2], const int k) __attribute__((always_inline)) {
 			if (k < nPre) {
 				const bool nextIsPre = k + 1 < nPre;
 				const int nu = nextIsPre ? preFirst + 2 * (k + 1) : afterPre;
@@ -1142,7 +1191,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		if constexpr (kPreRun > 2) slot(accPre2, 2);
 		// (every finish segment primes its successor when there is one)
 		bool primed = nPre > 0 && afterPre >= 0 && !kNoMfma;
-		f32x16 acc[2];
+		TowerAcc acc[2];
 		for (int u = firstWhole; u >= 0;) {
 			const int nw = nextWhole(u);
 			const int nu = nw >= 0 ? nw : (mySingle ? np2 : -1);
