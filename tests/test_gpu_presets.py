@@ -265,7 +265,10 @@ def test_resident_tower_schedule_does_not_change_the_bytes(dtype, monkeypatch):
     from helpers import small_config
     cases.append((small_config(frame_height=34, frame_width=50, gen_blocks=3), 4))
     cases.append((small_config(frame_height=17, frame_width=33, gen_blocks=2), 3))
-    # a small frame whose regions all have the fast schedule's shape (rows 16 / 16 / 14, columns 32 / 32 / 6)
+    # a small frame whose regions all have the fast schedule's shape (rows 16 / 16 / 14, columns 32 / 32: since round 5 --
+    # the 16x16x32 form -- the fast schedule takes full-width regions only and writes its groups without a lane mask) ...
+    cases.append((small_config(frame_height=46, frame_width=64, gen_blocks=3), 4))
+    # ... and one with a ragged last column (32 / 32 / 6), which therefore runs the general schedule
     cases.append((small_config(frame_height=46, frame_width=70, gen_blocks=3), 4))
     # the LEAKY instantiation (`activation: lrelu`: 16-bit epoch beside the values, f32 LeakyReLU)
     cases.append((M.PRESETS["psp-quality-lrelu"], 3))
@@ -282,7 +285,7 @@ def test_resident_tower_schedule_does_not_change_the_bytes(dtype, monkeypatch):
             outs = {}
             # 0: the product (the FAST instantiation where every region has its shape: epilogues behind the
             # next unit's MFMAs), "general": the general schedule forced, 8: the plain schedule
-            fast_expected = (cfg.frame_height, cfg.frame_width) in ((270, 480), (46, 70))   # (ReLU and LeakyReLU models)
+            fast_expected = (cfg.frame_height, cfg.frame_width) in ((270, 480), (46, 64))   # (ReLU and LeakyReLU models)
             for variant in (0, "general", 8):
                 lib.ju_debug_set(b"tower_variant", 8 if variant == 8 else 0)
                 lib.ju_debug_set(b"tower_fast", 0 if variant == "general" else 1)
