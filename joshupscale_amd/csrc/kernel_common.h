@@ -42,18 +42,6 @@ __device__ __forceinline__ f32x4 mfma16(Vec8<f16> a, Vec8<f16> b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma16(Vec8<bf16> a, Vec8<bf16> b, f32x4 c) {
 	return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// quarter s (elements 4s .. 4s + 3) of a 16-float accumulator; s is a constant once the caller's loops are unrolled
-__device__ __forceinline__ f32x4 accQuarter(const f32x16 &v, const int s) {
-	if (s == 0) return __builtin_shufflevector(v, v, 0, 1, 2, 3);
-	if (s == 1) return __builtin_shufflevector(v, v, 4, 5, 6, 7);
-	if (s == 2) return __builtin_shufflevector(v, v, 8, 9, 10, 11);
-	return __builtin_shufflevector(v, v, 12, 13, 14, 15);
-}
-__device__ __forceinline__ void setAccQuarter(f32x16 &v, const int s, const f32x4 q) {
-#pragma unroll
-	for (int i = 0; i < 4; ++i) v[4 * s + i] = q[i];
-}
-
 // ReLU on values already rounded to the 16-bit type, as a packed signed-int16 max
 // with 0: a negative bf16/f16 (sign bit set, -0.0 included) is a negative int16.
 // Rounding keeps the sign, so this equals relu-then-round bit for bit, and it is 2

@@ -923,7 +923,8 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				const int m = kOrder[pos];
 				const int set = (pos - P0) & 1;
 				const bool more = (pos + 1 < P1);
-				const int dx = m >> 2, ks = m & 3;
+				const int dx = m >> 2;
+				[[maybe_unused]] const int ks = m & 3;  // (32x32x16 form: the 16-channel k-step)
 #pragma unroll
 				for (int k = 0; k < NM; ++k) {
 					// MFMA k = (dy, r): ROWS=2 -> (k>>1, k&1); ROWS=1 -> (k, 0); it needs
