@@ -101,6 +101,18 @@ JU_API void ju_destroy(ju_runtime *runtime);
  * error (JU_ERR_INVALID_ARGUMENT). */
 JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image *output);
 
+/* Frame look-ahead (no reference counterpart; the reference's callers hand over one frame at a time,
+ * avisynth_plugin/src/main.cc:113-144): `count` CONSECUTIVE frames of the stream in one synchronous call.
+ * outputs[i] receives exactly the bytes ju_process(inputs[i], outputs[i]) called in order would have written,
+ * and the recurrent state afterwards is the same -- but ALL inputs must hold their pixels when the call is made.
+ * The flow net reads LR frames only, never the HR state, so for JU_LOC_DEVICE frames the runtime computes the flow
+ * fields of up to 8 frames in ONE pass of the flow net's launches, which fill the chip where one frame's do not
+ * (-30 % flow time per frame at 480x270); warp, tower and tail stay strictly frame by frame.  Frames the pass
+ * cannot take (host frames, GL resources, a model without the one-launch flow plan) simply run as ju_process
+ * does.  For callers that can read ahead: a file transcoder, an AviSynth filter fetching child frames n .. n+3.
+ * JU_LOOKAHEAD=<1..8> caps the frames per pass (1 = off). */
+JU_API int ju_process_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image *outputs, int count);
+
 /* Asynchronous form for JU_LOC_DEVICE images: enqueues the same work on the
  * runtime's stream and returns; ju_synchronize() waits.  Frames are still
  * strictly ordered (the recurrence is carried by stream order). */

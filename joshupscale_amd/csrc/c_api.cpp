@@ -138,6 +138,20 @@ int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image *outpu
 	return guarded([&] { engineOf(runtime).process(toFrame(input), toFrame(output)); });
 }
 
+int ju_process_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image *outputs, int count) {
+	return guarded([&] {
+		if (count < 0 || (count > 0 && (inputs == nullptr || outputs == nullptr))) {
+			throw std::invalid_argument("ju_process_batch: NULL images or a negative count");
+		}
+		std::vector<ju::Frame> in(static_cast<std::size_t>(count)), out(static_cast<std::size_t>(count));
+		for (int i = 0; i < count; ++i) {
+			in[i] = toFrame(inputs + i);
+			out[i] = toFrame(outputs + i);
+		}
+		engineOf(runtime).processBatch(in.data(), out.data(), count);
+	});
+}
+
 int ju_enqueue(ju_runtime *runtime, const ju_image *input, const ju_image *output) {
 	return guarded([&] {
 		const ju::Frame in = toFrame(input), out = toFrame(output);

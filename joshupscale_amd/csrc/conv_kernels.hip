@@ -586,6 +586,7 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 }  // namespace
 
 void launchConv(DType dt, const ConvParams &p, hipStream_t stream) {
+	if (p.items > 1) throw std::invalid_argument("launchConv: no look-ahead (items > 1) form of this kernel");
 	if (dt == kF16) launchConvT<f16>(p, stream);
 	else launchConvT<bf16>(p, stream);
 }

@@ -246,7 +246,7 @@ void Engine::buildWeights(const ModelFile &model) {
 
 void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
     const std::string &wname, Operand in, Operand res, Operand out, int H, int W,
-    bool relu, bool outHead, bool tower, bool pool, bool upsample) {
+    bool relu, bool outHead, bool tower, bool pool, bool upsample, ItemStride item) {
 	auto it = m_Convs.find(wname);
 	if (it == m_Convs.end()) throw std::logic_error("missing conv weights " + wname);
 	const ConvWeights &cw = it->second;
@@ -286,7 +286,15 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 	const DType dt = m_DType;
 	Step s;
 	s.tag = tag;
-	s.flops = 2.0 * H * W * cw.taps * cw.cinReal * cw.cout;
+	s.flops = 2.0 * H * W * cw.taps * cw.cinReal * cw.cout * std::max(item.items, 1);
+	if (item.items > 1) {  // a look-ahead launch: the layer of `items` frames (split-K convolutions only)
+		p.items = item.items;
+		p.inItemBytes = item.in;
+		p.outItemBytes = item.out;
+		if (tower || !(cw.splitK && convSplitKSupported(p))) {
+			throw std::logic_error("look-ahead: no batched form of " + wname);
+		}
+	}
 	if (tower) {
 		s.run = [dt, p](hipStream_t st) { launchConvTower(dt, p, st); };
 	} else if (cw.splitK && convSplitKSupported(p)) {
@@ -297,6 +305,210 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 		s.run = [dt, p](hipStream_t st) { launchConv(dt, p, st); };
 	}
 	prog->push_back(std::move(s));
+}
+
+// The flow auto-encoder (models.py:334-481) as launches: `items` = 1 for the per-frame program of binding set `set`,
+// > 1 for a look-ahead pass -- the same launches over `items` consecutive frames (grid.z), on the batch tensors, the
+// first block reading the frames of m_BatchIO (submitBatch).  A look-ahead pass exists only where every launch of
+// the plan has an item dimension (the one-launch blocks and the split-K convolutions): std::logic_error otherwise.
+void Engine::addFlowAutoencoder(std::vector<Step> *progOut, int set, int items) {
+	std::vector<Step> &prog = *progOut;
+	const ModelConfig &c = m_Config;
+	const DType dt = m_DType;
+	const bool batch = items > 1;
+	const int H = c.frameHeight, W = c.frameWidth;
+	const int PH = c.paddedHeight(), PW = c.paddedWidth();
+	const int padTop = (PH - H) / 2, padLeft = (PW - W) / 2;  // models.py:783-787
+	const FrameIO *io = &m_IO;
+	const FrameIO *batchIO = m_BatchIO;
+	const void *packedIn = m_Packed[set].get();
+	void *packedOut = m_Packed[set ^ 1].get();
+	const int nIn = c.numFlowInputs;
+	const unsigned *sums = c.normalizeBrightness ? m_TailB2.as<unsigned>() + 4 : nullptr;
+	auto T = [&](const std::string &n) -> void * { return (batch ? m_BatchTensors : m_Tensors).at(n).buf.get(); };
+	auto Op = [&](const std::string &n) { return batch ? Operand{T(n), 0} : operand(n); };
+	// bytes of ONE frame's tensor: the item stride of a look-ahead launch
+	auto itemBytes = [&](const std::string &n) -> long {
+		const Tensor &t = m_Tensors.at(n);
+		return static_cast<long>(t.count) * (t.isF32 ? 4 : 2);
+	};
+	auto noBatch = [&](const char *what) {
+		if (batch) throw std::logic_error(std::string("look-ahead: no batched form of ") + what);
+	};
+	const Operand none{};
+	const bool packInBlock = flowPacksInBlock();
+	if (batch && (!packInBlock || sums != nullptr)) noBatch("the input packing");
+	Operand cur{packedOut, 0};
+	long curItem = 0;  // item stride of `cur`
+	int h = PH, w = PW;
+	bool flowHeadDone = false;  // the fused head block wrote the flow tensor
+	const int nb = static_cast<int>(c.flowFilters.size()) / 2;
+	// the decoder's bilinear x2 is folded into the staging of the conv that follows
+	// when that conv stages its input once (cout = 32: every cout-group workgroup
+	// would repeat the expansion; measured: a loss already with two groups) and
+	// reads 64-channel chunks
+	auto fusesUpsample = [&](const std::string &next, int cin) {
+		auto it = m_Convs.find(next);
+		return m_FusedUpsample && it != m_Convs.end() && cin % 64 == 0 && it->second.nb == 1 &&
+		       it->second.cout <= 32;
+	};
+	// one launch for a whole block (both convs, pool, preceding upsample) where planned
+	const int flowAct = c.flowActivation == 1 ? 2 : 1;
+	auto addBlockStep = [&](const std::string &convA, const std::string &convB, const void *in, long inItem,
+	                        const std::string &outName, int bh, int bw, bool ups, bool pool, bool outHead, int act2) {
+		const ConvWeights &wa = m_Convs.at(convA), &wb = m_Convs.at(convB);
+		FlowBlockLaunch fb{};
+		fb.in = in;
+		fb.w1 = wa.w.get();
+		fb.b1 = wa.bias.as<float>();
+		fb.w2 = wb.w.get();
+		fb.b2 = wb.bias.as<float>();
+		fb.out = T(outName);
+		fb.H = bh;
+		fb.W = bw;
+		fb.cin = wa.cinP;
+		fb.cmid = wa.cout;
+		fb.upsample = ups;
+		fb.pool = pool;
+		fb.outHead = outHead;
+		fb.act1 = flowAct;
+		fb.act2 = act2;
+		fb.slope = c.flowNegativeSlope;
+		fb.items = items;
+		fb.inItemBytes = inItem;
+		fb.outItemBytes = itemBytes(outName);
+		const double flops =
+		    items * 2.0 * bh * bw * 9.0 * (double(wa.cinReal) * wa.cout + double(wb.cinReal) * wb.cout);
+		if (packInBlock && convA == "flow/block_1/conv_1") {
+			fb.packPrev = packedIn;
+			fb.packOut = packedOut;
+			fb.frameH = H;
+			fb.frameW = W;
+			fb.padTop = padTop;
+			fb.padLeft = padLeft;
+			fb.numInputs = nIn;
+			fb.sums = sums;
+			prog.push_back({"flow", flops, [dt, fb, io, batchIO, items](hipStream_t s) {
+				                FlowBlockLaunch f = fb;  // the caller's frames are known at launch time only
+				                f.packFrame = io->in;
+				                f.packFrameStride = io->inStride;
+				                for (int i = 0; i < items && items > 1; ++i) {
+					                f.packFrames[i] = batchIO[i].in;
+					                f.packFrameStrides[i] = batchIO[i].inStride;
+				                }
+				                launchFlowBlock(dt, f, s);
+			                }});
+			return;
+		}
+		prog.push_back({"flow", flops, [dt, fb](hipStream_t s) { launchFlowBlock(dt, fb, s); }});
+	};
+	auto unitUpsIn = [&](int k) { return k < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[k].fused && m_FlowUnits[k].upsIn; };
+	bool upsampleNext = false;  // `cur` is half resolution: the next conv upsamples it
+	for (int i = 0; i < 2 * nb; ++i) {
+		const std::string n = "flow/block_" + std::to_string(i + 1);
+		const int f = c.flowFilters[i];
+		if (m_FlowUnits[i].fused) {
+			const bool pool = i < nb;
+			if (upsampleNext != m_FlowUnits[i].upsIn) throw std::logic_error("flow plan out of step");
+			addBlockStep(n + "/conv_1", n + "/conv_2", cur.ptr, curItem, pool ? n + "/resample" : n + "/a_2", h, w,
+			    upsampleNext, pool, false, flowAct);
+			upsampleNext = false;
+			if (pool) {
+				h /= 2;
+				w /= 2;
+				cur = Operand{T(n + "/resample"), 0};
+				curItem = itemBytes(n + "/resample");
+			} else {
+				const void *src = T(n + "/a_2");
+				void *dst = T(n + "/resample");
+				if (unitUpsIn(i + 1)) {  // the next unit expands it while staging
+					upsampleNext = true;
+					cur = Op(n + "/a_2");
+					curItem = itemBytes(n + "/a_2");
+				} else {
+					const std::string next = i + 1 < 2 * nb ? "flow/block_" + std::to_string(i + 2) + "/conv_1"
+					                         : (c.flowFilters.size() % 2 ? "flow/conv_1" : "");
+					if (fusesUpsample(next, f) && !(i + 1 < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[i + 1].fused)) {
+						upsampleNext = true;
+						cur = Op(n + "/a_2");
+						curItem = itemBytes(n + "/a_2");
+					} else {
+						noBatch("the upsampling launch");
+						prog.push_back({"flow", 0.0,
+						    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
+						cur = Operand{dst, 0};
+					}
+				}
+				h *= 2;
+				w *= 2;
+			}
+			continue;
+		}
+		const ItemStride st1{items, curItem, itemBytes(n + "/a_1")};
+		addConvStep(&prog, "flow", n + "/conv_1", cur, none, Op(n + "/a_1"), h, w, true, false,
+		    false, false, upsampleNext, st1);
+		upsampleNext = false;
+		const bool fusePool = i < nb && m_FusedPool;
+		const std::string out2 = fusePool ? n + "/resample" : n + "/a_2";
+		const ItemStride st2{items, itemBytes(n + "/a_1"), itemBytes(out2)};
+		addConvStep(&prog, "flow", n + "/conv_2", Op(n + "/a_1"), none, Op(out2), h, w, true, false, false, fusePool,
+		    false, st2);
+		const void *src = T(n + "/a_2");  // dense tensors
+		void *dst = T(n + "/resample");
+		if (i < nb) {
+			if (!fusePool) {
+				noBatch("the pooling launch");
+				prog.push_back({"flow", 0.0,
+				    [=](hipStream_t s) { launchMaxPool2(dt, src, dst, h, w, f, s); }});
+			}
+			h /= 2;
+			w /= 2;
+			cur = Operand{dst, 0};
+			curItem = itemBytes(n + "/resample");
+		} else {
+			const std::string next = i + 1 < 2 * nb ? "flow/block_" + std::to_string(i + 2) + "/conv_1"
+			                         : (c.flowFilters.size() % 2 ? "flow/conv_1" : "");  // not the head
+			const bool nextFused = i + 1 < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[i + 1].fused;
+			if (unitUpsIn(i + 1) || (!nextFused && fusesUpsample(next, f))) {
+				upsampleNext = true;
+				cur = Op(n + "/a_2");
+				curItem = itemBytes(n + "/a_2");
+			} else {
+				noBatch("the upsampling launch");
+				prog.push_back({"flow", 0.0,
+				    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
+				cur = Operand{dst, 0};
+			}
+			h *= 2;
+			w *= 2;
+		}
+	}
+	if (c.flowFilters.size() % 2) {
+		if (m_FlowUnits[2 * nb].fused) {  // flow/conv_1 + flow/conv_2 -> the f16 flow head, one launch
+			if (upsampleNext != m_FlowUnits[2 * nb].upsIn) throw std::logic_error("flow plan out of step");
+			addBlockStep("flow/conv_1", "flow/conv_2", cur.ptr, curItem, "flow", h, w, upsampleNext, false, true, 0);
+			upsampleNext = false;
+			flowHeadDone = true;
+		} else {
+			noBatch("the head convolutions");
+			addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/a_1"), h, w, true, false,
+			    false, false, upsampleNext);
+			upsampleNext = false;
+			cur = Op("flow/a_1");
+		}
+	}
+	if (upsampleNext) throw std::logic_error("flow head cannot take a half-resolution input");
+	if (!flowHeadDone) {
+		noBatch("the head convolution");
+		addConvStep(&prog, "flow", "flow/conv_2", cur, none, Op("flow"), h, w, false, true);
+	}
+}
+
+// the flow net's first block builds the packed tensor itself when it runs as one launch
+bool Engine::flowPacksInBlock() const {
+	const ModelConfig &c = m_Config;
+	return m_PackInBlock && c.flowArch == 0 && !m_FlowUnits.empty() && m_FlowUnits[0].fused &&
+	       3 * c.numFlowInputs <= 16 && !c.flowFilters.empty() && c.flowFilters[0] == 32;
 }
 
 void Engine::buildProgram(int set) {
@@ -310,8 +522,11 @@ void Engine::buildProgram(int set) {
 	const FrameIO *io = &m_IO;  // read at launch time: staging buffers or the caller's
 	const void *packedIn = m_Packed[set].get();
 	void *packedOut = m_Packed[set ^ 1].get();
-	const void *stateIn = m_State[set].get();
-	void *stateOut = m_State[set ^ 1].get();
+	// the recurrent state this program reads / writes: m_State[set] -> m_State[set ^ 1], read at launch (capture)
+	// time -- a look-ahead pass binds its frames' programs to its own chain of state buffers (submitBatch)
+	m_StateBind[set].in = m_State[set].get();
+	m_StateBind[set].out = m_State[set ^ 1].get();
+	const StateBind *sb = &m_StateBind[set];
 	const int nIn = c.numFlowInputs;
 	auto T = [&](const std::string &n) -> void * { return m_Tensors.at(n).buf.get(); };
 	auto Op = [&](const std::string &n) { return operand(n); };
@@ -326,8 +541,7 @@ void Engine::buildProgram(int set) {
 		    [=](hipStream_t s) { launchFrameSums(io->in, io->inStride, H, W, sumsOut, s); }});
 	}
 	// (the flow net's first block builds the packed tensor itself when it runs as one launch)
-	const bool packInBlock = m_PackInBlock && c.flowArch == 0 && !m_FlowUnits.empty() && m_FlowUnits[0].fused &&
-	                         3 * nIn <= 16 && !c.flowFilters.empty() && c.flowFilters[0] == 32;
+	const bool packInBlock = flowPacksInBlock();
 	if (!packInBlock) {
 		prog.push_back({"pack", 0.0, [=](hipStream_t s) {
 			                launchPackFrames(dt, io->in, io->inStride, packedIn, packedOut, H, W, PH, PW,
@@ -361,142 +575,8 @@ void Engine::buildProgram(int set) {
 	int h = PH, w = PW;
 	bool flowHeadDone = false;  // the fused head block wrote the flow tensor
 	if (c.flowArch == 0) {
-		const int nb = static_cast<int>(c.flowFilters.size()) / 2;
-		// the decoder's bilinear x2 is folded into the staging of the conv that follows
-		// when that conv stages its input once (cout = 32: every cout-group workgroup
-		// would repeat the expansion; measured: a loss already with two groups) and
-		// reads 64-channel chunks
-		auto fusesUpsample = [&](const std::string &next, int cin) {
-			auto it = m_Convs.find(next);
-			return m_FusedUpsample && it != m_Convs.end() && cin % 64 == 0 && it->second.nb == 1 &&
-			       it->second.cout <= 32;
-		};
-		// one launch for a whole block (both convs, pool, preceding upsample) where planned
-		const int flowAct = c.flowActivation == 1 ? 2 : 1;
-		auto addBlockStep = [&](const std::string &convA, const std::string &convB, const void *in, void *out,
-		                        int bh, int bw, bool ups, bool pool, bool outHead, int act2) {
-			const ConvWeights &wa = m_Convs.at(convA), &wb = m_Convs.at(convB);
-			FlowBlockLaunch fb{};
-			fb.in = in;
-			fb.w1 = wa.w.get();
-			fb.b1 = wa.bias.as<float>();
-			fb.w2 = wb.w.get();
-			fb.b2 = wb.bias.as<float>();
-			fb.out = out;
-			fb.H = bh;
-			fb.W = bw;
-			fb.cin = wa.cinP;
-			fb.cmid = wa.cout;
-			fb.upsample = ups;
-			fb.pool = pool;
-			fb.outHead = outHead;
-			fb.act1 = flowAct;
-			fb.act2 = act2;
-			fb.slope = c.flowNegativeSlope;
-			const double flops = 2.0 * bh * bw * 9.0 * (double(wa.cinReal) * wa.cout + double(wb.cinReal) * wb.cout);
-			if (packInBlock && convA == "flow/block_1/conv_1") {
-				fb.packPrev = packedIn;
-				fb.packOut = packedOut;
-				fb.frameH = H;
-				fb.frameW = W;
-				fb.padTop = padTop;
-				fb.padLeft = padLeft;
-				fb.numInputs = nIn;
-				fb.sums = sums;
-				prog.push_back({"flow", flops, [dt, fb, io](hipStream_t s) {
-					                FlowBlockLaunch f = fb;  // the caller's frame is known at launch time only
-					                f.packFrame = io->in;
-					                f.packFrameStride = io->inStride;
-					                launchFlowBlock(dt, f, s);
-				                }});
-				return;
-			}
-			prog.push_back({"flow", flops, [dt, fb](hipStream_t s) { launchFlowBlock(dt, fb, s); }});
-		};
-		auto unitUpsIn = [&](int k) { return k < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[k].fused && m_FlowUnits[k].upsIn; };
-		bool upsampleNext = false;  // `cur` is half resolution: the next conv upsamples it
-		for (int i = 0; i < 2 * nb; ++i) {
-			const std::string n = "flow/block_" + std::to_string(i + 1);
-			const int f = c.flowFilters[i];
-			if (m_FlowUnits[i].fused) {
-				const bool pool = i < nb;
-				if (upsampleNext != m_FlowUnits[i].upsIn) throw std::logic_error("flow plan out of step");
-				addBlockStep(n + "/conv_1", n + "/conv_2", cur.ptr, T(pool ? n + "/resample" : n + "/a_2"), h, w,
-				    upsampleNext, pool, false, flowAct);
-				upsampleNext = false;
-				if (pool) {
-					h /= 2;
-					w /= 2;
-					cur = Operand{T(n + "/resample"), 0};
-				} else {
-					const void *src = T(n + "/a_2");
-					void *dst = T(n + "/resample");
-					if (unitUpsIn(i + 1)) {  // the next unit expands it while staging
-						upsampleNext = true;
-						cur = Op(n + "/a_2");
-					} else {
-						const std::string next = i + 1 < 2 * nb ? "flow/block_" + std::to_string(i + 2) + "/conv_1"
-						                         : (c.flowFilters.size() % 2 ? "flow/conv_1" : "");
-						if (fusesUpsample(next, f) && !(i + 1 < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[i + 1].fused)) {
-							upsampleNext = true;
-							cur = Op(n + "/a_2");
-						} else {
-							prog.push_back({"flow", 0.0,
-							    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
-							cur = Operand{dst, 0};
-						}
-					}
-					h *= 2;
-					w *= 2;
-				}
-				continue;
-			}
-			addConvStep(&prog, "flow", n + "/conv_1", cur, none, Op(n + "/a_1"), h, w, true, false,
-			    false, false, upsampleNext);
-			upsampleNext = false;
-			const bool fusePool = i < nb && m_FusedPool;
-			addConvStep(&prog, "flow", n + "/conv_2", Op(n + "/a_1"), none,
-			    Op(fusePool ? n + "/resample" : n + "/a_2"), h, w, true, false, false, fusePool);
-			const void *src = T(n + "/a_2");  // dense tensors
-			void *dst = T(n + "/resample");
-			if (i < nb) {
-				if (!fusePool) {
-					prog.push_back({"flow", 0.0,
-					    [=](hipStream_t s) { launchMaxPool2(dt, src, dst, h, w, f, s); }});
-				}
-				h /= 2;
-				w /= 2;
-				cur = Operand{dst, 0};
-			} else {
-				const std::string next = i + 1 < 2 * nb ? "flow/block_" + std::to_string(i + 2) + "/conv_1"
-				                         : (c.flowFilters.size() % 2 ? "flow/conv_1" : "");  // not the head
-				const bool nextFused = i + 1 < static_cast<int>(m_FlowUnits.size()) && m_FlowUnits[i + 1].fused;
-				if (unitUpsIn(i + 1) || (!nextFused && fusesUpsample(next, f))) {
-					upsampleNext = true;
-					cur = Op(n + "/a_2");
-				} else {
-					prog.push_back({"flow", 0.0,
-					    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
-					cur = Operand{dst, 0};
-				}
-				h *= 2;
-				w *= 2;
-			}
-		}
-		if (c.flowFilters.size() % 2) {
-			if (m_FlowUnits[2 * nb].fused) {  // flow/conv_1 + flow/conv_2 -> the f16 flow head, one launch
-				if (upsampleNext != m_FlowUnits[2 * nb].upsIn) throw std::logic_error("flow plan out of step");
-				addBlockStep("flow/conv_1", "flow/conv_2", cur.ptr, T("flow"), h, w, upsampleNext, false, true, 0);
-				upsampleNext = false;
-				flowHeadDone = true;
-			} else {
-				addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/a_1"), h, w, true, false,
-				    false, false, upsampleNext);
-				upsampleNext = false;
-				cur = Op("flow/a_1");
-			}
-		}
-		if (upsampleNext) throw std::logic_error("flow head cannot take a half-resolution input");
+		addFlowAutoencoder(&prog, set, 1);
+		flowHeadDone = true;  // (or its own head launch: addFlowAutoencoder)
 	} else if (m_ResidentFlow) {
 		// flow-resnet body = conv_1 + residual blocks, 64 filters: ONE launch of the
 		// resident tower kernel (own mailbox and publish counters)
@@ -548,7 +628,8 @@ void Engine::buildProgram(int set) {
 	if (!flowHeadDone) addConvStep(&prog, "flow", "flow/conv_2", cur, none, Op("flow"), h, w, false, true);
 	// ---- warp + space-to-depth + concat ----
 	{
-		const void *flow = T("flow");
+		m_FlowCur = T("flow");
+		const void *const *flowSlot = &m_FlowCur;  // (a look-ahead pass points it at its frame's field)
 		// the generator input lives in the tower layout (zero border = conv_1's padding), so that conv_1 can run
 		// on the tower's per-layer kernel wherever it is a launch of its own (8-bit towers, per-block towers)
 		const Operand genInOp = Op("gen_in");
@@ -556,7 +637,7 @@ void Engine::buildProgram(int set) {
 		const int genPitch = genInOp.pitch;
 		void *preWarp = c.temporalStrength > 0.0f ? T("pre_warp") : nullptr;
 		prog.push_back({"warp", 0.0, [=](hipStream_t s) {
-			                launchWarpPack(dt, stateIn, flow, io->in, io->inStride, genIn, genPitch, H, W, PW,
+			                launchWarpPack(dt, sb->in, *flowSlot, io->in, io->inStride, genIn, genPitch, H, W, PW,
 			                    padTop, padLeft, sums, preWarp, s);
 		                }});
 	}
@@ -637,7 +718,7 @@ void Engine::buildProgram(int set) {
 			rp.tailB1 = m_Convs.at("generator/conv_trans_1").bias.as<float>();
 			rp.tailW2 = m_TailW2Frag.get();
 			rp.tailB2 = m_TailB2.as<float>();
-			rp.state = stateOut;
+			rp.state = nullptr;  // (sb->out, at launch time)
 			rp.sums = sums;
 		}
 		TailFusedLaunch tf{};  // (debug variants of the tower kernel have no fused-tail form: separate launch)
@@ -650,7 +731,7 @@ void Engine::buildProgram(int set) {
 			tf.b1 = cw.bias.as<float>();
 			tf.w2 = m_TailW2Frag.get();
 			tf.b2 = m_TailB2.as<float>();
-			tf.state = stateOut;
+			tf.state = nullptr;  // (sb->out, at launch time)
 			tf.sums = sums;
 			tf.H = H;
 			tf.W = W;
@@ -667,6 +748,7 @@ void Engine::buildProgram(int set) {
 				    r.tailW1 = nullptr;
 				    launchResidentTower(dt, r, s);
 				    TailFusedLaunch t = tf;
+				    t.state = sb->out;
 				    t.frame = io->in;
 				    t.frameStride = io->inStride;
 				    t.outU8 = io->out;
@@ -675,6 +757,7 @@ void Engine::buildProgram(int set) {
 				    return;
 			    }
 			    if (r.tailW1 != nullptr) {  // caller's frames are known at launch time only
+				    r.state = sb->out;
 				    r.frame = io->in;
 				    r.frameStride = io->inStride;
 				    r.outU8 = io->out;
@@ -769,13 +852,14 @@ void Engine::buildProgram(int set) {
 		tf.b1 = cw.bias.as<float>();
 		tf.w2 = m_TailW2Frag.get();
 		tf.b2 = m_TailB2.as<float>();
-		tf.state = stateOut;
+		tf.state = nullptr;  // (sb->out, at launch time)
 		tf.sums = sums;
 		tf.H = H;
 		tf.W = W;
 		tf.slope = c.genActivation == 1 ? c.genNegativeSlope : -1.0f;
 		prog.push_back({"tail", 2.0 * H * W * (64.0 * 128 + 4 * 4 * 32 * 3), [=](hipStream_t s) {
 			                TailFusedLaunch t = tf;
+			                t.state = sb->out;
 			                t.frame = io->in;
 			                t.frameStride = io->inStride;
 			                t.outU8 = io->out;
@@ -789,7 +873,7 @@ void Engine::buildProgram(int set) {
 		const float *w2 = m_TailW2.as<float>();
 		const float *b2 = m_TailB2.as<float>();
 		prog.push_back({"tail", 2.0 * (2 * H) * (2 * W) * 4 * 32 * 3, [=](hipStream_t s) {
-			                launchTail(dt, y, w2, b2, io->in, io->inStride, stateOut, io->out,
+			                launchTail(dt, y, w2, b2, io->in, io->inStride, sb->out, io->out,
 			                    io->outStride, H, W, sums, s);
 		                }});
 	}
@@ -801,7 +885,7 @@ void Engine::buildProgram(int set) {
 		const TemporalParams tp{c.temporalStrength, c.temporalThreshold, c.temporalGain, c.temporalWindow,
 		    c.temporalL2 ? 1 : 0, c.temporalLimit ? 1 : 0, c.temporalLuma ? 1 : 0};
 		prog.push_back({"temporal", 0.0, [=](hipStream_t s) {
-			                launchTemporalFilter(stateOut, preWarp, io->out, io->outStride, H, W, sums,
+			                launchTemporalFilter(sb->out, preWarp, io->out, io->outStride, H, W, sums,
 			                    acc, tp, s);
 		                }});
 	}
@@ -998,6 +1082,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_DirectGraph = !(directGraph && directGraph[0] == '0');
 	if (const char *spin = std::getenv("JU_SYNC_SPIN_US")) m_SpinUs = static_cast<unsigned>(std::atoi(spin));
 	if (const char *pin = std::getenv("JU_PIN_HOST")) m_PinHost = pin[0] == '1';  // (opt-in: engine.h)
+	// frames per look-ahead pass of processBatch (1 = frame by frame)
+	if (const char *la = std::getenv("JU_LOOKAHEAD")) m_BatchMax = std::min(std::max(std::atoi(la), 1), kFlowBatchMax);
 
 	// From here on this engine launches kernels.  It joins its device's chain first and holds
 	// the chain's lock until it is ready: the eager passes below run the resident tower, which
@@ -1142,6 +1228,7 @@ void Engine::fallbackToLayers(unsigned code) {
 	m_Resident = false;
 	m_ResidentFlow = false;
 	m_DirectGraphs.clear();  // they replay the resident program
+	dropBatchGraphs();
 	// the aborted launch left the slot epochs of the regions out of step: start them over
 	m_ResMail.zeroAsync(m_Stream);
 	m_ResFlags.zeroAsync(m_Stream);
@@ -1184,6 +1271,7 @@ void Engine::restoreResident() {
 	m_ResidentFlow = m_ResidentFlowCapable;
 	m_CleanFrames = 0;
 	m_DirectGraphs.clear();
+	dropBatchGraphs();
 	m_ResMail.zeroAsync(m_Stream);
 	m_ResFlags.zeroAsync(m_Stream);
 	m_FlowMail.zeroAsync(m_Stream);
@@ -1476,6 +1564,181 @@ int Engine::prepareFrames(const Frame &in, const Frame &out) {
 	return captured;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Frame look-ahead.  The flow net reads LR frames only -- never the HR state (models.py:795-800: its input is the
+// packed history of the last num_flow_inputs frames) -- so the flow fields of n consecutive frames can be computed
+// before the first of them is upscaled: ONE pass of the flow net's eight launches over n frames instead of n passes.
+// At 480x270 those launches fill a third to a half of the chip each (136-240 workgroups on 256 CUs, a few hundred
+// microseconds of latency chains): n = 4 takes the flow net from 105 to ~70 us per frame
+// (tools/probes/flow_batch_estimate.py, profiles/r05_flow_batch_estimate.txt).  The recurrent part -- warp, tower,
+// tail -- stays strictly frame by frame, and every frame's bytes are those of process(): the same kernels add the
+// same terms in the same order whatever the launch's size.
+//
+// State.  Frame i of a pass reads the state frame i - 1 wrote; the pass owns the n - 1 buffers in between, reads
+// m_State[set] and leaves the last frame's state in m_State[set ^ 1] and the last history in m_Packed[set ^ 1], as
+// ONE process() call would: the pass flips the binding set once, and -- since nothing it wrote is read before the
+// pass -- a pass that failed (resident tower: bounded wait expired) can be run again frame by frame.
+// ---------------------------------------------------------------------------------------------------------------
+bool Engine::batchPlanned(int items) {
+	if (m_BatchUnsupported || m_Calibrate || m_Config.flowArch != 0 || !flowPacksInBlock() || m_Config.normalizeBrightness) {
+		return false;
+	}
+	if (items <= m_BatchCap && m_BatchFlow.count({items, 0})) return true;
+	try {
+		if (items > m_BatchCap) {
+			// (the tensors of every pass so far are too small: start over)
+			m_Stream.synchronize();
+			m_BatchGraphs.clear();
+			m_BatchFlow.clear();
+			m_BatchTensors.clear();
+			const int cap = std::max(items, std::min(4, kFlowBatchMax));
+			for (const auto &kv : m_Tensors) {
+				const bool flowTensor = kv.first == "flow" || kv.first.rfind("flow/", 0) == 0;
+				if (!flowTensor) continue;
+				Tensor t;
+				t.count = kv.second.count * cap;
+				t.isF32 = kv.second.isF32;
+				t.isState = kv.second.isState;
+				t.buf = DeviceBuffer(t.count * (t.isF32 ? 4 : 2));
+				m_BatchTensors.emplace(kv.first, std::move(t));
+			}
+			for (int i = 0; i + 1 < cap; ++i) {
+				if (!m_BatchState[i].get()) m_BatchState[i] = DeviceBuffer(m_State[0].bytes());
+			}
+			m_BatchCap = cap;
+		}
+		for (int set = 0; set < 2; ++set) {
+			std::vector<Step> prog;
+			addFlowAutoencoder(&prog, set, items);
+			m_BatchFlow[{items, set}] = std::move(prog);
+		}
+		return true;
+	} catch (const std::logic_error &e) {
+		logMessage(LogLevel::Info, "Engine", std::string("frame look-ahead is off for this model: ") + e.what());
+		m_BatchUnsupported = true;
+		m_BatchFlow.clear();
+		m_BatchTensors.clear();
+		m_BatchCap = 0;
+		return false;
+	}
+}
+
+void Engine::dropBatchGraphs() {
+	m_BatchGraphs.clear();
+}
+
+// One look-ahead pass over frames [0, n): enqueue only.  The caller holds nothing; on return the binding set is
+// flipped ONCE (see above).
+void Engine::submitBatch(const Frame *in, const Frame *out, int n) {
+	const int set = m_Idx;
+	std::vector<DirectKey> key(static_cast<std::size_t>(n));
+	for (int i = 0; i < n; ++i) {
+		m_BatchIO[i].in = static_cast<const std::uint8_t *>(in[i].ptr);
+		m_BatchIO[i].inStride = in[i].stride;
+		m_BatchIO[i].out = static_cast<std::uint8_t *>(out[i].ptr);
+		m_BatchIO[i].outStride = out[i].stride;
+		key[i] = DirectKey{in[i].ptr, in[i].stride, out[i].ptr, out[i].stride, set};
+	}
+	const std::vector<Step> &flow = m_BatchFlow.at({n, set});
+	const long flowItem = static_cast<long>(m_Tensors.at("flow").count) * 2;
+	const unsigned char *flowBase = m_BatchTensors.at("flow").buf.as<unsigned char>();
+	// the pass's launches, in stream order: the flow net over all frames, then frame by frame the rest of the
+	// per-frame program of this binding set, bound to the frame's buffers, flow field and link of the state chain
+	auto runAll = [&] {
+		const FrameIO keepIO = m_IO;
+		const StateBind keepBind = m_StateBind[set];
+		const void *keepFlow = m_FlowCur;
+		struct Restore {
+			std::function<void()> f;
+			~Restore() { f(); }
+		} restore{[&] {
+			m_IO = keepIO;
+			m_StateBind[set] = keepBind;
+			m_FlowCur = keepFlow;
+		}};
+		for (const Step &st : flow) st.run(m_Stream);
+		for (int i = 0; i < n; ++i) {
+			m_IO = m_BatchIO[i];
+			m_FlowCur = flowBase + i * flowItem;
+			m_StateBind[set].in = i == 0 ? keepBind.in : m_BatchState[i - 1].get();
+			m_StateBind[set].out = i + 1 == n ? keepBind.out : m_BatchState[i].get();
+			for (const Step &st : m_Program[set]) {
+				if (st.tag != "flow" && st.tag != "pack") st.run(m_Stream);
+			}
+		}
+	};
+	{
+		std::unique_lock<std::mutex> chain = chainBegin();
+		bool replayed = false;
+		if (m_UseGraph && m_DirectGraph) {
+			auto it = m_BatchGraphs.find(key);
+			if (it == m_BatchGraphs.end()) {
+				if (m_BatchGraphs.size() >= kMaxBatchGraphs) {  // least recently used out
+					auto victim = m_BatchGraphs.begin();
+					for (auto j = m_BatchGraphs.begin(); j != m_BatchGraphs.end(); ++j) {
+						if (j->second.lastUse < victim->second.lastUse) victim = j;
+					}
+					m_BatchGraphs.erase(victim);
+				}
+				it = m_BatchGraphs.emplace(key, DirectEntry{}).first;
+			}
+			DirectEntry &e = it->second;
+			e.lastUse = ++m_DirectClock;
+			// (first sighting: eager -- it also sets the dynamic-LDS attribute of a tile height this pass's launch
+			// sizes choose for the first time, which must not happen inside a capture; second: capture and replay)
+			if (!e.graph.valid() && ++e.seen >= 2) {
+				e.graph = GraphExec::capture(m_Stream, runAll);
+				++m_InlineCaptures;
+			}
+			if (e.graph.valid()) {
+				e.graph.launch(m_Stream);
+				++m_GraphReplays;
+				replayed = true;
+			}
+		}
+		if (!replayed) {
+			runAll();
+			++m_EagerRuns;
+		}
+		chainEnd(chain);
+	}
+	m_Idx = set ^ 1;
+	m_BatchFrames += static_cast<std::uint64_t>(n);
+}
+
+void Engine::processBatch(const Frame *in, const Frame *out, int count) {
+	if (count < 0 || (count > 0 && (in == nullptr || out == nullptr))) throw std::invalid_argument("processBatch: bad arguments");
+	DeviceGuard g(m_Device);
+	int i = 0;
+	while (i < count) {
+		// the longest run of frames from i that can go as one pass
+		int n = 0;
+		while (i + n < count && n < m_BatchMax && directEligible(in[i + n], out[i + n])) ++n;
+		if (n < 2 || !batchPlanned(n)) {
+			process(in[i], out[i]);
+			++i;
+			continue;
+		}
+		const int set = m_Idx;
+		submitBatch(in + i, out + i, n);
+		m_Stream.synchronizeSpin(m_SpinUs);
+		if (const unsigned code = takeResidentError()) {
+			// nothing the pass wrote was one of its inputs (see above): the same frames again, one by one, on the
+			// per-block kernels
+			m_Idx = set;
+			m_BatchFrames -= static_cast<std::uint64_t>(n);
+			fallbackToLayers(code);
+			for (int k = 0; k < n; ++k) {
+				submit(in[i + k], out[i + k]);
+				m_Stream.synchronize();
+			}
+		} else {
+			for (int k = 0; k < n; ++k) maybeRestoreResident();
+		}
+		i += n;
+	}
+}
+
 void Engine::runProgram() {
 	if (m_UseGraph && !m_DirectIO && m_Graph[m_Idx].valid()) {
 		m_Graph[m_Idx].launch(m_Stream);
@@ -1751,6 +2014,8 @@ double Engine::stat(const std::string &key) const {
 		        residentTowerFastGeometry(m_Config.frameHeight, m_Config.frameWidth, m_ResGX, m_ResGY, m_ResRH)) ? 1.0 : 0.0;
 	}
 	if (key == "fallbacks") return static_cast<double>(m_Fallbacks);
+	if (key == "lookahead_frames") return static_cast<double>(m_BatchFrames);  // frames that went through look-ahead passes
+	if (key == "lookahead_max") return static_cast<double>(m_BatchMax);
 	if (key == "host_pins") return static_cast<double>(m_PinsMade);  // host frame buffers page-locked so far
 	if (key == "launches_per_frame") return static_cast<double>(m_Program[0].size());
 	if (key == "tower_variant") return static_cast<double>(towerVariant());  // (developer switch, tests)

@@ -54,6 +54,12 @@ public:
 
 	// Synchronous, like Runtime::processImage (tensorrt_backend.cc:270-278).
 	void process(const Frame &in, const Frame &out);
+	// `count` consecutive frames of the stream, synchronously: the frames process(in[0], out[0]) ...
+	// process(in[count - 1], out[count - 1]) would write, byte for byte -- but every input must hold its pixels when
+	// the call is made (frame look-ahead): where the model and the frames allow (device-resident frames, the flow
+	// auto-encoder's one-launch plan) the flow fields of up to kFlowBatchMax frames are computed in one pass of the
+	// flow net's launches (engine.cpp, "Frame look-ahead"); anything else runs frame by frame.
+	void processBatch(const Frame *in, const Frame *out, int count);
 	// Asynchronous variant for device-resident frames: enqueue only.
 	void enqueue(const Frame &in, const Frame &out);
 	void synchronize();
@@ -128,9 +134,16 @@ private:
 	// H x W: the resolution the layer runs at (decides its tile shape)
 	ConvWeights &addConv(const std::string &name, const FoldedConv &f,
 	    const std::vector<int> &cinMap, int H, int W);
+	struct ItemStride {  // a look-ahead launch: the layer of `items` frames, their tensors `in` / `out` bytes apart
+		int items;
+		long in, out;
+		ItemStride(int n = 1, long i = 0, long o = 0) : items(n), in(i), out(o) {}
+	};
 	void addConvStep(std::vector<Step> *prog, const std::string &tag, const std::string &wname,
 	    Operand in, Operand res, Operand out, int H, int W, bool relu, bool outHead,
-	    bool tower = false, bool pool = false, bool upsample = false);
+	    bool tower = false, bool pool = false, bool upsample = false, ItemStride item = ItemStride());
+	void addFlowAutoencoder(std::vector<Step> *prog, int set, int items);
+	bool flowPacksInBlock() const;
 	Operand operand(const std::string &name);
 	Tensor &addTowerTensor(const std::string &name, int H, int W, int C);
 	void buildWeights(const ModelFile &model);
@@ -148,6 +161,14 @@ private:
 		std::ptrdiff_t outStride = 0;
 	};
 	FrameIO m_IO;
+	// what the per-frame program of a binding set reads as the previous HR state / writes as the new one, and the
+	// flow field its warp reads: read at launch (capture) time, like m_IO -- a look-ahead pass rebinds them per frame
+	struct StateBind {
+		const void *in = nullptr;
+		void *out = nullptr;
+	};
+	StateBind m_StateBind[2];
+	const void *m_FlowCur = nullptr;
 	bool m_DirectIO = false;  // decided per call
 	bool m_PreferDirect = true;  // JU_DIRECT=0: always stage (and replay the graph)
 	void submit(const Frame &in, const Frame &out);
@@ -271,6 +292,21 @@ private:
 	bool directEligible(const Frame &in, const Frame &out) const;
 	DirectEntry &directEntry(const DirectKey &key);
 	void captureDirect(DirectEntry *e, int idx);
+	// frame look-ahead (processBatch; engine.cpp): the frames of the pass being recorded, the flow net's tensors for
+	// m_BatchCap frames, the state buffers between the frames of a pass, the flow launches per (frames, binding set)
+	// and the graphs per tuple of frame buffers
+	FrameIO m_BatchIO[kFlowBatchMax];
+	std::map<std::string, Tensor> m_BatchTensors;
+	DeviceBuffer m_BatchState[kFlowBatchMax - 1];
+	int m_BatchCap = 0, m_BatchMax = kFlowBatchMax;
+	bool m_BatchUnsupported = false;
+	std::map<std::pair<int, int>, std::vector<Step>> m_BatchFlow;
+	std::map<std::vector<DirectKey>, DirectEntry> m_BatchGraphs;
+	static constexpr std::size_t kMaxBatchGraphs = 64;
+	std::uint64_t m_BatchFrames = 0;
+	bool batchPlanned(int items);
+	void submitBatch(const Frame *in, const Frame *out, int n);
+	void dropBatchGraphs();
 	std::uint64_t m_DirectClock = 0;
 	bool m_DirectGraph = true;  // JU_DIRECT_GRAPH=0: device frames always launch eagerly
 	static constexpr std::size_t kMaxDirectGraphs = 64;     // unregistered tuples (LRU)

@@ -51,12 +51,15 @@ struct FlowBlockParams {
 	// PACK instantiation (the flow net's first block): the 16-channel input records are built
 	// here from the u8 frame and the previous packed tensor (launchPackFrames' arithmetic) and
 	// written to `packOut` by the tile that owns the pixel; `in` is unused
-	const std::uint8_t *frame;
-	std::ptrdiff_t frameStride;
 	const void *packPrev;
 	void *packOut;
 	int frameH, frameW, padTop, padLeft, numInputs;
 	const unsigned *sums;
+	// frame look-ahead: blockIdx.z = the frame of this launch (FlowBlockLaunch::items); item i's tensors at
+	// in + i * inItem / out + i * outItem bytes, its frame (PACK) frames[i]
+	long inItem, outItem;
+	const std::uint8_t *frames[kFlowBatchMax];
+	std::ptrdiff_t frameStrides[kFlowBatchMax];
 };
 
 template <int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK, int NW = 4>
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	const int hh = lane >> 5;
 	const int x0 = blockIdx.x * kFbOutW;  // first output column of the tile
 	const int y0 = blockIdx.y * TH;       // first output row
-	const T *__restrict__ in = static_cast<const T *>(p.in);
+	const int item = blockIdx.z;          // frame of a look-ahead launch (0 otherwise)
+	const T *__restrict__ in = reinterpret_cast<const T *>(static_cast<const unsigned char *>(p.in) + item * p.inItem);
 	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
 	    (__attribute__((address_space(3))) unsigned char *)smem));
 
@@ -164,10 +168,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 		// previous tensor's ch 0 .., the rest zero.  One thread per tile pixel; the tile that OWNS
 		// a pixel (its 30 x TH output area) also writes the record to the new packed tensor, the
 		// next frame's history.  Pixels outside the padded image are the convolution's zeros.
+		// A look-ahead launch (item = blockIdx.z of gridDim.z frames) takes history slot k of item i from frame i - k of
+		// the launch where there is one -- the same conversion of the same bytes the earlier frame's own pack did -- and
+		// from the previous tensor's slot k - i - 1 otherwise; the last item alone writes the new history.
 		const float bright = brightnessOf(p.sums, 1.0f / static_cast<float>(p.frameH * p.frameW));
 		const T *__restrict__ prev = static_cast<const T *>(p.packPrev);
-		T *__restrict__ cur = static_cast<T *>(p.packOut);
+		T *__restrict__ cur = item + 1 == static_cast<int>(gridDim.z) ? static_cast<T *>(p.packOut) : nullptr;
 		const int nch = 3 * p.numInputs;
+		const int fromFrames = min(item + 1, p.numInputs);  // history slots 0 .. fromFrames - 1 come from frames
 		constexpr int NPIX = G::XR * kFbW;
 		for (int q = tid; q < NPIX; q += NT) {
 			const int r = q / kFbW, k = q - r * kFbW;
@@ -177,33 +185,51 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 			const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
 			if (inside) {
 				const int y = gy - p.padTop, x = gx - p.padLeft;
-				float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-				if (y >= 0 && y < p.frameH && x >= 0 && x < p.frameW) {
-					const unsigned v = *reinterpret_cast<const unsigned *>(p.frame + y * p.frameStride + x * 4);
-					c0 = preprocessU8(v & 0xff) - bright;
-					c1 = preprocessU8((v >> 8) & 0xff) - bright;
-					c2 = preprocessU8((v >> 16) & 0xff) - bright;
-				}
+				const bool inFrame = y >= 0 && y < p.frameH && x >= 0 && x < p.frameW;
 				const size_t idx = (size_t)gy * p.W + gx;
-				const Vec8<T> p0 = *reinterpret_cast<const Vec8<T> *>(prev + idx * 16);
-				const Vec8<T> p1 = *reinterpret_cast<const Vec8<T> *>(prev + idx * 16 + 8);
 				T pv[16], o[16];
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					pv[i] = p0[i];
-					pv[8 + i] = p1[i];
-				}
-				o[0] = static_cast<T>(c0);
-				o[1] = static_cast<T>(c1);
-				o[2] = static_cast<T>(c2);
+				for (int j = 0; j < 16; ++j) o[j] = zero;
 #pragma unroll
-				for (int j = 3; j < 16; ++j) o[j] = (j < nch) ? pv[j - 3] : zero;
+				for (int h = 0; h < 5; ++h) {  // (3 * numInputs <= 16)
+					if (h < fromFrames) {
+						float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+						if (inFrame) {
+							const unsigned v = *reinterpret_cast<const unsigned *>(p.frames[item - h] + y * p.frameStrides[item - h] + x * 4);
+							c0 = preprocessU8(v & 0xff) - bright;
+							c1 = preprocessU8((v >> 8) & 0xff) - bright;
+							c2 = preprocessU8((v >> 16) & 0xff) - bright;
+						}
+						o[3 * h] = static_cast<T>(c0);
+						o[3 * h + 1] = static_cast<T>(c1);
+						o[3 * h + 2] = static_cast<T>(c2);
+					}
+				}
+				if (fromFrames < p.numInputs) {
+					const Vec8<T> p0 = *reinterpret_cast<const Vec8<T> *>(prev + idx * 16);
+					const Vec8<T> p1 = *reinterpret_cast<const Vec8<T> *>(prev + idx * 16 + 8);
+#pragma unroll
+					for (int i = 0; i < 8; ++i) {
+						pv[i] = p0[i];
+						pv[8 + i] = p1[i];
+					}
+					// o[j] = pv[j - 3 * fromFrames]: the shift is uniform over the launch's item, one unrolled copy each
+					auto shifted = [&](auto sTag) __attribute__((always_inline)) {
+						constexpr int S = decltype(sTag)::value;
+#pragma unroll
+						for (int j = S; j < 16; ++j) o[j] = (j < nch) ? pv[j - S] : zero;
+					};
+					if (fromFrames == 1) shifted(std::integral_constant<int, 3>{});
+					else if (fromFrames == 2) shifted(std::integral_constant<int, 6>{});
+					else if (fromFrames == 3) shifted(std::integral_constant<int, 9>{});
+					else shifted(std::integral_constant<int, 12>{});
+				}
 #pragma unroll
 				for (int i = 0; i < 8; ++i) {
 					o0[i] = o[i];
 					o1[i] = o[8 + i];
 				}
-				if (r >= 2 && r < 2 + TH && k >= 2 && k < 2 + kFbOutW) {
+				if (cur != nullptr && r >= 2 && r < 2 + TH && k >= 2 && k < 2 + kFbOutW) {
 					*reinterpret_cast<Vec8<T> *>(cur + idx * 16) = o0;
 					*reinterpret_cast<Vec8<T> *>(cur + idx * 16 + 8) = o1;
 				}
@@ -508,7 +534,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		{
-			unsigned char *outp = static_cast<unsigned char *>(p.out);
+			unsigned char *outp = static_cast<unsigned char *>(p.out) + item * p.outItem;
 			constexpr int PXI = 64 / NCH;  // pixels per wave-instruction
 #pragma unroll
 			for (int it = 0; it < G::STAGE_PX / PXI; ++it) {
@@ -547,14 +573,14 @@ constexpr int fbWaves() {
 }
 
 template <typename T, int CIN, int CMID, int TH, bool UPS, bool POOL, int OUTK, bool PACK = false>
-void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
+void launchFlowBlockInst(const FlowBlockParams &p, int items, hipStream_t stream) {
 	constexpr int NW = fbWaves<CIN, CMID>();
 	using G = FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, NW>;
 	static_assert(G::FITS, "tile does not fit LDS");
 	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTK, NW, PACK>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "flow block");
-	dim3 grid((p.W + kFbOutW - 1) / kFbOutW, (p.H + TH - 1) / TH);
+	dim3 grid((p.W + kFbOutW - 1) / kFbOutW, (p.H + TH - 1) / TH, items);
 	hipLaunchKernelGGL(kern, grid, dim3(NW * 64), G::LDS, stream, p);
 	hipCheckLaunch("flow_block");
 }
@@ -569,8 +595,8 @@ void launchFlowBlockInst(const FlowBlockParams &p, hipStream_t stream) {
 constexpr int kFbMid = 14;
 constexpr int kFbFixedRows = 8;  // the fixed part of a tile in units of one row's work (fitted to the measurement above)
 
-inline long fbLaunchCost(int H, long tilesX, int TH, int numCUs) {
-	const long tiles = tilesX * ((H + TH - 1) / TH);
+inline long fbLaunchCost(int H, long tilesX, int TH, int numCUs, int items = 1) {
+	const long tiles = tilesX * ((H + TH - 1) / TH) * items;  // (a look-ahead launch: the tiles of all its frames)
 	return (tiles + numCUs - 1) / numCUs * (TH + kFbFixedRows);
 }
 
@@ -580,13 +606,13 @@ inline int fbForcedTile() {
 }
 
 template <typename T, int CIN, int CMID, bool UPS, bool POOL, int OUTK, bool PACK, int... THS>
-void launchFlowBlockBest(const FlowBlockParams &p, int numCUs, hipStream_t stream) {
+void launchFlowBlockBest(const FlowBlockParams &p, int items, int numCUs, hipStream_t stream) {
 	const long tilesX = (p.W + kFbOutW - 1) / kFbOutW;
 	int best = 0;
 	long bestCost = 0;
 	auto consider = [&](int TH, bool fits) {
 		if (!fits) return;
-		const long c = fbForcedTile() == TH ? -1 : fbLaunchCost(p.H, tilesX, TH, numCUs);
+		const long c = fbForcedTile() == TH ? -1 : fbLaunchCost(p.H, tilesX, TH, numCUs, items);
 		if (best == 0 || c < bestCost) {
 			best = TH;
 			bestCost = c;
@@ -598,7 +624,7 @@ void launchFlowBlockBest(const FlowBlockParams &p, int numCUs, hipStream_t strea
 		constexpr int TH = decltype(thTag)::value;
 		if constexpr (FbGeom<CIN, CMID, TH, UPS, POOL, OUTK, fbWaves<CIN, CMID>()>::FITS) {
 			if (!done && best == TH) {
-				launchFlowBlockInst<T, CIN, CMID, TH, UPS, POOL, OUTK, PACK>(p, stream);
+				launchFlowBlockInst<T, CIN, CMID, TH, UPS, POOL, OUTK, PACK>(p, items, stream);
 				done = true;
 			}
 		}
@@ -608,16 +634,16 @@ void launchFlowBlockBest(const FlowBlockParams &p, int numCUs, hipStream_t strea
 }
 
 template <typename T, int CIN, int CMID, bool UPS, bool POOL, int OUTK, bool PACK = false>
-void launchFlowBlockT(const FlowBlockParams &p, int numCUs, hipStream_t stream) {
+void launchFlowBlockT(const FlowBlockParams &p, int items, int numCUs, hipStream_t stream) {
 	if constexpr (OUTK == 2) {
 		// (64 -> 64 -> 64 residual block, JU_RES_BLOCK=tile only: two 128-byte tiles; 14 rows is what fits)
-		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, kFbMid, 6>(p, numCUs, stream);
+		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, kFbMid, 6>(p, items, numCUs, stream);
 	} else if constexpr (CMID == 128) {
 		// (the 128-filter blocks, 68 x 120 at 480 x 270: a few thousand pixels -- short tiles, or most of the chip idles;
 		// measured for the encoder block: 2 rows 11.7 us, 4 rows 16.0, 6 rows 19.9)
-		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 2>(p, numCUs, stream);
+		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 2>(p, items, numCUs, stream);
 	} else {
-		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 20, 18, 10, 6>(p, numCUs, stream);
+		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 20, 18, 10, 6>(p, items, numCUs, stream);
 	}
 }
 
@@ -639,8 +665,6 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.slope = q.slope;
 	p.skip = ablationSkipBits();
 	p.prio = wavePriorityMode(0);
-	p.frame = q.packFrame;
-	p.frameStride = q.packFrameStride;
 	p.packPrev = q.packPrev;
 	p.packOut = q.packOut;
 	p.frameH = q.frameH;
@@ -649,12 +673,25 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	p.padLeft = q.padLeft;
 	p.numInputs = q.numInputs;
 	p.sums = q.sums;
+	const int items = q.items > 1 ? q.items : 1;
+	if (items > kFlowBatchMax) throw std::invalid_argument("flow block: more look-ahead frames than kFlowBatchMax");
+	p.inItem = items > 1 ? q.inItemBytes : 0;
+	p.outItem = items > 1 ? q.outItemBytes : 0;
+	for (int i = 0; i < kFlowBatchMax; ++i) {
+		p.frames[i] = items > 1 ? (i < items ? q.packFrames[i] : nullptr) : (i == 0 ? q.packFrame : nullptr);
+		p.frameStrides[i] = items > 1 ? (i < items ? q.packFrameStrides[i] : 0) : (i == 0 ? q.packFrameStride : 0);
+	}
+	if (items > 1 && q.residual) throw std::invalid_argument("flow block: the residual form has no look-ahead launch");
 	const int cus = currentDeviceCUs();
 	if (q.packOut != nullptr) {
-		if (!(q.cin == 16 && q.cmid == 32 && !q.upsample && q.pool && !q.outHead && !q.residual && q.packFrame && q.packPrev)) {
+		if (items > 1 && q.sums != nullptr) throw std::invalid_argument("flow block: look-ahead packing has no brightness sums");
+		for (int i = 0; i < items; ++i) {
+			if (p.frames[i] == nullptr) throw std::invalid_argument("flow block: input packing needs every frame of the launch");
+		}
+		if (!(q.cin == 16 && q.cmid == 32 && !q.upsample && q.pool && !q.outHead && !q.residual && q.packPrev)) {
 			throw std::invalid_argument("flow block: input packing is built for the first block (16 -> 32 -> 32, pool)");
 		}
-		return launchFlowBlockT<T, 16, 32, false, true, 0, true>(p, cus, stream);
+		return launchFlowBlockT<T, 16, 32, false, true, 0, true>(p, items, cus, stream);
 	}
 	if (q.upsample && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused upsampling needs even H and W");
 	if (q.pool && (q.H % 2 || q.W % 2)) throw std::invalid_argument("flow block: fused max-pool needs even H and W");
@@ -662,7 +699,7 @@ void launchFlowBlockDT(const FlowBlockLaunch &q, hipStream_t stream) {
 	const int outk = q.residual ? 2 : (q.outHead ? 1 : 0);
 #define JU_FB_CASE(CIN_, CMID_, UPS_, POOL_, OUTK_)                                              \
 	if (q.cin == CIN_ && q.cmid == CMID_ && q.upsample == UPS_ && q.pool == POOL_ && outk == OUTK_) { \
-		return launchFlowBlockT<T, CIN_, CMID_, UPS_, POOL_, OUTK_>(p, cus, stream);                \
+		return launchFlowBlockT<T, CIN_, CMID_, UPS_, POOL_, OUTK_>(p, items, cus, stream);         \
 	}
 	JU_FB_CASE(16, 32, false, true, 0)   // encoder block 1: 12(16) -> 32 -> 32, pool
 	JU_FB_CASE(32, 64, false, true, 0)   // encoder block 2: 32 -> 64 -> 64, pool

@@ -53,6 +53,11 @@ struct ConvParams {
 	// Tile shape chosen per layer (convTiling): couts per workgroup = 32*nb (the
 	// weights must be packed for the same nb), rows per wave rw (tile = 4*rw rows).
 	int nb, rw;
+	// Frame look-ahead (Engine::processBatch): the same layer of `items` consecutive frames in one launch, item i at
+	// in + i * inItemBytes / out + i * outItemBytes.  0 or 1 = one frame.  Honoured by launchConvSplitK only (the
+	// other launchers refuse items > 1).
+	int items;
+	long inItemBytes, outItemBytes;
 };
 
 // Zero-bordered activation layout of the generator trunk ("tower layout"):
@@ -111,6 +116,7 @@ void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
 // conv A 3x3 cin -> cmid, activation, conv B 3x3 cmid -> cmid, [activation], [2x2
 // max-pool]; `upsample`: `in` is the half-resolution tensor [H/2][W/2][cin] and the TF1
 // bilinear x2 is part of the tile staging.  Weights: packConvWeights with nb = 1.
+constexpr int kFlowBatchMax = 8;  // frames per look-ahead pass of the flow net (Engine::processBatch)
 struct FlowBlockLaunch {
 	const void *in;
 	const void *w1;
@@ -137,6 +143,15 @@ struct FlowBlockLaunch {
 	void *packOut;
 	int frameH, frameW, padTop, padLeft, numInputs;
 	const unsigned *sums;
+	// Frame look-ahead: the block of `items` (<= kFlowBatchMax) consecutive frames in one launch (grid.z), item i at
+	// in + i * inItemBytes / out + i * outItemBytes; 0 or 1 = one frame.  With input packing, item i's current frame
+	// is packFrames[i] and its history slot k is packFrames[i - k] where the launch holds that frame, else what
+	// packPrev holds for it; only the LAST item writes packOut (the history of the frame after the batch), and
+	// `sums` must be null.  packFrame / packFrameStride are ignored when items > 1.
+	int items;
+	long inItemBytes, outItemBytes;
+	const std::uint8_t *packFrames[kFlowBatchMax];
+	std::ptrdiff_t packFrameStrides[kFlowBatchMax];
 };
 // H x W: the block's resolution (the 128-filter blocks run as one launch only where their 2-row tiles are ONE round of the
 // chip: flow_kernels.hip); 0 = shape only

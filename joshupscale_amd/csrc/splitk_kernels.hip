@@ -44,6 +44,7 @@ struct SplitKParams {
 	float slope;
 	int skip;  // timing ablation (JU_FB_SKIP, developer only): 1 weights, 2 staging, 4 K loops, 8 reduction, 16 stores
 	int prio;  // wave priority scheme (kernel_common.h applyWavePriority)
+	long inItem, outItem;  // frame look-ahead: blockIdx.z = the frame, its tensors at in + z * inItem / out + z * outItem bytes
 };
 
 template <int CIN, int CB>
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 	const int x0 = tx * 32, y0 = ty * p.TH;
 	const int cog0 = blockIdx.y * CB;
 	const int nPairs = (min(p.TH, p.H - y0) + 1) >> 1;
-	const T *__restrict__ in = static_cast<const T *>(p.in);
+	const T *__restrict__ in = reinterpret_cast<const T *>(static_cast<const unsigned char *>(p.in) + blockIdx.z * p.inItem);
 	const unsigned ldsBase = static_cast<unsigned>(reinterpret_cast<unsigned long long>(
 	    (__attribute__((address_space(3))) unsigned char *)smem));
 	// this wave's input channels: k-steps wave*KS .. +KS of the CIN/16
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the next pair's rows)
 		__syncthreads();  // D
 		// ---- staging tile -> global, 16 bytes per thread ----
-		T *out = static_cast<T *>(p.out);
+		T *out = reinterpret_cast<T *>(static_cast<unsigned char *>(p.out) + blockIdx.z * p.outItem);
 		if constexpr (!POOL) {
 			if (tid < CB * 256) {
 				const int q = tid & 3, cx = (tid >> 2) & 31, r = (tid >> 7) & 1, b = tid >> 8;
@@ -241,12 +242,12 @@ __global__ __launch_bounds__(512, 1) void conv_splitk_kernel(SplitKParams p) {
 }
 
 template <typename T, int CIN, int CB, bool POOL>
-void launchSplitKInst(const SplitKParams &p, int tilesY, hipStream_t stream) {
+void launchSplitKInst(const SplitKParams &p, int tilesY, int items, hipStream_t stream) {
 	using G = SkGeom<CIN, CB>;
 	auto kern = conv_splitk_kernel<T, CIN, CB, POOL>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "split-K conv");
-	hipLaunchKernelGGL(kern, dim3(p.tilesX * tilesY, p.cout / (32 * CB)), dim3(512), G::LDS, stream, p);
+	hipLaunchKernelGGL(kern, dim3(p.tilesX * tilesY, p.cout / (32 * CB), items), dim3(512), G::LDS, stream, p);
 	hipCheckLaunch("conv_splitk");
 }
 
@@ -278,6 +279,9 @@ void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStrea
 	p.skip = ablationSkipBits();
 	p.prio = wavePriorityMode(0);
 	p.tilesX = (q.W + 31) / 32;
+	const int items = q.items > 1 ? q.items : 1;  // (frame look-ahead: the layer of `items` frames in one launch)
+	p.inItem = items > 1 ? q.inItemBytes : 0;
+	p.outItem = items > 1 ? q.outItemBytes : 0;
 	// Tile height and cout blocks per workgroup: every workgroup pulls its cout blocks'
 	// whole weights (147 KB per block at 256 channels), so the fewest workgroups that still
 	// fill most of the chip in ONE round; two cout blocks per workgroup (128 channels only:
@@ -287,7 +291,7 @@ void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStrea
 	for (;;) {
 		bool found = false;
 		for (th = 2; th <= 16; th += 2) {
-			if ((long)p.tilesX * ((q.H + th - 1) / th) * (nCog / cb) <= cus) {
+			if ((long)p.tilesX * ((q.H + th - 1) / th) * (nCog / cb) * items <= cus) {
 				found = true;
 				break;
 			}
@@ -301,8 +305,8 @@ void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStrea
 	const bool f16t = dt == kF16;
 #define JU_SK_CASE(CIN_, CB_, POOL_)                                                       \
 	if (q.cin == CIN_ && cb == CB_ && (q.pool != 0) == POOL_) {                              \
-		if (f16t) launchSplitKInst<f16, CIN_, CB_, POOL_>(p, tilesY, stream);                  \
-		else launchSplitKInst<bf16, CIN_, CB_, POOL_>(p, tilesY, stream);                      \
+		if (f16t) launchSplitKInst<f16, CIN_, CB_, POOL_>(p, tilesY, items, stream);           \
+		else launchSplitKInst<bf16, CIN_, CB_, POOL_>(p, tilesY, items, stream);               \
 		return;                                                                              \
 	}
 	JU_SK_CASE(128, 1, false)

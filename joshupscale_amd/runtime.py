@@ -78,6 +78,7 @@ _PRODUCT_SIGS = {
     "ju_validate_model": (C.c_int, [C.c_void_p, C.c_size_t]),
     "ju_destroy": (None, [C.c_void_p]),
     "ju_process": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage)]),
+    "ju_process_batch": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), C.c_int]),
     "ju_enqueue": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage)]),
     "ju_synchronize": (C.c_int, [C.c_void_p]),
     "ju_prepare_frames": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), _P(C.c_int)]),
@@ -216,6 +217,15 @@ class Runtime:
     def process(self, inp: JuImage, out: JuImage) -> None:
         """Raw ``processImage`` on two image descriptors (synchronous)."""
         _check(self._lib, self._lib.ju_process(self._h, C.byref(inp), C.byref(out)))
+
+    def process_batch(self, inputs, outputs) -> None:
+        """``ju_process_batch``: consecutive frames of the stream in one synchronous call (frame look-ahead --
+        every input must hold its pixels now); the bytes of ``process`` called frame by frame."""
+        n = len(inputs)
+        if len(outputs) != n:
+            raise ValueError("as many outputs as inputs")
+        ins, outs = (JuImage * n)(*inputs), (JuImage * n)(*outputs)
+        _check(self._lib, self._lib.ju_process_batch(self._h, ins, outs, n))
 
     def enqueue(self, inp: JuImage, out: JuImage) -> None:
         _check(self._lib, self._lib.ju_enqueue(self._h, C.byref(inp), C.byref(out)))

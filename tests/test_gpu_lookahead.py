@@ -1,0 +1,223 @@
+"""Frame look-ahead (ju_process_batch; engine.cpp "Frame look-ahead") -- needs an MI355X.
+
+The flow net reads LR frames only (reference models.py:795-800: its input is the packed history of the last
+num_flow_inputs frames), so the flow fields of several consecutive frames are computed in one pass of the flow net's
+launches; warp, tower and tail stay frame by frame.  The contract is byte equality with ju_process called frame by
+frame -- frames, recurrent state and frame history -- for every pass length, both parities, across passes, mixed with
+plain calls, after a reset, and through the resident tower's fallback.
+"""
+
+import dataclasses
+
+import numpy as np
+import pytest
+
+from helpers import M, small_config
+from joshupscale_amd import runtime as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_clip(cfg, n, seed, outs=1):
+    import torch
+    h, w = cfg.frame_height, cfg.frame_width
+    frames = M.synthetic_frames(n, h, w, seed=seed, kind="noise")
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(frames).to(dev)
+    d_out = torch.zeros((outs, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    return frames, d_in, d_out
+
+
+def _frame_by_frame(blob, dtype, cfg, d_in, d_out, n):
+    h, w = cfg.frame_height, cfg.frame_width
+    want = []
+    with R.Runtime(blob, 0, dtype) as rt:
+        out = rt.device_image(d_out[0].data_ptr(), 4 * w, 4 * h)
+        for t in range(n):
+            rt.process(rt.device_image(d_in[t].data_ptr(), w, h), out)
+            want.append(d_out[0].cpu().numpy())
+        state = rt.read_tensor("state").copy()
+    return want, state
+
+
+@pytest.mark.parametrize("preset,dtype", [("psp-quality", R.DTYPE_BF16), ("psp-fast", R.DTYPE_F16),
+                                          ("ps2-quality", R.DTYPE_FP8), ("psp-quality-lrelu", R.DTYPE_BF16)])
+def test_look_ahead_passes_give_the_frame_by_frame_bytes(preset, dtype):
+    """Passes of every length 2..8 back to back (21 frames + a plain call between them: both parities of the binding
+    set at a pass's start, the state and history handed from pass to pass and to ju_process and back), one output
+    buffer per frame.  Every frame, and the recurrent state at the end, equal the frame-by-frame runtime's."""
+    cfg = M.PRESETS[preset]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    n = 2 + 3 + 1 + 4 + 5 + 8 + 1 + 6 + 7
+    frames, d_in, d_out = _device_clip(cfg, n, seed=71, outs=8)
+    want, want_state = _frame_by_frame(blob, dtype, cfg, d_in, d_out, n)
+    with R.Runtime(blob, 0, dtype) as rt:
+        assert rt.stat("lookahead_max") == 8
+        t = 0
+        for k in (2, 3, 1, 4, 5, 8, 1, 6, 7):
+            ins = [rt.device_image(d_in[t + i].data_ptr(), w, h) for i in range(k)]
+            outs = [rt.device_image(d_out[i].data_ptr(), 4 * w, 4 * h) for i in range(k)]
+            if k == 1:
+                rt.process(ins[0], outs[0])
+            else:
+                rt.process_batch(ins, outs)
+            got = d_out[:k].cpu().numpy()
+            for i in range(k):
+                assert np.array_equal(got[i], want[t + i]), (preset, "pass of", k, "frame", t + i)
+            t += k
+        assert np.array_equal(rt.read_tensor("state"), want_state)
+        # (640x448: the 128-filter flow blocks are launches per convolution there, one of them on the generic kernel,
+        # which has no batched form -- the call runs frame by frame)
+        assert rt.stat("lookahead_frames") == (0 if preset == "ps2-quality" else n - 2), "the passes did not take the look-ahead path"
+        assert rt.stat("fallbacks") == 0
+
+
+def test_look_ahead_replays_graphs_and_takes_long_and_ragged_calls():
+    """A call of any length is cut into passes of at most JU_LOOKAHEAD frames; a tuple of frame buffers seen the
+    second time is a captured graph from then on (first sighting eager, like ju_process), and all frames of a pass
+    may share one output buffer (the caller's business: the last frame's pixels remain)."""
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames, d_in, d_out = _device_clip(cfg, 8, seed=5)
+    want = []
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        out = rt.device_image(d_out[0].data_ptr(), 4 * w, 4 * h)
+        for t in range(40):
+            rt.process(rt.device_image(d_in[t % 8].data_ptr(), w, h), out)
+            if t % 4 == 3 or t == 39:
+                want.append(d_out[0].cpu().numpy())
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        out = rt.device_image(d_out[0].data_ptr(), 4 * w, 4 * h)
+        ring = [rt.device_image(d_in[t].data_ptr(), w, h) for t in range(8)]
+        for p in range(10):  # passes of four over a ring of eight: two tuples x (one binding set each)
+            rt.process_batch([ring[(4 * p + i) % 8] for i in range(4)], [out] * 4)
+            assert np.array_equal(d_out[0].cpu().numpy(), want[p]), p
+        assert rt.stat("lookahead_frames") == 40
+        # tuples: (frames 0-3 | 4-7) x the binding set at the pass's start, which flips once per pass and so repeats
+        # with the ring: 2 tuples -> 2 eager passes, 2 captures, 8 replays
+        assert rt.stat("eager_runs") == 2 and rt.stat("graph_captures") == 2 and rt.stat("graph_replays") == 8
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:   # one call with 19 frames: passes of 8, 8, 3
+        out = rt.device_image(d_out[0].data_ptr(), 4 * w, 4 * h)
+        rt.process_batch([rt.device_image(d_in[t % 8].data_ptr(), w, h) for t in range(19)], [out] * 19)
+        assert rt.stat("lookahead_frames") == 19
+        rt.process(rt.device_image(d_in[19 % 8].data_ptr(), w, h), out)
+        assert np.array_equal(d_out[0].cpu().numpy(), want[4])
+        rt.process_batch([], [])
+
+
+def test_look_ahead_mixes_with_host_frames_and_respects_the_cap(monkeypatch):
+    """Frames a pass cannot take -- host frames here -- run as ju_process does, in order, inside the same call; and
+    JU_LOOKAHEAD=1 turns the passes off altogether.  Same bytes every way."""
+    import torch
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames, d_in, d_out = _device_clip(cfg, 7, seed=23, outs=7)
+    want, _ = _frame_by_frame(blob, R.DTYPE_BF16, cfg, d_in, d_out, 7)
+    host_out = np.zeros((4 * h, 4 * w, 4), np.uint8)
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        ins = [rt.device_image(d_in[t].data_ptr(), w, h) for t in range(7)]
+        outs = [rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h) for t in range(7)]
+        ins[3], outs[3] = R.host_image(frames[3]), R.host_image(host_out)   # device x3, host, device x3
+        rt.process_batch(ins, outs)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for t in range(7):
+            assert np.array_equal(host_out if t == 3 else got[t], want[t]), t
+        assert rt.stat("lookahead_frames") == 6
+    monkeypatch.setenv("JU_LOOKAHEAD", "1")
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        assert rt.stat("lookahead_max") == 1
+        rt.process_batch([rt.device_image(d_in[t].data_ptr(), w, h) for t in range(7)],
+                         [rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h) for t in range(7)])
+        got = d_out.cpu().numpy()
+        assert all(np.array_equal(got[t], want[t]) for t in range(7)) and rt.stat("lookahead_frames") == 0
+
+
+@pytest.mark.parametrize("variant", ["generic-flow", "brightness", "flow-resnet", "temporal"])
+def test_models_without_a_batched_flow_plan_run_frame_by_frame(variant, monkeypatch):
+    """The pass needs the flow auto-encoder's one-launch plan with the input packing in its first block: other
+    models and developer switches (per-convolution flow kernels, normalize_brightness, the flow res-net) take the
+    same call frame by frame; the temporal output filter rides on the passes (its accumulators see the frames in
+    order).  Same bytes in every case."""
+    cfg = small_config()
+    if variant == "generic-flow":
+        monkeypatch.setenv("JU_FLOW_CONV", "generic")
+    elif variant == "brightness":
+        cfg = small_config(normalize_brightness=True)
+    elif variant == "flow-resnet":
+        cfg = dataclasses.replace(M.PRESETS["psp-quality-flowres"], frame_height=64, frame_width=96)
+    else:
+        cfg = dataclasses.replace(M.PRESETS["psp-fast"], temporal_strength=0.6, temporal_window=3)
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames, d_in, d_out = _device_clip(cfg, 6, seed=3, outs=6)
+    want, want_state = _frame_by_frame(blob, R.DTYPE_F16, cfg, d_in, d_out, 6)
+    with R.Runtime(blob, 0, R.DTYPE_F16) as rt:
+        rt.process_batch([rt.device_image(d_in[t].data_ptr(), w, h) for t in range(6)],
+                         [rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h) for t in range(6)])
+        got = d_out.cpu().numpy()
+        for t in range(6):
+            assert np.array_equal(got[t], want[t]), (variant, t)
+        assert np.array_equal(rt.read_tensor("state"), want_state)
+        assert rt.stat("lookahead_frames") == (6 if variant == "temporal" else 0), variant
+
+
+def test_a_pass_whose_resident_tower_times_out_is_run_again_frame_by_frame():
+    """The resident tower's bounded neighbour wait can expire (CUs taken by another process).  A look-ahead pass
+    never writes what it reads -- it starts from m_State[set] / m_Packed[set] and leaves its results in the other
+    halves and in buffers of its own -- so the engine falls back to the per-block kernels and runs the SAME frames
+    again one by one: the caller sees the frame-by-frame bytes and no error."""
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames, d_in, d_out = _device_clip(cfg, 9, seed=41, outs=5)
+    lib = R.load_library()
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        ins = [rt.device_image(d_in[t].data_ptr(), w, h) for t in range(9)]
+        outs = [rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h) for t in range(5)]
+        rt.process_batch(ins[:4], outs[:4])
+        lib.ju_debug_set(b"resident_fault", 1)
+        try:
+            rt.process_batch(ins[4:9], outs)          # times out inside the pass, falls back, re-runs
+        finally:
+            lib.ju_debug_set(b"resident_fault", 0)
+        assert rt.stat("fallbacks") == 1 and rt.stat("resident_tower") == 0 and rt.stat("lookahead_frames") == 4
+        got = d_out.cpu().numpy()
+        state = rt.read_tensor("state").copy()
+        rt.process_batch(ins[:3], outs[:3])           # look-ahead goes on over the per-block tower
+        assert rt.stat("lookahead_frames") == 7
+    # reference: the same fault in a frame-by-frame runtime (the per-block tower's bytes from the faulted frame on)
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        out = rt.device_image(d_out[0].data_ptr(), 4 * w, 4 * h)
+        for t in range(9):
+            if t == 4:
+                lib.ju_debug_set(b"resident_fault", 1)
+            try:
+                rt.process(rt.device_image(d_in[t].data_ptr(), w, h), out)
+            finally:
+                lib.ju_debug_set(b"resident_fault", 0)
+            if t >= 4:
+                assert np.array_equal(d_out[0].cpu().numpy(), got[t - 4]), t
+        assert np.array_equal(rt.read_tensor("state"), state)
+
+
+def test_bad_arguments_are_errors_not_crashes():
+    cfg = small_config()
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    h, w = cfg.frame_height, cfg.frame_width
+    frames, d_in, d_out = _device_clip(cfg, 2, seed=1)
+    lib = R.load_library()
+    with R.Runtime(blob, 0, R.DTYPE_F16) as rt:
+        good_in = rt.device_image(d_in[0].data_ptr(), w, h)
+        good_out = rt.device_image(d_out[0].data_ptr(), 4 * w, 4 * h)
+        with pytest.raises(R.JoshUpscaleError):
+            rt.process_batch([good_in, rt.device_image(d_in[1].data_ptr(), w - 1, h)], [good_out, good_out])
+        assert lib.ju_process_batch(rt._h, None, None, 2) != 0
+        assert lib.ju_process_batch(rt._h, None, None, -1) != 0
+        assert lib.ju_process_batch(None, None, None, 0) != 0
+        rt.reset()
+        rt.process_batch([good_in, good_in], [good_out, good_out])
