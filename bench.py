@@ -183,6 +183,10 @@ def main() -> int:
     ap.add_argument("--roofline-iters", type=int, default=20)
     ap.add_argument("--preroll", type=int, default=PREROLL_FRAMES,
                     help="untimed clock-warm frames in front of --warmup (fixed; not part of the contract's W)")
+    ap.add_argument("--lookahead", type=int, default=None,
+                    help="frames per ju_process_batch pass (1 = ju_process frame by frame).  Default: 8 for device "
+                         "frames -- the frames are resident in HBM, so the boundary call can read ahead -- and 1 for "
+                         "psp-fast (BASELINE config 3 is the latency configuration) and for host frames")
     ap.add_argument("--no-prepare", action="store_true",
                     help="do not register the frame buffers (ju_prepare_frames): graphs are then captured "
                          "inside ju_process at a pair's second use, and a timed region that contains such a "
@@ -214,6 +218,11 @@ def main() -> int:
     # The frames are timed through the PRODUCT library (libJoshUpscale.so: no test hooks); the per-kernel times of
     # the roofline come afterwards from a second runtime of its test flavour (libJoshUpscale_test.so: the same
     # objects + ju_time_steps).  JU_LIBRARY (A/B of developer builds) replaces both.
+    look = args.lookahead
+    if look is None:
+        look = 1 if (args.preset == "psp-fast" or args.location != "device") else 8
+    look = max(1, min(look, 8))
+    os.environ["JU_LOOKAHEAD"] = str(look)  # (the runtimes' cap on frames per pass = what this run hands over per call)
     rt = R.Runtime(blob, device=local_rank, dtype=dt, hooks=False)
 
     h, w = cfg.frame_height, cfg.frame_width
@@ -231,10 +240,42 @@ def main() -> int:
     # Set-up: register every frame-buffer pair the loop will use, so that their hipGraphs are
     # captured HERE (the reference captures its graphs in the constructor,
     # tensorrt_backend.cc:257-263) and the timed region only replays.
+    def passes(count: int):
+        """The boundary calls of a phase of `count` frames: (first ring position, frames) per call -- passes of `look`
+        frames from the phase's start, a shorter one at its end."""
+        i = 0
+        while i < count:
+            n = min(look, count - i)
+            yield i % len(ins), n
+            i += n
+
+    def register(runtime, counts) -> int:
+        """Set-up: every frame-buffer pair and every pass tuple the phases will use, so that their hipGraphs are
+        captured HERE and the timed region only replays."""
+        got = 0
+        for i in range(len(ins)):
+            got += runtime.prepare_frames(ins[i], outs[i])
+        seen = set()
+        for count in counts:
+            for pos, n in passes(count):
+                if n > 1 and (pos, n) not in seen:
+                    seen.add((pos, n))
+                    got += runtime.prepare_batch([ins[(pos + k) % len(ins)] for k in range(n)],
+                                                 [outs[(pos + k) % len(outs)] for k in range(n)])
+        return got
+
+    def run_phase(runtime, count: int) -> None:
+        for pos, n in passes(count):
+            if n == 1:
+                runtime.process(ins[pos], outs[pos % len(outs)])
+            else:
+                runtime.process_batch([ins[(pos + k) % len(ins)] for k in range(n)],
+                                      [outs[(pos + k) % len(outs)] for k in range(n)])
+
+    phases = (args.preroll, args.warmup, args.steps)
     prepared = 0
     if not args.no_prepare:
-        for i in range(len(ins)):
-            prepared += rt.prepare_frames(ins[i], outs[i])
+        prepared = register(rt, phases)
 
     def step(i: int) -> None:
         rt.process(ins[i % len(ins)], outs[i % len(outs)])
@@ -244,33 +285,34 @@ def main() -> int:
                 "captures": rt.stat("graph_captures")}
 
     with SclkSampler(local_rank) as sclk:
-        for i in range(args.preroll):  # clock-warm, fixed, outside the contract's warm-up
-            step(i)
-    for i in range(args.warmup):
-        step(args.preroll + i)
+        run_phase(rt, args.preroll)  # clock-warm, fixed, outside the contract's warm-up
+    run_phase(rt, args.warmup)
     jdist.barrier()
     torch.cuda.synchronize()
     c0 = counters()
+    la0 = rt.stat("lookahead_frames")
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.preroll + args.warmup + i)
+    run_phase(rt, args.steps)
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0
     jdist.barrier()
     elapsed = time.perf_counter() - t0
     c1 = counters()
     timed_region = {k: int(c1[k] - c0[k]) for k in c0}
+    timed_region["lookahead_frames"] = int(rt.stat("lookahead_frames") - la0)
     elapsed = jdist.max_over_ranks(elapsed, device)
     rank_fps = jdist.gather_floats(args.steps / own_elapsed, device)
 
     # per-frame latency of the synchronous boundary call (outside the timed region):
     # what a caller blocked in processImage sees; SURVEY 8d config 3 asks for p50/p99
     lat = []
+    per_frame_fps = None
     if rank == 0:
         for i in range(min(args.steps, 200)):
             t1 = time.perf_counter()
             step(i)
             lat.append((time.perf_counter() - t1) * 1e3)
+        per_frame_fps = len(lat) / (sum(lat) * 1e-3)  # (the frame-by-frame boundary call, same runtime, same box)
         lat.sort()
 
     result = None
@@ -309,14 +351,17 @@ def main() -> int:
         # input frame, the state decays -- read 325 us in-frame for a kernel that takes ~350 in the timed frames: MFMAs
         # on degenerate data draw less power and the chip clocks higher, tools/probes/two_runtimes2.py.)
         if args.location == "device" and not args.no_prepare:
-            for i in range(len(ins)):
-                rt.prepare_frames(ins[i], outs[i])
-        for i in range(args.preroll + args.warmup + args.steps):
-            rt.process(ins[i % len(ins)], outs[i % len(outs)])
+            register(rt, phases)
+        for count in phases:
+            run_phase(rt, count)
         # (timed inside whole frames: the kernel in the clock / cache context of the workload --
         # what `rocprofv3 --kernel-trace --stats` of this command averages; the back-to-back
         # figure of the launches alone is reported beside it)
-        ms, launches, flops = rt.time_steps("tower@frame", args.roofline_iters)
+        # (inside look-ahead passes when the timed region ran them: the towers of consecutive frames then follow one
+        # another with only the warp in between -- another power state than frame-by-frame calls)
+        in_passes = timed_region["lookahead_frames"] > 0
+        ctx = "@pass" if in_passes else "@frame"
+        ms, launches, flops = rt.time_steps("tower" + ctx, args.roofline_iters)
         ms_alone = rt.time_steps("tower", args.roofline_iters)[0]
         flops_per_launch = flops / max(launches, 1)
         achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -330,7 +375,7 @@ def main() -> int:
             # is HBM-bound: 2 x 9.55 GFLOP x (H W / 129600) against the fp16 stream in and out + the e4m3 copy in and
             # out = 384 B per pixel (+ 72 KB of weights): 335 FLOP/B at 640x448, below the 625 FLOP/B ridge of
             # 5 PFLOP/s over 8 TB/s (round 4 mislabelled it MFMA-bound).  The MFMA fraction is reported beside it.
-            ms, _, fl1 = rt.time_steps("tower#1@frame", args.roofline_iters)
+            ms, _, fl1 = rt.time_steps("tower#1" + ctx, args.roofline_iters)
             launches, flops_per_launch = cfg.gen_blocks, fl1
             achieved = fl1 / (ms * 1e-3) / 1e12
             peak = PEAK_FP8_TFLOPS
@@ -343,7 +388,7 @@ def main() -> int:
                 "launch_ms": ms, "launches_per_frame": cfg.gen_blocks, "bytes_per_launch": bytes_blk,
                 "flop_per_byte": fl1 / bytes_blk, "ridge_flop_per_byte": PEAK_FP8_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9),
                 "launch_ms_how": "HIP events around the kernel's launches inside whole frames on the engine's stream "
-                                 "(ju_time_steps tag@frame), mean over %d frames" % args.roofline_iters,
+                                 "(ju_time_steps tag%s), mean over %d %s" % (ctx, args.roofline_iters, "passes" if in_passes else "frames"),
                 "mfma": {"achieved": achieved, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP8_TFLOPS,
                          "flops_per_launch": fl1},
             }
@@ -351,8 +396,8 @@ def main() -> int:
             # 8-bit tower: step 0 of the stage is the quantise kernel, then per block the first
             # convolution (e4m3 in, e4m3 out: MFMA-bound by arithmetic) and the second (+ the
             # fp16 residual stream in and out: memory-bound, and the one most time goes to)
-            ms1, _, fl1 = rt.time_steps("tower#1@frame", args.roofline_iters)
-            ms2, _, _ = rt.time_steps("tower#2@frame", args.roofline_iters)
+            ms1, _, fl1 = rt.time_steps("tower#1" + ctx, args.roofline_iters)
+            ms2, _, _ = rt.time_steps("tower#2" + ctx, args.roofline_iters)
             px = h * w
             bytes2 = px * (64 + 128 + 128 + 64) + 9 * 64 * 64   # t8 in, stream in/out, x8 out, weights
             fp8_roofline = {
@@ -417,7 +462,13 @@ def main() -> int:
                 "model_broadcast": dict(jdist.LAST_BROADCAST, seconds=broadcast_s),
                 "per_rank_fps": {"values": rank_fps, "min": min(rank_fps), "max": max(rank_fps)},
                 "affinity": AFFINITY,
-                "boundary": "ju_process (synchronous processImage)",
+                "boundary": ("ju_process_batch (synchronous; passes of %d consecutive frames: the flow fields of a pass in one "
+                             "sweep of the flow net's launches, warp / tower / tail frame by frame; bytes equal "
+                             "ju_process)" % look) if in_passes else "ju_process (synchronous processImage)",
+                "lookahead": {"frames_per_pass": look if in_passes else 1,
+                              "frame_by_frame_value": per_frame_fps,
+                              "frame_by_frame_how": "ju_process on the same runtime after the timed region, %d frames "
+                                                    "(the latency loop)" % len(lat)},
                 "library": {"timed": product["library"], "kernel_times": os.path.basename(R.library_path(True))},
                 "timed_region": timed_region,
                 "resident_fallbacks": product["fallbacks"],
@@ -449,7 +500,7 @@ def main() -> int:
                 "traffic_source": traffic_source,
                 "launch_ms": ms, "launches_per_frame": launches,
                 "launch_ms_how": "HIP events around the kernel's launches inside whole frames on the engine's stream "
-                                 "(ju_time_steps tag@frame), mean over %d frames" % args.roofline_iters,
+                                 "(ju_time_steps tag%s), mean over %d %s" % (ctx, args.roofline_iters, "passes" if in_passes else "frames"),
                 "launch_ms_back_to_back": ms_alone,
                 # rounds 1-2 priced `frac` on the back-to-back figure; both are kept side by side
                 "frac_back_to_back": (flops_per_launch / (ms_alone * 1e-3) / 1e12 / peak) if ms_alone > 0 and launches == 1 else None,

@@ -112,6 +112,11 @@ JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image
  * does.  For callers that can read ahead: a file transcoder, an AviSynth filter fetching child frames n .. n+3.
  * JU_LOOKAHEAD=<1..8> caps the frames per pass (1 = off). */
 JU_API int ju_process_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image *outputs, int count);
+/* What ju_prepare_frames is to ju_process: registers a tuple of 2 .. JU_LOOKAHEAD JU_LOC_DEVICE frame buffers the
+ * caller is going to hand to ju_process_batch as one pass; its hipGraphs (one per binding set) are captured now,
+ * nothing executes.  Unregistered tuples are captured at their second use.  *captured (optional) = graphs captured
+ * by this call; 0 for a tuple that will not run as one pass. */
+JU_API int ju_prepare_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image *outputs, int count, int *captured);
 
 /* Asynchronous form for JU_LOC_DEVICE images: enqueues the same work on the
  * runtime's stream and returns; ju_synchronize() waits.  Frames are still

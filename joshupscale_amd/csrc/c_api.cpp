@@ -152,6 +152,22 @@ int ju_process_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image
 	});
 }
 
+int ju_prepare_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image *outputs, int count, int *captured) {
+	if (captured) *captured = 0;
+	return guarded([&] {
+		if (count < 0 || (count > 0 && (inputs == nullptr || outputs == nullptr))) {
+			throw std::invalid_argument("ju_prepare_batch: NULL images or a negative count");
+		}
+		std::vector<ju::Frame> in(static_cast<std::size_t>(count)), out(static_cast<std::size_t>(count));
+		for (int i = 0; i < count; ++i) {
+			in[i] = toFrame(inputs + i);
+			out[i] = toFrame(outputs + i);
+		}
+		const int n = engineOf(runtime).prepareBatch(in.data(), out.data(), count);
+		if (captured) *captured = n;
+	});
+}
+
 int ju_enqueue(ju_runtime *runtime, const ju_image *input, const ju_image *output) {
 	return guarded([&] {
 		const ju::Frame in = toFrame(input), out = toFrame(output);

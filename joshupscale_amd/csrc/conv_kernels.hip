@@ -144,6 +144,15 @@ __device__ __forceinline__ void convChunkMfma(const unsigned char *smW, const un
 // no upsample launch.
 template <typename T, int TAPS, int CK, int NB, int RW, bool DBUF, bool UPS = false>
 __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
+	// (a look-ahead launch, ConvParams::items > 1: grid.z = frames x cout groups, the frame's tensors `item` strides on)
+	int cogOfBlock = blockIdx.z;
+	if (p.items > 1) {
+		const int ncog = gridDim.z / p.items;
+		const int item = cogOfBlock / ncog;
+		cogOfBlock -= item * ncog;
+		p.in = static_cast<const unsigned char *>(p.in) + item * p.inItemBytes;
+		p.out = static_cast<unsigned char *>(p.out) + item * p.outItemBytes;
+	}
 	constexpr int HALO = (TAPS == 9) ? 1 : 0;
 	constexpr int TH = 4 * RW;            // tile rows: 4 waves x RW rows each
 	constexpr int IW = kTW + 2 * HALO;    // staged tile incl. halo
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_mfma_kernel(ConvParams p) {
 	const int hh = lane >> 5;
 	const int tx0 = blockIdx.x * kTW;
 	const int ty0 = blockIdx.y * TH;
-	const int cog = blockIdx.z;
+	const int cog = cogOfBlock;
 	const int nCC = p.cin / CK;
 	const int inPitch = p.inPitch ? p.inPitch : p.W;
 	const int outPitch = p.outPitch ? p.outPitch : p.W;
@@ -521,7 +530,8 @@ void launchConvInst(const ConvParams &p, hipStream_t stream) {
 	auto kern = conv_mfma_kernel<T, TAPS, CK, NB, RW, DBUF, UPS>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), ldsMax, &ldsDone, "conv");
-	dim3 grid((p.W + kTW - 1) / kTW, (p.H + 4 * RW - 1) / (4 * RW), p.cout / (32 * NB));
+	if (launchesAreDry()) return;
+	dim3 grid((p.W + kTW - 1) / kTW, (p.H + 4 * RW - 1) / (4 * RW), p.cout / (32 * NB) * (p.items > 1 ? p.items : 1));
 	hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, p);
 	hipCheckLaunch("conv_mfma");
 }
@@ -586,7 +596,7 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 }  // namespace
 
 void launchConv(DType dt, const ConvParams &p, hipStream_t stream) {
-	if (p.items > 1) throw std::invalid_argument("launchConv: no look-ahead (items > 1) form of this kernel");
+	if (p.items > 1 && p.res != nullptr) throw std::invalid_argument("launchConv: a look-ahead launch (items > 1) takes no residual");
 	if (dt == kF16) launchConvT<f16>(p, stream);
 	else launchConvT<bf16>(p, stream);
 }

@@ -14,6 +14,13 @@
 
 namespace ju {
 
+namespace {
+thread_local int g_DryLaunches = 0;
+}
+bool launchesAreDry() { return g_DryLaunches > 0; }
+DryLaunchScope::DryLaunchScope() { ++g_DryLaunches; }
+DryLaunchScope::~DryLaunchScope() { --g_DryLaunches; }
+
 Engine::Tensor &Engine::addTensor(
     const std::string &name, std::size_t count, bool f32, bool state) {
 	Tensor t;
@@ -291,9 +298,8 @@ void Engine::addConvStep(std::vector<Step> *prog, const std::string &tag,
 		p.items = item.items;
 		p.inItemBytes = item.in;
 		p.outItemBytes = item.out;
-		if (tower || !(cw.splitK && convSplitKSupported(p))) {
-			throw std::logic_error("look-ahead: no batched form of " + wname);
-		}
+		// (split-K and generic convolutions have an item dimension; the tower kernel and residual inputs do not)
+		if (tower || p.res != nullptr) throw std::logic_error("look-ahead: no batched form of " + wname);
 	}
 	if (tower) {
 		s.run = [dt, p](hipStream_t st) { launchConvTower(dt, p, st); };
@@ -433,10 +439,10 @@ void Engine::addFlowAutoencoder(std::vector<Step> *progOut, int set, int items) 
 						cur = Op(n + "/a_2");
 						curItem = itemBytes(n + "/a_2");
 					} else {
-						noBatch("the upsampling launch");
 						prog.push_back({"flow", 0.0,
-						    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
+						    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s, items); }});
 						cur = Operand{dst, 0};
+						curItem = itemBytes(n + "/resample");
 					}
 				}
 				h *= 2;
@@ -474,10 +480,10 @@ void Engine::addFlowAutoencoder(std::vector<Step> *progOut, int set, int items) 
 				cur = Op(n + "/a_2");
 				curItem = itemBytes(n + "/a_2");
 			} else {
-				noBatch("the upsampling launch");
 				prog.push_back({"flow", 0.0,
-				    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s); }});
+				    [=](hipStream_t s) { launchUpsample2(dt, src, dst, h, w, f, s, items); }});
 				cur = Operand{dst, 0};
+				curItem = itemBytes(n + "/resample");
 			}
 			h *= 2;
 			w *= 2;
@@ -490,17 +496,17 @@ void Engine::addFlowAutoencoder(std::vector<Step> *progOut, int set, int items) 
 			upsampleNext = false;
 			flowHeadDone = true;
 		} else {
-			noBatch("the head convolutions");
 			addConvStep(&prog, "flow", "flow/conv_1", cur, none, Op("flow/a_1"), h, w, true, false,
-			    false, false, upsampleNext);
+			    false, false, upsampleNext, ItemStride{items, curItem, itemBytes("flow/a_1")});
 			upsampleNext = false;
 			cur = Op("flow/a_1");
+			curItem = itemBytes("flow/a_1");
 		}
 	}
 	if (upsampleNext) throw std::logic_error("flow head cannot take a half-resolution input");
 	if (!flowHeadDone) {
-		noBatch("the head convolution");
-		addConvStep(&prog, "flow", "flow/conv_2", cur, none, Op("flow"), h, w, false, true);
+		addConvStep(&prog, "flow", "flow/conv_2", cur, none, Op("flow"), h, w, false, true, false, false, false,
+		    ItemStride{items, curItem, itemBytes("flow")});
 	}
 }
 
@@ -1627,10 +1633,42 @@ void Engine::dropBatchGraphs() {
 	m_BatchGraphs.clear();
 }
 
-// One look-ahead pass over frames [0, n): enqueue only.  The caller holds nothing; on return the binding set is
-// flipped ONCE (see above).
-void Engine::submitBatch(const Frame *in, const Frame *out, int n) {
-	const int set = m_Idx;
+// The launches of one look-ahead pass over the n frames of m_BatchIO, in stream order (recorded when m_Stream is
+// capturing): the flow net over all frames, then frame by frame the rest of binding set `set`'s per-frame program,
+// bound to the frame's buffers, its flow field and its link of the state chain.
+void Engine::runBatch(int set, int n, const std::function<void(const Step &, bool)> *around) {
+	auto run = [&](const Step &st) {
+		if (around) (*around)(st, false);
+		st.run(m_Stream);
+		if (around) (*around)(st, true);
+	};
+	const std::vector<Step> &flow = m_BatchFlow.at({n, set});
+	const long flowItem = static_cast<long>(m_Tensors.at("flow").count) * 2;
+	const unsigned char *flowBase = m_BatchTensors.at("flow").buf.as<unsigned char>();
+	const FrameIO keepIO = m_IO;
+	const StateBind keepBind = m_StateBind[set];
+	const void *keepFlow = m_FlowCur;
+	struct Restore {
+		std::function<void()> f;
+		~Restore() { f(); }
+	} restore{[&] {
+		m_IO = keepIO;
+		m_StateBind[set] = keepBind;
+		m_FlowCur = keepFlow;
+	}};
+	for (const Step &st : flow) run(st);
+	for (int i = 0; i < n; ++i) {
+		m_IO = m_BatchIO[i];
+		m_FlowCur = flowBase + i * flowItem;
+		m_StateBind[set].in = i == 0 ? keepBind.in : m_BatchState[i - 1].get();
+		m_StateBind[set].out = i + 1 == n ? keepBind.out : m_BatchState[i].get();
+		for (const Step &st : m_Program[set]) {
+			if (st.tag != "flow" && st.tag != "pack") run(st);
+		}
+	}
+}
+
+std::vector<Engine::DirectKey> Engine::bindBatch(const Frame *in, const Frame *out, int n, int set) {
 	std::vector<DirectKey> key(static_cast<std::size_t>(n));
 	for (int i = 0; i < n; ++i) {
 		m_BatchIO[i].in = static_cast<const std::uint8_t *>(in[i].ptr);
@@ -1639,55 +1677,66 @@ void Engine::submitBatch(const Frame *in, const Frame *out, int n) {
 		m_BatchIO[i].outStride = out[i].stride;
 		key[i] = DirectKey{in[i].ptr, in[i].stride, out[i].ptr, out[i].stride, set};
 	}
-	const std::vector<Step> &flow = m_BatchFlow.at({n, set});
-	const long flowItem = static_cast<long>(m_Tensors.at("flow").count) * 2;
-	const unsigned char *flowBase = m_BatchTensors.at("flow").buf.as<unsigned char>();
-	// the pass's launches, in stream order: the flow net over all frames, then frame by frame the rest of the
-	// per-frame program of this binding set, bound to the frame's buffers, flow field and link of the state chain
-	auto runAll = [&] {
-		const FrameIO keepIO = m_IO;
-		const StateBind keepBind = m_StateBind[set];
-		const void *keepFlow = m_FlowCur;
-		struct Restore {
-			std::function<void()> f;
-			~Restore() { f(); }
-		} restore{[&] {
-			m_IO = keepIO;
-			m_StateBind[set] = keepBind;
-			m_FlowCur = keepFlow;
-		}};
-		for (const Step &st : flow) st.run(m_Stream);
-		for (int i = 0; i < n; ++i) {
-			m_IO = m_BatchIO[i];
-			m_FlowCur = flowBase + i * flowItem;
-			m_StateBind[set].in = i == 0 ? keepBind.in : m_BatchState[i - 1].get();
-			m_StateBind[set].out = i + 1 == n ? keepBind.out : m_BatchState[i].get();
-			for (const Step &st : m_Program[set]) {
-				if (st.tag != "flow" && st.tag != "pack") st.run(m_Stream);
+	return key;
+}
+
+Engine::DirectEntry &Engine::batchEntry(const std::vector<DirectKey> &key) {
+	auto it = m_BatchGraphs.find(key);
+	if (it == m_BatchGraphs.end()) {
+		if (m_BatchGraphs.size() >= kMaxBatchGraphs) {  // least recently used out
+			auto victim = m_BatchGraphs.begin();
+			for (auto j = m_BatchGraphs.begin(); j != m_BatchGraphs.end(); ++j) {
+				if (j->second.lastUse < victim->second.lastUse) victim = j;
 			}
+			m_BatchGraphs.erase(victim);
 		}
-	};
+		it = m_BatchGraphs.emplace(key, DirectEntry{}).first;
+	}
+	it->second.lastUse = ++m_DirectClock;
+	return it->second;
+}
+
+// ju_prepare_batch: the graphs of a tuple of frame buffers a caller is going to hand to processBatch, one per
+// binding set, captured NOW (as prepareFrames does for one pair): nothing executes, no buffer is touched.  Returns
+// the graphs captured; 0 for a tuple that will not go as one pass.
+int Engine::prepareBatch(const Frame *in, const Frame *out, int n) {
+	if (n < 0 || (n > 0 && (in == nullptr || out == nullptr))) throw std::invalid_argument("prepareBatch: bad arguments");
+	DeviceGuard g(m_Device);
+	if (n < 2 || n > m_BatchMax || !m_UseGraph || !m_DirectGraph) return 0;
+	for (int i = 0; i < n; ++i) {
+		if (!directEligible(in[i], out[i])) return 0;
+	}
+	if (!batchPlanned(n)) return 0;
+	std::unique_lock<std::mutex> chain = chainBegin();  // (no capture while another engine's constructor drains the device)
+	int captured = 0;
+	for (int set = 0; set < 2; ++set) {
+		DirectEntry &e = batchEntry(bindBatch(in, out, n, set));
+		if (e.graph.valid()) continue;
+		{
+			DryLaunchScope dry;  // the attributes of the tile heights this pass's launch sizes choose
+			for (const Step &st : m_BatchFlow.at({n, set})) st.run(m_Stream);
+		}
+		e.graph = GraphExec::capture(m_Stream, [&] { runBatch(set, n); });
+		e.seen = 2;
+		++captured;
+		++m_PreparedCaptures;
+	}
+	return captured;
+}
+
+// One look-ahead pass over frames [0, n): enqueue only.  On return the binding set is flipped ONCE (see above).
+void Engine::submitBatch(const Frame *in, const Frame *out, int n) {
+	const int set = m_Idx;
+	const std::vector<DirectKey> key = bindBatch(in, out, n, set);
 	{
 		std::unique_lock<std::mutex> chain = chainBegin();
 		bool replayed = false;
 		if (m_UseGraph && m_DirectGraph) {
-			auto it = m_BatchGraphs.find(key);
-			if (it == m_BatchGraphs.end()) {
-				if (m_BatchGraphs.size() >= kMaxBatchGraphs) {  // least recently used out
-					auto victim = m_BatchGraphs.begin();
-					for (auto j = m_BatchGraphs.begin(); j != m_BatchGraphs.end(); ++j) {
-						if (j->second.lastUse < victim->second.lastUse) victim = j;
-					}
-					m_BatchGraphs.erase(victim);
-				}
-				it = m_BatchGraphs.emplace(key, DirectEntry{}).first;
-			}
-			DirectEntry &e = it->second;
-			e.lastUse = ++m_DirectClock;
+			DirectEntry &e = batchEntry(key);
 			// (first sighting: eager -- it also sets the dynamic-LDS attribute of a tile height this pass's launch
 			// sizes choose for the first time, which must not happen inside a capture; second: capture and replay)
 			if (!e.graph.valid() && ++e.seen >= 2) {
-				e.graph = GraphExec::capture(m_Stream, runAll);
+				e.graph = GraphExec::capture(m_Stream, [&] { runBatch(set, n); });
 				++m_InlineCaptures;
 			}
 			if (e.graph.valid()) {
@@ -1697,7 +1746,7 @@ void Engine::submitBatch(const Frame *in, const Frame *out, int n) {
 			}
 		}
 		if (!replayed) {
-			runAll();
+			runBatch(set, n);
 			++m_EagerRuns;
 		}
 		chainEnd(chain);
@@ -1893,7 +1942,9 @@ std::size_t Engine::readTensor(const std::string &name, float *dst, std::size_t 
 
 double Engine::flopsOf(const std::string &tagSpecIn) const {
 	std::string tagSpec = tagSpecIn;
-	const std::size_t at = tagSpec.find("@frame");
+	std::size_t at = tagSpec.find("@frame");
+	bool inPass = false;
+	if (at == std::string::npos && (at = tagSpec.find("@pass")) != std::string::npos) inPass = true;
 	if (at != std::string::npos) tagSpec = tagSpec.substr(0, at);
 	std::string tag = tagSpec;
 	int only = -1;
@@ -1904,7 +1955,9 @@ double Engine::flopsOf(const std::string &tagSpecIn) const {
 	}
 	double f = 0.0;
 	int k = 0;
-	for (const Step &s : m_Program[0]) {
+	// ("flow@pass": the pass's flow launches, each over all its frames -- once timeSteps has planned them)
+	const auto passFlow = m_BatchFlow.find({m_BatchMax, 0});
+	for (const Step &s : (inPass && tag == "flow" && passFlow != m_BatchFlow.end()) ? passFlow->second : m_Program[0]) {
 		if (tag.empty() || s.tag == tag) {
 			if (only < 0 || k == only) f += s.flops;
 			++k;
@@ -1920,12 +1973,19 @@ double Engine::timeSteps(const std::string &tagSpecIn, int iters, int *launches)
 	// tagged launches): the kernel in the clock / cache context of the real workload, which is
 	// what a kernel trace of the benchmark averages -- back-to-back launches of the tower alone
 	// draw more power and read 4-5 % slower on the same box
+	// "tower@pass" = the same inside look-ahead passes of JU_LOOKAHEAD frames (processBatch): there the towers of
+	// consecutive frames follow one another with only the warp in between; "flow@pass": the pass's flow launches
+	// (each covers all frames of the pass)
 	std::string tagSpec = tagSpecIn;
-	bool inFrame = false;
-	const std::size_t at = tagSpec.find("@frame");
+	bool inFrame = false, inPass = false;
+	std::size_t at = tagSpec.find("@frame");
 	if (at != std::string::npos) {
 		inFrame = true;
 		tagSpec = tagSpec.substr(0, at);
+	} else if ((at = tagSpec.find("@pass")) != std::string::npos) {
+		inPass = true;
+		tagSpec = tagSpec.substr(0, at);
+		if (m_BatchMax < 2 || !batchPlanned(m_BatchMax)) throw std::invalid_argument("timeSteps: this model has no look-ahead passes");
 	}
 	std::string tag = tagSpec;
 	int only = -1;
@@ -1936,7 +1996,8 @@ double Engine::timeSteps(const std::string &tagSpecIn, int iters, int *launches)
 	}
 	std::vector<const Step *> steps;
 	int k = 0;
-	for (const Step &s : m_Program[m_Idx]) {
+	const bool passFlow = inPass && tag == "flow";
+	for (const Step &s : passFlow ? m_BatchFlow.at({m_BatchMax, m_Idx}) : m_Program[m_Idx]) {
 		if (tag.empty() || s.tag == tag) {
 			if (only < 0 || k == only) steps.push_back(&s);
 			++k;
@@ -1950,7 +2011,23 @@ double Engine::timeSteps(const std::string &tagSpecIn, int iters, int *launches)
 	m_IO.outStride = static_cast<std::ptrdiff_t>(m_Config.frameWidth) * 16;
 	double ms = 0.0;
 	std::unique_lock<std::mutex> chain = chainBegin();  // (the timed launches may be resident towers)
-	if (inFrame) {
+	if (inPass) {
+		const int n = m_BatchMax, set = m_Idx;
+		for (int i = 0; i < n; ++i) m_BatchIO[i] = m_IO;  // (every frame of the pass on the staging buffers)
+		std::vector<std::unique_ptr<Event>> ev;
+		const std::function<void(const Step &, bool)> around = [&](const Step &s, bool) {
+			if (std::find(steps.begin(), steps.end(), &s) == steps.end()) return;
+			ev.emplace_back(new Event());
+			ev.back()->record(m_Stream);
+		};
+		runBatch(set, n);  // warm
+		for (int i = 0; i < iters; ++i) runBatch(set, n, &around);
+		chainEnd(chain);
+		m_Stream.synchronize();
+		double sum = 0.0;
+		for (std::size_t i = 0; i + 1 < ev.size(); i += 2) sum += static_cast<double>(Event::elapsedMs(*ev[i], *ev[i + 1]));
+		ms = ev.empty() ? 0.0 : sum / (static_cast<double>(ev.size()) / 2);
+	} else if (inFrame) {
 		auto isTimed = [&](const Step *s) { return std::find(steps.begin(), steps.end(), s) != steps.end(); };
 		for (const Step &s : m_Program[m_Idx]) s.run(m_Stream);  // warm
 		std::vector<std::unique_ptr<Event>> ev;

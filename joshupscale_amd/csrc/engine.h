@@ -60,6 +60,10 @@ public:
 	// auto-encoder's one-launch plan) the flow fields of up to kFlowBatchMax frames are computed in one pass of the
 	// flow net's launches (engine.cpp, "Frame look-ahead"); anything else runs frame by frame.
 	void processBatch(const Frame *in, const Frame *out, int count);
+	// Registers a tuple of device-resident frame buffers the caller is going to hand to processBatch as ONE pass
+	// (2 .. JU_LOOKAHEAD frames): its graphs, one per binding set, are captured now -- what prepareFrames is to
+	// process.  Nothing executes.  Returns the graphs captured (0: the tuple will not go as one pass).
+	int prepareBatch(const Frame *in, const Frame *out, int count);
 	// Asynchronous variant for device-resident frames: enqueue only.
 	void enqueue(const Frame &in, const Frame &out);
 	void synchronize();
@@ -306,7 +310,10 @@ private:
 	std::uint64_t m_BatchFrames = 0;
 	bool batchPlanned(int items);
 	void submitBatch(const Frame *in, const Frame *out, int n);
+	void runBatch(int set, int n, const std::function<void(const Step &, bool)> *around = nullptr);
 	void dropBatchGraphs();
+	std::vector<DirectKey> bindBatch(const Frame *in, const Frame *out, int n, int set);
+	DirectEntry &batchEntry(const std::vector<DirectKey> &key);
 	std::uint64_t m_DirectClock = 0;
 	bool m_DirectGraph = true;  // JU_DIRECT_GRAPH=0: device frames always launch eagerly
 	static constexpr std::size_t kMaxDirectGraphs = 64;     // unregistered tuples (LRU)

@@ -580,6 +580,7 @@ void launchFlowBlockInst(const FlowBlockParams &p, int items, hipStream_t stream
 	auto kern = flow_block_kernel<T, CIN, CMID, TH, UPS, POOL, OUTK, NW, PACK>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "flow block");
+	if (launchesAreDry()) return;
 	dim3 grid((p.W + kFbOutW - 1) / kFbOutW, (p.H + TH - 1) / TH, items);
 	hipLaunchKernelGGL(kern, grid, dim3(NW * 64), G::LDS, stream, p);
 	hipCheckLaunch("flow_block");

@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2_kernel(
     const T *__restrict__ in, T *__restrict__ out, int H, int W, int C) {
+	// (blockIdx.y: the frame of a look-ahead launch, dense tensors one after the other)
+	in += (size_t)blockIdx.y * H * W * C;
+	out += (size_t)blockIdx.y * H * W * C * 4;
 	// tf.compat.v1.image.resize_bilinear(align_corners=False,
 	// half_pixel_centers=False): src = dst / 2 (reference keras_layers.py:46-52)
 	const int OH = H * 2, OW = W * 2, CC = C / 8;
@@ -638,13 +641,14 @@ void launchMaxPool2(DType dt, const void *in, void *out, int H, int W, int C, hi
 	hipCheckLaunch("maxpool2");
 }
 
-void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, hipStream_t stream) {
+void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, hipStream_t stream, int items) {
 	const unsigned nb = blocksFor((size_t)(H * 2) * (W * 2) * (C / 8));
+	if (launchesAreDry()) return;
 	if (dt == kF16) {
-		hipLaunchKernelGGL(upsample2_kernel<f16>, dim3(nb), dim3(256), 0, stream,
+		hipLaunchKernelGGL(upsample2_kernel<f16>, dim3(nb, items > 1 ? items : 1), dim3(256), 0, stream,
 		    static_cast<const f16 *>(in), static_cast<f16 *>(out), H, W, C);
 	} else {
-		hipLaunchKernelGGL(upsample2_kernel<bf16>, dim3(nb), dim3(256), 0, stream,
+		hipLaunchKernelGGL(upsample2_kernel<bf16>, dim3(nb, items > 1 ? items : 1), dim3(256), 0, stream,
 		    static_cast<const bf16 *>(in), static_cast<bf16 *>(out), H, W, C);
 	}
 	hipCheckLaunch("upsample2");

@@ -116,6 +116,18 @@ void launchConv(DType dt, const ConvParams &p, hipStream_t stream);
 // conv A 3x3 cin -> cmid, activation, conv B 3x3 cmid -> cmid, [activation], [2x2
 // max-pool]; `upsample`: `in` is the half-resolution tensor [H/2][W/2][cin] and the TF1
 // bilinear x2 is part of the tile staging.  Weights: packConvWeights with nb = 1.
+// Attribute-only launches: while a DryLaunchScope lives on the calling thread, launchFlowBlock and launchConvSplitK
+// do everything a launch does on the host (shape checks, tile choice, the dynamic-LDS attribute of an instantiation
+// used for the first time) but enqueue nothing -- Engine::prepareBatch runs a look-ahead pass's flow launches this
+// way before it CAPTURES them (hipFuncSetAttribute is not something to do inside a stream capture).
+bool launchesAreDry();
+struct DryLaunchScope {
+	DryLaunchScope();
+	~DryLaunchScope();
+	DryLaunchScope(const DryLaunchScope &) = delete;
+	DryLaunchScope &operator=(const DryLaunchScope &) = delete;
+};
+
 constexpr int kFlowBatchMax = 8;  // frames per look-ahead pass of the flow net (Engine::processBatch)
 struct FlowBlockLaunch {
 	const void *in;
@@ -320,8 +332,9 @@ void launchExpandChannels(DType dt, const void *in16, void *out64, int nPix, hip
 void launchMaxPool2(DType dt, const void *in, void *out, int H, int W, int C,
     hipStream_t stream);  // in [H][W][C] -> out [H/2][W/2][C]
 
-void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C,
-    hipStream_t stream);  // TF1 asymmetric bilinear, in [H][W][C] -> out [2H][2W][C]
+// TF1 asymmetric bilinear, in [H][W][C] -> out [2H][2W][C]; items > 1: the dense tensors of a look-ahead launch's
+// frames, one after the other
+void launchUpsample2(DType dt, const void *in, void *out, int H, int W, int C, hipStream_t stream, int items = 1);
 
 // ---- warp + space-to-depth + concat ----------------------------------------
 // state : previous HR output, f16 [4H][4W][4] (B,G,R,0)

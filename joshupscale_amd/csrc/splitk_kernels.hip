@@ -247,6 +247,7 @@ void launchSplitKInst(const SplitKParams &p, int tilesY, int items, hipStream_t 
 	auto kern = conv_splitk_kernel<T, CIN, CB, POOL>;
 	static std::atomic<std::uint64_t> ldsDone{0};
 	ensureDynamicLds(reinterpret_cast<const void *>(kern), G::LDS, &ldsDone, "split-K conv");
+	if (launchesAreDry()) return;
 	hipLaunchKernelGGL(kern, dim3(p.tilesX * tilesY, p.cout / (32 * CB), items), dim3(512), G::LDS, stream, p);
 	hipCheckLaunch("conv_splitk");
 }

@@ -79,6 +79,7 @@ _PRODUCT_SIGS = {
     "ju_destroy": (None, [C.c_void_p]),
     "ju_process": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage)]),
     "ju_process_batch": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), C.c_int]),
+    "ju_prepare_batch": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), C.c_int, _P(C.c_int)]),
     "ju_enqueue": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage)]),
     "ju_synchronize": (C.c_int, [C.c_void_p]),
     "ju_prepare_frames": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), _P(C.c_int)]),
@@ -226,6 +227,17 @@ class Runtime:
             raise ValueError("as many outputs as inputs")
         ins, outs = (JuImage * n)(*inputs), (JuImage * n)(*outputs)
         _check(self._lib, self._lib.ju_process_batch(self._h, ins, outs, n))
+
+    def prepare_batch(self, inputs, outputs) -> int:
+        """``ju_prepare_batch``: capture the graphs of a tuple of device frame buffers that will go through
+        ``process_batch`` as one pass; returns the graphs captured (0: the tuple will not run as one pass)."""
+        n = len(inputs)
+        if len(outputs) != n:
+            raise ValueError("as many outputs as inputs")
+        ins, outs = (JuImage * n)(*inputs), (JuImage * n)(*outputs)
+        got = C.c_int()
+        _check(self._lib, self._lib.ju_prepare_batch(self._h, ins, outs, n, C.byref(got)))
+        return got.value
 
     def enqueue(self, inp: JuImage, out: JuImage) -> None:
         _check(self._lib, self._lib.ju_enqueue(self._h, C.byref(inp), C.byref(out)))

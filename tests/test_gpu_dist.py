@@ -50,7 +50,8 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
     assert res["config"]["submission"]["graph_replays"] > 0
     # the driver's command line (--steps 20 --warmup 5) measures the steady state: every timed
     # frame replays a graph captured in set-up (ju_prepare_frames)
-    assert res["config"]["timed_region"] == {"replays": 20, "eager": 0, "captures": 0}
+    assert res["config"]["timed_region"] == {"replays": 20, "eager": 0, "captures": 0, "lookahead_frames": 0}
+    assert res["config"]["lookahead"]["frames_per_pass"] == 1 and res["config"]["boundary"].startswith("ju_process (")
     assert res["config"]["submission"]["prepared_captures"] == 32 and res["config"]["submission"]["inline_captures"] == 0
     assert len(res["config"]["per_rank_fps"]["values"]) == 1
     # what runs before the timed region is disclosed at the TOP level (advisor, round 3): the contract's W and the
@@ -73,7 +74,7 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
                           capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert bare.returncode == 0, bare.stderr[-2000:]
     res1 = json.loads([ln for ln in bare.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res1["config"]["timed_region"] == {"replays": 20, "eager": 0, "captures": 0}
+    assert res1["config"]["timed_region"] == {"replays": 20, "eager": 0, "captures": 0, "lookahead_frames": 0}
     assert abs(res["value"] / res1["value"] - 1.0) < 0.06, (res["value"], res1["value"])
     # a timed region that is not pure replay is not reported: without registered buffers the 20
     # timed steps would be eager first sightings and inline captures (round 2's driver figure)
@@ -86,3 +87,23 @@ def test_bench_under_torchrun_uses_the_native_broadcast():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert bad.returncode != 0 and "torch.distributed.run" in (bad.stderr + bad.stdout)
+
+
+def test_bench_with_frame_look_ahead_times_pure_replays_of_registered_passes():
+    """--lookahead N (the default, 8, for the headline preset): the timed frames go through ju_process_batch in passes
+    of N whose graphs were captured in set-up (ju_prepare_batch) -- the timed region is replays only, also for the
+    shorter pass at its end --, the dominant kernel is timed inside such passes, and the frame-by-frame figure of
+    the same runtime is reported beside the value."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "21", "--warmup", "5",
+                        "--no-cpu-baseline", "--preset", "psp-fast", "--dtype", "fp16", "--lookahead", "4"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    # 21 frames = five passes of 4 and a single frame (ju_process)
+    assert res["config"]["timed_region"] == {"replays": 6, "eager": 0, "captures": 0, "lookahead_frames": 20}
+    la = res["config"]["lookahead"]
+    assert la["frames_per_pass"] == 4 and la["frame_by_frame_value"] > 100
+    assert res["config"]["boundary"].startswith("ju_process_batch")
+    assert res["steps"] == 21 and res["value"] == pytest.approx(21 / (res["ms_per_step"] * 21e-3), rel=1e-6)
+    assert "tag@pass" in res["roofline"]["launch_ms_how"] and 0.0 < res["roofline"]["frac"] <= 1.0
+    assert res["value"] > 0.95 * la["frame_by_frame_value"]

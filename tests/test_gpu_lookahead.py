@@ -68,9 +68,9 @@ def test_look_ahead_passes_give_the_frame_by_frame_bytes(preset, dtype):
                 assert np.array_equal(got[i], want[t + i]), (preset, "pass of", k, "frame", t + i)
             t += k
         assert np.array_equal(rt.read_tensor("state"), want_state)
-        # (640x448: the 128-filter flow blocks are launches per convolution there, one of them on the generic kernel,
-        # which has no batched form -- the call runs frame by frame)
-        assert rt.stat("lookahead_frames") == (0 if preset == "ps2-quality" else n - 2), "the passes did not take the look-ahead path"
+        # (640x448: the 128-filter flow blocks are launches per convolution there -- split-K, the generic kernel and the
+        # upsampling launch all have an item dimension)
+        assert rt.stat("lookahead_frames") == n - 2, "the passes did not take the look-ahead path"
         assert rt.stat("fallbacks") == 0
 
 
@@ -221,3 +221,30 @@ def test_bad_arguments_are_errors_not_crashes():
         assert lib.ju_process_batch(None, None, None, 0) != 0
         rt.reset()
         rt.process_batch([good_in, good_in], [good_out, good_out])
+
+
+def test_prepare_batch_captures_in_setup_and_the_passes_only_replay():
+    """ju_prepare_batch is to ju_process_batch what ju_prepare_frames is to ju_process: the graphs of a registered
+    tuple (one per binding set) exist before its first pass, which therefore replays -- no eager first sighting, no
+    capture inside the call -- and writes the bytes of an unregistered runtime.  Tuples that cannot run as one pass
+    (a single frame, host frames, more frames than JU_LOOKAHEAD) register nothing."""
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames, d_in, d_out = _device_clip(cfg, 8, seed=77, outs=4)
+    want, _ = _frame_by_frame(blob, R.DTYPE_BF16, cfg, d_in, d_out, 8)
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        ins = [rt.device_image(d_in[t].data_ptr(), w, h) for t in range(8)]
+        outs = [rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h) for t in range(4)]
+        assert rt.prepare_batch(ins[:4], outs) == 2 and rt.prepare_batch(ins[4:], outs) == 2
+        assert rt.prepare_batch(ins[:4], outs) == 0                         # registered already
+        assert rt.prepare_batch(ins[:1], outs[:1]) == 0
+        assert rt.prepare_batch(ins + ins[:1], outs + outs + outs[:1]) == 0  # nine frames: not one pass
+        assert rt.prepare_batch([R.host_image(frames[0]), ins[1]], outs[:2]) == 0
+        assert rt.stat("prepared_captures") == 4 and rt.stat("eager_runs") == 0
+        for p in range(2):
+            rt.process_batch(ins[4 * p:4 * p + 4], outs)
+            got = d_out.cpu().numpy()
+            for i in range(4):
+                assert np.array_equal(got[i], want[4 * p + i]), (p, i)
+        assert rt.stat("graph_replays") == 2 and rt.stat("eager_runs") == 0 and rt.stat("graph_captures") == 0
