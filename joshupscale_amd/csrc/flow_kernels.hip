@@ -641,8 +641,10 @@ void launchFlowBlockT(const FlowBlockParams &p, int items, int numCUs, hipStream
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, kFbMid, 6>(p, items, numCUs, stream);
 	} else if constexpr (CMID == 128) {
 		// (the 128-filter blocks, 68 x 120 at 480 x 270: a few thousand pixels -- short tiles, or most of the chip idles;
-		// measured for the encoder block: 2 rows 11.7 us, 4 rows 16.0, 6 rows 19.9)
-		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 2>(p, items, numCUs, stream);
+		// measured for the encoder block: 2 rows 11.7 us, 4 rows 16.0, 6 rows 19.9.  One frame is a single round of
+		// 2-row tiles; a look-ahead launch of 8 frames is five such rounds or two of 6-row tiles -- the cost rule above
+		// picks.  The decoder block's four input planes leave LDS for 2 rows only.)
+		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 6, 4, 2>(p, items, numCUs, stream);
 	} else {
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 20, 18, 10, 6>(p, items, numCUs, stream);
 	}

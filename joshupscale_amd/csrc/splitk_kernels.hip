@@ -289,18 +289,37 @@ void launchConvSplitK(DType dt, const ConvParams &q, const void *zeros, hipStrea
 	// LDS) when even the tallest tile leaves more workgroups than CUs.
 	const int nCog = q.cout / 32;
 	int cb = 1, th = 2;
-	for (;;) {
-		bool found = false;
-		for (th = 2; th <= 16; th += 2) {
-			if ((long)p.tilesX * ((q.H + th - 1) / th) * (nCog / cb) * items <= cus) {
-				found = true;
-				break;
+	if (items > 1) {
+		// A look-ahead launch has several rounds' worth of tiles: the height (and cout blocks per workgroup) whose
+		// rounds x (rows + a tile's fixed part: weights, ramp -- about six rows' worth) is smallest.  34 x 60, 256
+		// couts, 8 frames: 18-row tiles are exactly one round (2 x 2 x 8 x 8 = 256 workgroups); the one-frame rule
+		// below would stop at 16 rows and pay 1.5 rounds (53 -> 33 us per pass, profiles/r05_flow_layers_pass.txt).
+		long best = -1;
+		for (int c = 1; c <= ((q.cin == 128 && nCog % 2 == 0) ? 2 : 1); ++c) {
+			for (int t = 2; t <= 34; t += 2) {
+				const long wgs = (long)p.tilesX * ((q.H + t - 1) / t) * (nCog / c) * items;
+				const long cost = (wgs + cus - 1) / cus * c * (std::min(t, (q.H + 1) / 2 * 2) + 6);
+				if (best < 0 || cost < best) {
+					best = cost;
+					cb = c;
+					th = t;
+				}
 			}
 		}
-		if (found || cb == 2 || q.cin != 128 || nCog % 2) break;
-		cb = 2;
+	} else {
+		for (;;) {
+			bool found = false;
+			for (th = 2; th <= 16; th += 2) {
+				if ((long)p.tilesX * ((q.H + th - 1) / th) * (nCog / cb) <= cus) {
+					found = true;
+					break;
+				}
+			}
+			if (found || cb == 2 || q.cin != 128 || nCog % 2) break;
+			cb = 2;
+		}
+		if (th > 16) th = 16;
 	}
-	if (th > 16) th = 16;
 	p.TH = th;
 	const int tilesY = (q.H + th - 1) / th;
 	const bool f16t = dt == kF16;

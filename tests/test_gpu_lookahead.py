@@ -1,6 +1,6 @@
 """Frame look-ahead (ju_process_batch; engine.cpp "Frame look-ahead") -- needs an MI355X.
 
-The flow net reads LR frames only (reference models.py:795-800: its input is the packed history of the last
+The flow net reads LR frames only (reference models.py:790, 823: its input is the current frame and the history of the last
 num_flow_inputs frames), so the flow fields of several consecutive frames are computed in one pass of the flow net's
 launches; warp, tower and tail stay frame by frame.  The contract is byte equality with ju_process called frame by
 frame -- frames, recurrent state and frame history -- for every pass length, both parities, across passes, mixed with

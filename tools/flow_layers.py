@@ -21,6 +21,21 @@ for k in range(n):
     print(f"flow#{k:2d}: {best:7.2f} us  {fl / 1e9:6.2f} GFLOP  {fl / best / 1e6 if best else 0:7.1f} TFLOP/s")
 ms, n, fl = rt.time_steps("flow", 20)
 print(f"sum of isolated launches {total:.1f} us; back-to-back {ms * n * 1e3:.1f} us per frame")
+# the same launches over the frames of a look-ahead pass (JU_LOOKAHEAD, default 8), timed inside whole passes
+look = int(rt.stat("lookahead_max"))
+if look > 1:
+    try:
+        _, n, _ = rt.time_steps("flow@pass", 1)
+        total = 0.0
+        for k in range(n):
+            best = min(rt.time_steps(f"flow#{k}@pass", 10)[0] for _ in range(3)) * 1e3
+            fl = rt.time_steps(f"flow#{k}@pass", 1)[2]
+            total += best
+            print(f"pass of {look} flow#{k:2d}: {best:7.2f} us = {best / look:6.2f} us per frame  {fl / 1e9:6.2f} GFLOP  "
+                  f"{fl / best / 1e6 if best else 0:7.1f} TFLOP/s")
+        print(f"pass of {look}: flow launches {total:.1f} us = {total / look:.1f} us per frame")
+    except R.JoshUpscaleError as e:
+        print("no look-ahead passes:", e)
 for tag in ["pack", "flow", "warp", "tower", "tail", ""]:
     ms, n, fl = rt.time_steps(tag, 10)
     print(f"stage {tag or 'ALL':9s}: {n:3d} launches, {ms * n * 1e3:8.1f} us per frame")

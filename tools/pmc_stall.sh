@@ -16,7 +16,7 @@ for set in "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/ps_$TAG$i
-  timeout 250 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/ps_$TAG$i -- python3 $R/bench.py $EXTRA --steps 6 --warmup 2 --no-cpu-baseline --roofline-iters 1 > $R/gpurun_out/ps_$TAG$i.log 2>&1
+  timeout 250 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/ps_$TAG$i -- python3 $R/bench.py $EXTRA --lookahead 1 --steps 6 --warmup 2 --no-cpu-baseline --roofline-iters 1 > $R/gpurun_out/ps_$TAG$i.log 2>&1
 done
 PAT="$PAT" TAG="$TAG" python3 - <<'PY'
 import csv, glob, os, collections, json, re

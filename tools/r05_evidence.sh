@@ -25,6 +25,7 @@ done
 bash tools/variants.sh > $O/variants.txt 2>&1
 python3 tools/flow_layers.py > $O/flow_layers.txt 2>&1
 python3 tools/tower_phases.py > $O/tower_phases.txt 2>&1
-timeout 600 python3 tests/soak_determinism.py 3000 psp-quality bf16 > $O/soak.txt 2>&1
-timeout 600 python3 tests/soak_determinism.py 3000 psp-quality fp8 >> $O/soak.txt 2>&1
+timeout 600 python3 tests/soak_determinism.py 3000 psp-quality bf16 8 > $O/soak.txt 2>&1
+timeout 600 python3 tests/soak_determinism.py 3000 psp-quality fp8 8 >> $O/soak.txt 2>&1
+python3 tools/probes/lookahead_bench.py > $O/lookahead_bench.txt 2>&1
 tail -3 $O/soak.txt; tail -12 $O/pmc_table_psp-quality_bf16.txt; cat $O/flow_layers.txt | tail -8
