@@ -1,5 +1,7 @@
 #include "engine.h"
 
+#include <cstdio>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -1087,7 +1089,6 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	const char *directGraph = std::getenv("JU_DIRECT_GRAPH");
 	m_DirectGraph = !(directGraph && directGraph[0] == '0');
 	if (const char *spin = std::getenv("JU_SYNC_SPIN_US")) m_SpinUs = static_cast<unsigned>(std::atoi(spin));
-	if (const char *pin = std::getenv("JU_PIN_HOST")) m_PinHost = pin[0] == '1';  // (opt-in: engine.h)
 	// frames per look-ahead pass of processBatch (1 = frame by frame)
 	if (const char *la = std::getenv("JU_LOOKAHEAD")) m_BatchMax = std::min(std::max(std::atoi(la), 1), kFlowBatchMax);
 
@@ -1104,8 +1105,25 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		// One eager pass per binding set: sets the kernels' dynamic-LDS attributes
 		// and surfaces launch errors before anything is captured.
 		m_UseGraph = false;
+		// JU_TRACE_STEPS=<file> (developer switch): every launch of this eager pass is appended to the file BEFORE it
+		// runs and waited for after -- the last line names the kernel behind a GPU memory fault, which the runtime
+		// otherwise reports asynchronously and without a name
+		const char *trace = std::getenv("JU_TRACE_STEPS");
+		const bool traceSync = !std::getenv("JU_TRACE_NOSYNC");  // (JU_TRACE_NOSYNC=1: the list only)
 		for (int s = 0; s < 2; ++s) {
-			for (const Step &st : m_Program[s]) st.run(m_Stream);
+			int k = 0;
+			for (const Step &st : m_Program[s]) {
+				if (trace) {
+					if (std::FILE *f = std::fopen(trace, "a")) {
+						std::fprintf(f, "%dx%d dtype %d%s set %d step %d %s\n", W, H, static_cast<int>(m_DType), m_Fp8Tower ? " fp8" : "", s, k,
+						    st.tag.c_str());
+						std::fclose(f);
+					}
+				}
+				st.run(m_Stream);
+				if (trace && traceSync) m_Stream.synchronize();
+				++k;
+			}
 		}
 		m_Stream.synchronize();
 		if (const unsigned code = takeResidentError()) {
@@ -1137,66 +1155,10 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	}
 }
 
-void Engine::noteHostFrame(const void *lowest, std::size_t bytes) {
-	if (!m_PinHost || lowest == nullptr || bytes == 0) return;
-	auto it = m_HostPins.find(lowest);
-	if (it != m_HostPins.end() && it->second.bytes != bytes) {  // the same address, another extent: a different buffer
-		if (it->second.pinned) (void)hipHostUnregister(const_cast<void *>(lowest));
-		(void)hipGetLastError();
-		m_HostPins.erase(it);
-		it = m_HostPins.end();
-	}
-	if (it == m_HostPins.end()) {
-		if (m_HostPins.size() >= kMaxHostPinCandidates) {  // forget the oldest range that holds no registration
-			auto victim = m_HostPins.end();
-			for (auto j = m_HostPins.begin(); j != m_HostPins.end(); ++j) {
-				if (!j->second.pinned && (victim == m_HostPins.end() || j->second.lastUse < victim->second.lastUse)) victim = j;
-			}
-			if (victim != m_HostPins.end()) m_HostPins.erase(victim);
-		}
-		it = m_HostPins.emplace(lowest, HostPin{}).first;
-		it->second.bytes = bytes;
-	}
-	HostPin &h = it->second;
-	h.lastUse = ++m_PinClock;
-	if (h.pinned || h.failed || ++h.seen < 2) return;
-	// second sighting: page-lock it, evicting the least recently used registration when the cache is full
-	std::size_t pinned = 0;
-	auto oldest = m_HostPins.end();
-	for (auto j = m_HostPins.begin(); j != m_HostPins.end(); ++j) {
-		if (!j->second.pinned) continue;
-		++pinned;
-		if (oldest == m_HostPins.end() || j->second.lastUse < oldest->second.lastUse) oldest = j;
-	}
-	if (pinned >= kMaxHostPins && oldest != m_HostPins.end()) {
-		(void)hipStreamSynchronize(m_Stream);  // (no copy of an earlier frame may still be using it)
-		(void)hipHostUnregister(const_cast<void *>(oldest->first));
-		(void)hipGetLastError();
-		oldest->second.pinned = false;
-		oldest->second.seen = 0;
-	}
-	if (hipHostRegister(const_cast<void *>(lowest), bytes, hipHostRegisterDefault) == hipSuccess) {
-		h.pinned = true;
-		++m_PinsMade;
-	} else {
-		(void)hipGetLastError();  // (page-locked by the caller already, overlapping range, out of lockable memory: copy as before)
-		h.failed = true;
-	}
-}
-
-void Engine::releaseHostPins() {
-	for (auto &kv : m_HostPins) {
-		if (kv.second.pinned) (void)hipHostUnregister(const_cast<void *>(kv.first));
-	}
-	(void)hipGetLastError();  // (a buffer the caller has freed since: nothing left to unregister)
-	m_HostPins.clear();
-}
-
 Engine::~Engine() {
 	try {
 		DeviceGuard g(m_Device);
 		(void)hipStreamSynchronize(m_Stream);
-		releaseHostPins();
 		DeviceChain &c = chainOf(m_Device);
 		std::lock_guard<std::mutex> lock(c.mutex);
 		if (c.lastOwner == this) {  // (its event dies with this engine; the work behind it is done)
@@ -1372,8 +1334,6 @@ void Engine::stageIn(const Frame &in) {
 	}
 	switch (in.location) {
 	case Location::Host:
-		noteHostFrame(in.stride > 0 ? src : src + static_cast<std::ptrdiff_t>(rows - 1) * in.stride,
-		    (rows - 1) * static_cast<std::size_t>(in.stride > 0 ? in.stride : -in.stride) + rowBytes);
 		if (in.stride == plain) {
 			JU_HIP(hipMemcpyAsync(dst, src, rowBytes * rows, hipMemcpyHostToDevice, m_Stream));
 		} else if (in.stride > 0) {
@@ -1430,8 +1390,6 @@ void Engine::stageOut(const Frame &out) {
 	}
 	switch (out.location) {
 	case Location::Host:
-		noteHostFrame(out.stride > 0 ? dst : dst + static_cast<std::ptrdiff_t>(rows - 1) * out.stride,
-		    (rows - 1) * static_cast<std::size_t>(out.stride > 0 ? out.stride : -out.stride) + rowBytes);
 		if (out.stride == plain) {
 			JU_HIP(hipMemcpyAsync(dst, src, rowBytes * rows, hipMemcpyDeviceToHost, m_Stream));
 		} else if (out.stride > 0) {
@@ -2095,7 +2053,6 @@ double Engine::stat(const std::string &key) const {
 	if (key == "fallbacks") return static_cast<double>(m_Fallbacks);
 	if (key == "lookahead_frames") return static_cast<double>(m_BatchFrames);  // frames that went through look-ahead passes
 	if (key == "lookahead_max") return static_cast<double>(m_BatchMax);
-	if (key == "host_pins") return static_cast<double>(m_PinsMade);  // host frame buffers page-locked so far
 	if (key == "launches_per_frame") return static_cast<double>(m_Program[0].size());
 	if (key == "tower_variant") return static_cast<double>(towerVariant());  // (developer switch, tests)
 	if (key == "direct_graphs") {

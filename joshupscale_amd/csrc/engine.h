@@ -318,29 +318,13 @@ private:
 	bool m_DirectGraph = true;  // JU_DIRECT_GRAPH=0: device frames always launch eagerly
 	static constexpr std::size_t kMaxDirectGraphs = 64;     // unregistered tuples (LRU)
 	static constexpr std::size_t kMaxRegisteredPairs = 256;
-	// Host frames (JU_LOC_CPU: the AviSynth caller, avisynth_plugin/src/main.cc:113-144).  A copy from / to pageable
-	// memory goes through the runtime's own bounce buffers.  OPT-IN (JU_PIN_HOST=1): a caller buffer seen a SECOND
-	// time is page-locked (hipHostRegister) and copied by DMA from then on -- bounded (LRU of kMaxHostPins
-	// registrations, unregistered on eviction and in the destructor), never for a caller that hands over a fresh
-	// buffer every frame, and a range that cannot be registered is left alone.  Off by default, by measurement
-	// (profiles/r05_host_path_ab.txt): the path is bound by the 8.8 MB that cross PCIe per frame (+174 us at
-	// ~50 GB/s on top of the 496 us frame); page-locking buys +2.3 % (1459 -> 1493 frames/s, p99 0.76 -> 0.68 ms),
-	// and a registration changes how the HIP runtime treats EVERY later copy that touches those addresses: once
-	// the caller's allocator has recycled part of a registered range for another array, the caller's own
-	// hipMemcpy of that array fails with hipErrorInvalidValue (seen in this repository's GPU suite with numpy
-	// buffers and torch).  Only a caller whose frame buffers are stable for the runtime's lifetime should set it.
-	struct HostPin {
-		std::size_t bytes = 0;
-		std::uint64_t lastUse = 0;
-		unsigned seen = 0;
-		bool pinned = false, failed = false;
-	};
-	std::map<const void *, HostPin> m_HostPins;  // keyed by the lowest address of the frame's rows
-	std::uint64_t m_PinClock = 0, m_PinsMade = 0;
-	bool m_PinHost = false;
-	static constexpr std::size_t kMaxHostPins = 32, kMaxHostPinCandidates = 256;
-	void noteHostFrame(const void *lowest, std::size_t bytes);
-	void releaseHostPins();
+	// Host frames (JU_LOC_CPU: the AviSynth caller, avisynth_plugin/src/main.cc:113-144) are copied from / to pageable
+	// memory through the HIP runtime's own bounce buffers.  Page-locking recycled caller buffers (hipHostRegister at a
+	// buffer's second sighting, JU_PIN_HOST=1) was built in round 5, measured at +2.3 % on that PCIe-bound path
+	// (profiles/r05_host_path_ab.txt) and REMOVED: a registration on malloc'ed memory outlives its buffer in the HIP
+	// runtime's view of those addresses -- later pageable copies from a recycled range were done as direct GPU reads of
+	// an unmapped host page ("Memory access fault by GPU ... on address <host heap>", one run in two of the full GPU
+	// suite; before that, hipErrorInvalidValue from torch's own hipMemcpy).  DESIGN.md section 7.
 	// introspection ("graph_replays" / "eager_runs" / "graph_captures": captures of device-frame
 	// graphs made inside process / enqueue, i.e. not by prepareFrames or the constructor)
 	std::uint64_t m_GraphReplays = 0, m_EagerRuns = 0, m_InlineCaptures = 0, m_PreparedCaptures = 0;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # developer tool, GPU box: the host-frame path (JU_LOC_CPU: PCIe-inclusive, never `value`) with and without page-locking
-# recycled caller buffers (JU_PIN_HOST), interleaved, beside the device-frame line of the same box
+# recycled caller buffers (JU_PIN_HOST), interleaved, beside the device-frame line of the same box.
+# (Historical: the switch was removed at the end of round 5 -- csrc/engine.h says why; the "host 1" lines now equal "host 0".)
 for r in 1 2 3; do
   for mode in "device 1" "host 0" "host 1"; do
     set -- $mode
