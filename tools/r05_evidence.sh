@@ -6,6 +6,14 @@ R=$GRAFT_REPO_ROOT
 cd $R
 O=gpurun_out/r05
 mkdir -p $O
+# PMC tables, one per (preset, dtype)
+for pd in "psp-quality bf16" "psp-quality fp8" "ps2-quality fp8" "ps2-quality bf16" "psp-fast fp16"; do
+  set -- $pd
+  bash tools/pmc_all.sh --preset $1 --dtype $2 > $O/pmc_table_$1_$2.txt 2>&1
+  cp gpurun_out/pmc_per_kernel.json $O/pmc_per_kernel_$1_$2.json
+  # (bench.py quotes roofline.traffic from profiles/: the table of THIS source, before the bench lines below are taken)
+  cp gpurun_out/pmc_per_kernel.json profiles/r05_pmc_per_kernel_$1_$2.json
+done
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_cmd_bench.json 2> $O/driver_cmd.err
 for spec in "final" "fp8_psp --dtype fp8 --no-cpu-baseline" "fp8_ps2 --preset ps2-quality --dtype fp8 --no-cpu-baseline" \
             "ps2 --preset ps2-quality --no-cpu-baseline" "fast --preset psp-fast --dtype fp16 --no-cpu-baseline" \
@@ -15,12 +23,6 @@ for spec in "final" "fp8_psp --dtype fp8 --no-cpu-baseline" "fp8_ps2 --preset ps
   bash tools/profile_bench.sh r05_$tag "$@" > /dev/null 2>&1
   cp gpurun_out/bench_r05_$tag.json $O/${tag}_bench.json
   cp $(ls gpurun_out/prof_r05_$tag/*/*_kernel_stats.csv | head -1) $O/${tag}_kernel_stats.csv
-done
-# PMC tables, one per (preset, dtype)
-for pd in "psp-quality bf16" "psp-quality fp8" "ps2-quality fp8" "ps2-quality bf16" "psp-fast fp16"; do
-  set -- $pd
-  bash tools/pmc_all.sh --preset $1 --dtype $2 > $O/pmc_table_$1_$2.txt 2>&1
-  cp gpurun_out/pmc_per_kernel.json $O/pmc_per_kernel_$1_$2.json
 done
 bash tools/variants.sh > $O/variants.txt 2>&1
 python3 tools/flow_layers.py > $O/flow_layers.txt 2>&1
