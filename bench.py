@@ -477,9 +477,10 @@ def main() -> int:
                 "submission": {"graph_replays": product["graph_replays"], "eager_runs": product["eager_runs"],
                                "cached_graphs": product["direct_graphs"], "prepared_captures": prepared,
                                "inline_captures": product["graph_captures"],
-                               "how": "one hipGraph per (input, output, binding set) tuple of device frames, "
-                                      "captured in set-up by ju_prepare_frames (unregistered pairs: at the "
-                                      "tuple's second use), replayed afterwards"},
+                               "how": "one hipGraph per (input, output, binding set) tuple of device frames -- per tuple "
+                                      "of a look-ahead pass's frame buffers when the boundary is ju_process_batch --, "
+                                      "captured in set-up by ju_prepare_frames / ju_prepare_batch (unregistered tuples: at "
+                                      "their second use), replayed afterwards"},
                 "tower": "resident (one launch)" if product["resident_tower"] else "per-layer launches",
                 "latency_ms": {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
                                "max": lat[-1], "frames": len(lat)},

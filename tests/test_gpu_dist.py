@@ -94,7 +94,13 @@ def test_bench_with_frame_look_ahead_times_pure_replays_of_registered_passes():
     of N whose graphs were captured in set-up (ju_prepare_batch) -- the timed region is replays only, also for the
     shorter pass at its end --, the dominant kernel is timed inside such passes, and the frame-by-frame figure of
     the same runtime is reported beside the value."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "21", "--warmup", "5",
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    # (under the launcher, as the driver's scaling runs start it: one rank per GPU, the model over the RCCL broadcast)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "21", "--warmup", "5",
                         "--no-cpu-baseline", "--preset", "psp-fast", "--dtype", "fp16", "--lookahead", "4"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
