@@ -104,7 +104,9 @@ JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image
 /* Frame look-ahead (no reference counterpart; the reference's callers hand over one frame at a time,
  * avisynth_plugin/src/main.cc:113-144): `count` CONSECUTIVE frames of the stream in one synchronous call.
  * outputs[i] receives exactly the bytes ju_process(inputs[i], outputs[i]) called in order would have written,
- * and the recurrent state afterwards is the same -- but ALL inputs must hold their pixels when the call is made.
+ * and the recurrent state afterwards is the same -- but ALL inputs must hold their pixels when the call is made
+ * (an input that overlaps the OUTPUT of an earlier frame of the call -- to be read after that write, frame by frame --
+ * simply starts a new pass).
  * The flow net reads LR frames only, never the HR state, so for JU_LOC_DEVICE frames the runtime computes the flow
  * fields of up to 8 frames in ONE pass of the flow net's launches, which fill the chip where one frame's do not
  * (-30 % flow time per frame at 480x270); warp, tower and tail stay strictly frame by frame.  Frames the pass

@@ -1720,9 +1720,27 @@ void Engine::processBatch(const Frame *in, const Frame *out, int count) {
 	DeviceGuard g(m_Device);
 	int i = 0;
 	while (i < count) {
-		// the longest run of frames from i that can go as one pass
+		// the longest run of frames from i that can go as one pass: device-resident, and none of them READING what an
+		// earlier frame of the pass writes (frame by frame such an input would be read after that write; the pass's flow
+		// sweep reads every input first)
+		auto range = [](const Frame &f) {
+			const auto rows = static_cast<std::ptrdiff_t>(f.height);
+			const auto *p0 = static_cast<const std::uint8_t *>(f.ptr);
+			const std::uint8_t *lo = f.stride >= 0 ? p0 : p0 + (rows - 1) * f.stride;
+			const std::size_t bytes = static_cast<std::size_t>(rows - 1) * static_cast<std::size_t>(f.stride >= 0 ? f.stride : -f.stride) + f.width * 4;
+			return std::make_pair(lo, lo + bytes);
+		};
 		int n = 0;
-		while (i + n < count && n < m_BatchMax && directEligible(in[i + n], out[i + n])) ++n;
+		while (i + n < count && n < m_BatchMax && directEligible(in[i + n], out[i + n])) {
+			const auto r = range(in[i + n]);
+			bool clash = false;
+			for (int k = 0; k < n && !clash; ++k) {
+				const auto w = range(out[i + k]);
+				clash = r.first < w.second && w.first < r.second;
+			}
+			if (clash) break;
+			++n;
+		}
 		if (n < 2 || !batchPlanned(n)) {
 			process(in[i], out[i]);
 			++i;

@@ -248,3 +248,38 @@ def test_prepare_batch_captures_in_setup_and_the_passes_only_replay():
             for i in range(4):
                 assert np.array_equal(got[i], want[4 * p + i]), (p, i)
         assert rt.stat("graph_replays") == 2 and rt.stat("eager_runs") == 0 and rt.stat("graph_captures") == 0
+
+
+def test_an_input_that_an_earlier_frame_of_the_call_overwrites_starts_a_new_pass():
+    """Frame by frame, an input buffer that overlaps an EARLIER frame's output is read after that write; a pass's flow
+    sweep would read it before.  The call keeps the frame-by-frame meaning: such a frame starts a new pass.  (Input
+    rows of 480 x 4 bytes inside the first rows of a 1920-pixel-wide output: a caller recycling one big arena.)"""
+    import torch
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames = M.synthetic_frames(4, h, w, seed=13, kind="noise")
+    dev = torch.device("cuda", 0)
+
+    def run(batched):
+        d_in = torch.from_numpy(frames).to(dev)
+        arena = torch.zeros((2, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+        arena[1].view(-1)[: h * w * 4] = d_in[2].view(-1)        # frame 2's pixels live inside output buffer 1 ...
+        torch.cuda.synchronize()
+        got = []
+        with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+            ins = [rt.device_image(d_in[0].data_ptr(), w, h), rt.device_image(d_in[1].data_ptr(), w, h),
+                   rt.device_image(arena[1].data_ptr(), w, h), rt.device_image(d_in[3].data_ptr(), w, h)]
+            # ... which frame 1 writes: frame 2 then reads frame 1's first output rows as its pixels
+            outs = [rt.device_image(arena[0].data_ptr(), 4 * w, 4 * h), rt.device_image(arena[1].data_ptr(), 4 * w, 4 * h),
+                    rt.device_image(arena[0].data_ptr(), 4 * w, 4 * h), rt.device_image(arena[0].data_ptr(), 4 * w, 4 * h)]
+            if batched:
+                rt.process_batch(ins, outs)
+                assert rt.stat("lookahead_frames") == 4          # two passes: frames 0-1 and 2-3
+            else:
+                for i, o in zip(ins, outs):
+                    rt.process(i, o)
+            got = [arena[0].cpu().numpy(), rt.read_tensor("state").copy()]
+        return got
+    a, b = run(False), run(True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
