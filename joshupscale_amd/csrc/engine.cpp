@@ -1579,8 +1579,11 @@ bool Engine::batchPlanned(int items) {
 			m_BatchFlow[{items, set}] = std::move(prog);
 		}
 		return true;
-	} catch (const std::logic_error &e) {
-		logMessage(LogLevel::Info, "Engine", std::string("frame look-ahead is off for this model: ") + e.what());
+	} catch (const std::exception &e) {
+		// (std::logic_error: a launch of this model's flow plan has no item dimension; anything else -- the pass's
+		// tensors did not fit the device -- equally means "frame by frame from now on", not a failed call)
+		logMessage(dynamic_cast<const std::logic_error *>(&e) ? LogLevel::Info : LogLevel::Warning, "Engine",
+		    std::string("frame look-ahead is off for this runtime: ") + e.what());
 		m_BatchUnsupported = true;
 		m_BatchFlow.clear();
 		m_BatchTensors.clear();
