@@ -451,6 +451,9 @@ def main() -> int:
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "preroll": args.preroll, "untimed_frames": args.preroll + args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # the same runtime through the frame-by-frame boundary call (ju_process), measured right after the timed
+            # region: `value` is taken through ju_process_batch passes unless --lookahead 1 / psp-fast / host frames
+            "frame_by_frame_value": per_frame_fps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {

@@ -109,6 +109,7 @@ def test_bench_with_frame_look_ahead_times_pure_replays_of_registered_passes():
     assert res["config"]["timed_region"] == {"replays": 6, "eager": 0, "captures": 0, "lookahead_frames": 20}
     la = res["config"]["lookahead"]
     assert la["frames_per_pass"] == 4 and la["frame_by_frame_value"] > 100
+    assert res["frame_by_frame_value"] == la["frame_by_frame_value"]      # (also at the top level, beside `value`)
     assert res["config"]["boundary"].startswith("ju_process_batch")
     assert res["steps"] == 21 and res["value"] == pytest.approx(21 / (res["ms_per_step"] * 21e-3), rel=1e-6)
     assert "tag@pass" in res["roofline"]["launch_ms_how"] and 0.0 < res["roofline"]["frac"] <= 1.0
