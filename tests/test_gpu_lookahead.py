@@ -283,3 +283,26 @@ def test_an_input_that_an_earlier_frame_of_the_call_overwrites_starts_a_new_pass
         return got
     a, b = run(False), run(True)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("switch", ["JU_NO_GRAPH", "JU_DIRECT_GRAPH"])
+def test_passes_without_graphs_launch_eagerly_and_give_the_same_bytes(switch, monkeypatch):
+    """JU_NO_GRAPH=1 / JU_DIRECT_GRAPH=0 (developer switches): a pass is then the same launches issued one by one."""
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames, d_in, d_out = _device_clip(cfg, 6, seed=29, outs=6)
+    want, want_state = _frame_by_frame(blob, R.DTYPE_F16, cfg, d_in, d_out, 6)
+    monkeypatch.setenv(switch, "1" if switch == "JU_NO_GRAPH" else "0")
+    with R.Runtime(blob, 0, R.DTYPE_F16) as rt:
+        ins = [rt.device_image(d_in[t].data_ptr(), w, h) for t in range(6)]
+        outs = [rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h) for t in range(6)]
+        assert rt.prepare_batch(ins[:3], outs[:3]) == 0           # nothing to capture
+        for rnd in range(2):
+            rt.reset()
+            rt.process_batch(ins[:3], outs[:3])
+            rt.process_batch(ins[3:], outs[3:])
+            got = d_out.cpu().numpy()
+            assert all(np.array_equal(got[t], want[t]) for t in range(6)), rnd
+        assert np.array_equal(rt.read_tensor("state"), want_state)
+        assert rt.stat("lookahead_frames") == 12 and rt.stat("graph_captures") == 0
