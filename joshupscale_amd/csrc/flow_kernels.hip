@@ -79,15 +79,22 @@ struct FbGeom {
 	// lower / right bilinear neighbour
 	static constexpr int LR = XR / 2 + 1, LC = kFbW / 2 + 1;
 	static constexpr int LBYTES = UPS ? NPL * LR * LC * PBX : 0;
+	// XPAIR (the decoder block with four input planes, tiles taller than two rows): the up-sampled input lives in LDS
+	// two planes at a time -- plane p + 1 is expanded from the patch while conv A runs plane p -- so that 4- and 6-row
+	// tiles fit (all four planes: 139 KB of X at 4 rows).  A 2-row tile computes four conv A rows for two (the look-ahead
+	// launches, which are several rounds of tiles whatever the height, were spending half their time there:
+	// profiles/r05_fb_ablate_pass.txt); a 6-row tile eight for six.
+	static constexpr bool XPAIR = UPS && NPL > 2 && TH > 2;
+	static constexpr int NPLX = XPAIR ? 2 : NPL;       // planes of X resident at once
 	static constexpr int OFF_X = 0;
-	static constexpr int OFF_T = NPL * XPLANE;
+	static constexpr int OFF_T = NPLX * XPLANE;
 	static constexpr int TREGION = TBYTES > LBYTES ? TBYTES : LBYTES;  // the patch is dead before T is written
 	// output staging per wave: 32 couts of a row pair (or of its pooled row)
 	static constexpr int ESZ = 2;                       // (OUTK 1: f16 instead of T, same size)
 	static constexpr int RBW = 32 * ESZ;                // bytes per pixel per cout block
 	static constexpr int STAGE_PX = POOL ? 16 : 64;
 	static constexpr int STAGE_WAVE = STAGE_PX * RBW;
-	static constexpr bool STAGE_IN_X = NPL * XPLANE >= NW * STAGE_WAVE;  // X is dead once conv A is done
+	static constexpr bool STAGE_IN_X = NPLX * XPLANE >= NW * STAGE_WAVE;  // X is dead once conv A is done
 	static constexpr int OFF_STAGE = STAGE_IN_X ? OFF_X : OFF_T + TREGION;
 	static constexpr int LDS = OFF_T + TREGION + (STAGE_IN_X ? 0 : NW * STAGE_WAVE);
 	static_assert(CIN == 16 || CIN == 32 || CIN == 64 || CIN == 128 || CIN == 256, "input channels");
@@ -135,7 +142,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 	// ---- conv A weights: A fragments of this wave's cout block, straight to registers ----
 	// register sets of conv A fragments: all planes, or (RELOAD) two sets at one wave per SIMD / one set at two (its
 	// SIMD partner computes while a wave waits for its next plane)
-	constexpr int NWA = G::RELOAD ? (NW == 4 ? 2 : 1) : G::NPL;
+	// (XPAIR: one set -- the taller tile's accumulators need the registers, and the next plane's fragments, fetched behind
+	// this plane's last MFMAs, travel while the plane after is expanded)
+	constexpr int NWA = G::RELOAD ? ((NW == 4 && !G::XPAIR) ? 2 : 1) : G::NPL;
 	Vec8<T> wa[NWA][9 * G::KS1];
 	const unsigned char *waSrc = static_cast<const unsigned char *>(p.w1) +
 	                             (size_t)cb * G::NPL * (9 * G::KS1 * 1024) + lane * 16;
@@ -156,6 +165,53 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 		for (int pl = 0; pl < G::NPL; ++pl) loadPlaneA(pl, pl);
 	}
 
+	// UPS: planes [plFirst, plFirst + plCount) of the tile from the low-resolution patch (in LDS behind OFF_T) -- see the
+	// staging branch below for the arithmetic
+	[[maybe_unused]] constexpr int LPPX = G::PBX / 16;
+	[[maybe_unused]] auto expandPlanes = [&](int plFirst, int plCount) __attribute__((always_inline)) {
+		if constexpr (UPS) {
+			constexpr int LPP = LPPX;
+			constexpr int NPIX = G::LR * G::LC;
+			const unsigned char *smL = smem + G::OFF_T;
+			constexpr int BR = G::XR / 2, BC = kFbW / 2;  // 2x2 blocks of the tile
+			const int nel = plCount * BR * BC * LPP;
+			for (int e = tid; e < nel; e += NT) {
+				const int c = e % LPP;
+				const int bq = (e / LPP) % (BR * BC);
+				const int pl = plFirst + e / (LPP * BR * BC);
+				const int br = bq / BC, bc = bq - br * BC;
+				const unsigned char *base = smL + pl * (NPIX * G::PBX) + (br * G::LC + bc) * G::PBX + c * 16;
+				const Vec8<T> tl = *reinterpret_cast<const Vec8<T> *>(base);
+				const Vec8<T> tr = *reinterpret_cast<const Vec8<T> *>(base + G::PBX);
+				const Vec8<T> bl = *reinterpret_cast<const Vec8<T> *>(base + G::LC * G::PBX);
+				const Vec8<T> brr = *reinterpret_cast<const Vec8<T> *>(base + (G::LC + 1) * G::PBX);
+				Vec8<T> o01, o10, o11;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
+					const float d = static_cast<float>(bl[j]), e2 = static_cast<float>(brr[j]);
+					const float top = a + (b2 - a) * 0.5f;
+					const float bot = d + (e2 - d) * 0.5f;
+					o01[j] = static_cast<T>(top);
+					o10[j] = static_cast<T>(a + (d - a) * 0.5f);
+					o11[j] = static_cast<T>(top + (bot - top) * 0.5f);
+				}
+				const int r = 2 * br, k = 2 * bc;
+				const int gy = y0 - 2 + r, gx = x0 - 2 + k;
+				const Vec8<T> zero = {static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f),
+				    static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f)};
+				// (H, W even: a 2x2 block is inside or outside the image as a whole)
+				const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+				unsigned char *xb = smem + G::OFF_X + (G::XPAIR ? (pl & 1) : pl) * G::XPLANE + (r * kFbW + k) * G::PBX;
+				const unsigned s0 = (static_cast<unsigned>(c) ^ fbSwz<G::PBX>(k)) << 4;
+				const unsigned s1x = (static_cast<unsigned>(c) ^ fbSwz<G::PBX>(k + 1)) << 4;
+				*reinterpret_cast<Vec8<T> *>(xb + s0) = inside ? tl : zero;
+				*reinterpret_cast<Vec8<T> *>(xb + G::PBX + s1x) = inside ? o01 : zero;
+				*reinterpret_cast<Vec8<T> *>(xb + kFbW * G::PBX + s0) = inside ? o10 : zero;
+				*reinterpret_cast<Vec8<T> *>(xb + (kFbW + 1) * G::PBX + s1x) = inside ? o11 : zero;
+			}
+		}
+	};
 	// ---- stage the input tile ----
 	// X pixel (r, k) = image (y0 - 2 + r, x0 - 2 + k); pixels outside the image are the
 	// convolution's zero padding.
@@ -295,42 +351,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 		// == a exactly), so the result is bit-identical to the separate kernel.  The patch was
 		// loaded with clamped coordinates, so "right" / "below" at the tensor's edge are the
 		// edge pixel itself, which is what min(lo + 1, n - 1) selects.
-		constexpr int BR = G::XR / 2, BC = kFbW / 2;  // 2x2 blocks of the tile
-		constexpr int NEL = G::NPL * BR * BC * LPP;
-		for (int e = tid; e < NEL; e += NT) {
-			const int c = e % LPP;
-			const int bq = (e / LPP) % (BR * BC);
-			const int pl = e / (LPP * BR * BC);
-			const int br = bq / BC, bc = bq - br * BC;
-			const unsigned char *base = smL + pl * (NPIX * G::PBX) + (br * G::LC + bc) * G::PBX + c * 16;
-			const Vec8<T> tl = *reinterpret_cast<const Vec8<T> *>(base);
-			const Vec8<T> tr = *reinterpret_cast<const Vec8<T> *>(base + G::PBX);
-			const Vec8<T> bl = *reinterpret_cast<const Vec8<T> *>(base + G::LC * G::PBX);
-			const Vec8<T> brr = *reinterpret_cast<const Vec8<T> *>(base + (G::LC + 1) * G::PBX);
-			Vec8<T> o01, o10, o11;
-#pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				const float a = static_cast<float>(tl[j]), b2 = static_cast<float>(tr[j]);
-				const float d = static_cast<float>(bl[j]), e2 = static_cast<float>(brr[j]);
-				const float top = a + (b2 - a) * 0.5f;
-				const float bot = d + (e2 - d) * 0.5f;
-				o01[j] = static_cast<T>(top);
-				o10[j] = static_cast<T>(a + (d - a) * 0.5f);
-				o11[j] = static_cast<T>(top + (bot - top) * 0.5f);
-			}
-			const int r = 2 * br, k = 2 * bc;
-			const int gy = y0 - 2 + r, gx = x0 - 2 + k;
-			const Vec8<T> zero = {static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f),
-			    static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f)};
-			// (H, W even: a 2x2 block is inside or outside the image as a whole)
-			const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-			unsigned char *xb = smem + G::OFF_X + pl * G::XPLANE + (r * kFbW + k) * G::PBX;
-			const unsigned s0 = (static_cast<unsigned>(c) ^ fbSwz<G::PBX>(k)) << 4;
-			const unsigned s1x = (static_cast<unsigned>(c) ^ fbSwz<G::PBX>(k + 1)) << 4;
-			*reinterpret_cast<Vec8<T> *>(xb + s0) = inside ? tl : zero;
-			*reinterpret_cast<Vec8<T> *>(xb + G::PBX + s1x) = inside ? o01 : zero;
-			*reinterpret_cast<Vec8<T> *>(xb + kFbW * G::PBX + s0) = inside ? o10 : zero;
-			*reinterpret_cast<Vec8<T> *>(xb + (kFbW + 1) * G::PBX + s1x) = inside ? o11 : zero;
+		if constexpr (!G::XPAIR) {
+			expandPlanes(0, G::NPL);
+		} else {
+			expandPlanes(0, 1);  // (the other planes: one ahead of conv A's plane loop, below)
 		}
 		__syncthreads();  // X complete; the patch (aliasing T) is dead
 	}
@@ -410,18 +434,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void flow_block_kernel(FlowBlockPa
 				if constexpr (G::RELOAD && NWA == 2) {
 					if (pl + 1 < G::NPL) loadPlaneA((pl + 1) & 1, pl + 1);
 				}
+				if constexpr (G::XPAIR) {
+					// the next plane of the input, into the buffer the plane before this one was read from (every wave is past
+					// the barrier that ended that plane)
+					if (pl + 1 < G::NPL && !(JU_SKIP(p) & 1)) expandPlanes(pl + 1, 1);
+				}
 #pragma unroll
 				for (int s = 0; s < HOLD; ++s) {
 					const int pair = pstart + s * PSTEP;
 					if (pair < NPAIR) {
 						FbPair<T, G::KS1, G::PBX>::run(
-						    ldsBase + G::OFF_X + pl * G::XPLANE + (2 * pair) * (kFbW * G::PBX), colOffA, colSwzA, hh,
-						    wa[G::RELOAD ? (pl & (NWA - 1)) : pl], acc[s]);
+						    ldsBase + G::OFF_X + (G::XPAIR ? (pl & 1) : pl) * G::XPLANE + (2 * pair) * (kFbW * G::PBX), colOffA,
+						    colSwzA, hh, wa[G::RELOAD ? (pl & (NWA - 1)) : pl], acc[s]);
 					}
 				}
 				if constexpr (G::RELOAD && NWA == 1) {
 					if (pl + 1 < G::NPL) loadPlaneA(0, pl + 1);  // (behind the plane's last MFMAs: the set is free)
 				}
+				if constexpr (G::XPAIR) __syncthreads();  // this plane's buffer is free, the next plane's complete
 			}
 #pragma unroll
 			for (int s = 0; s < HOLD; ++s) {
@@ -641,9 +671,10 @@ void launchFlowBlockT(const FlowBlockParams &p, int items, int numCUs, hipStream
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, kFbMid, 6>(p, items, numCUs, stream);
 	} else if constexpr (CMID == 128) {
 		// (the 128-filter blocks, 68 x 120 at 480 x 270: a few thousand pixels -- short tiles, or most of the chip idles;
-		// measured for the encoder block: 2 rows 11.7 us, 4 rows 16.0, 6 rows 19.9.  One frame is a single round of
-		// 2-row tiles; a look-ahead launch of 8 frames is five such rounds or two of 6-row tiles -- the cost rule above
-		// picks.  The decoder block's four input planes leave LDS for 2 rows only.)
+		// measured for the encoder / decoder block: 2 rows 11.7 / 23.8 us, 4 rows 16.0 / 32.1, 6 rows 19.9 / 39.1.  One
+		// frame is a single round of 2-row tiles; a look-ahead launch of 8 frames is five such rounds or two of 6-row
+		// tiles -- the cost rule above picks.  The decoder block's taller tiles keep two of its four input planes in LDS
+		// at a time: FbGeom::XPAIR.)
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 6, 4, 2>(p, items, numCUs, stream);
 	} else {
 		launchFlowBlockBest<T, CIN, CMID, UPS, POOL, OUTK, PACK, 20, 18, 10, 6>(p, items, numCUs, stream);
