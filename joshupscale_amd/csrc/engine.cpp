@@ -1534,7 +1534,7 @@ int Engine::prepareFrames(const Frame &in, const Frame &out) {
 // before the first of them is upscaled: ONE pass of the flow net's eight launches over n frames instead of n passes.
 // At 480x270 each of those launches is ONE round of 136-240 workgroups on 256 CUs -- a 7-24 us latency chain (weights,
 // staging, conv A, conv B, stores) with most SIMDs idle most of the time (0.3-0.6 waves per SIMD,
-// profiles/r05_pmc_stall_flow.txt): over 8 frames the same launches take 67 instead of 105 us per frame
+// profiles/r05_pmc_stall_flow.txt): over 8 frames the same launches take 62 instead of 105 us per frame
 // (profiles/r05_flow_layers_pass.txt; priced beforehand by tools/probes/flow_batch_estimate.py), and a pass pays one
 // synchronisation instead of eight: 2163 -> 2461 frames/s (profiles/r05_lookahead_bench_box_a.txt).  The recurrent part -- warp, tower,
 // tail -- stays strictly frame by frame, and every frame's bytes are those of process(): the same kernels add the
