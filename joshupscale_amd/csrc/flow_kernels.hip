@@ -756,16 +756,18 @@ bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHea
 	if (cin == 16 && cmid == 32) return !upsample && pool && !outHead;
 	if (cin == 32 && cmid == 64) return !upsample && pool && !outHead;
 	if (cmid == 128) {
-		// Round 5.  These blocks run 2-row tiles (conv B's 72 fragments leave one wave per SIMD: no taller tile pays), so
-		// they are one launch only where those tiles are ONE round of the chip -- 480 x 270: 4 x 34 = 136 tiles at the
-		// 68 x 120 level, 15.1 -> 11.7 us (block 3) and 24.1 -> 23.3 us with three launches fewer (block 5); at 640 x 448
-		// (6 x 56 = 336 tiles, two rounds) block 3 is equal and block 5 loses 9 us to the launches of their own
-		// (profiles/r05_flow_layers_ps2.txt), which stay.  JU_FLOW_WIDE=0 keeps the launches of their own everywhere,
-		// 1 fuses the encoder block only, 3 fuses whatever the tile count: A/B runs.
+		// Round 5.  These blocks are one launch where their tiles are ONE round of the chip at some tile height they have
+		// (2, 4, 6 rows; the decoder block's taller tiles: FbGeom::XPAIR) -- 480 x 270: 4 x 34 = 136 two-row tiles at the
+		// 68 x 120 level, 15.1 -> 11.7 us (block 3) and 24.1 -> 23.3 us with three launches fewer (block 5); 640 x 448:
+		// 6 x 28 = 168 four-row tiles, 178.8 -> 169.3 us of flow net per frame (with 2-row tiles only -- 336, two rounds --
+		// block 5 lost 9 us to the launches of their own there: profiles/r05_flow_layers_ps2.txt).  Larger frames keep the
+		// launches per convolution.  JU_FLOW_WIDE=0 keeps them everywhere, 1 fuses the encoder block only, 3 fuses whatever
+		// the tile count: A/B runs.
 		const char *wideEnv = std::getenv("JU_FLOW_WIDE");  // (read per call: only engine construction asks, and the tests switch it)
 		const int wide = wideEnv ? std::atoi(wideEnv) : 2;
+		const int rows = (cin == 256 && !upsample) ? 2 : 6;  // the tallest tile of the shape
 		const bool oneRound = H <= 0 || W <= 0 || wide >= 3 ||
-		                      static_cast<long>((W + kFbOutW - 1) / kFbOutW) * ((H + 1) / 2) <= currentDeviceCUs();
+		                      static_cast<long>((W + kFbOutW - 1) / kFbOutW) * ((H + rows - 1) / rows) <= currentDeviceCUs();
 		if (cin == 64) return wide >= 1 && oneRound && !upsample && pool && !outHead;
 		if (cin == 256) return wide >= 2 && oneRound && !pool && !outHead;
 		return false;

@@ -68,8 +68,8 @@ def test_look_ahead_passes_give_the_frame_by_frame_bytes(preset, dtype):
                 assert np.array_equal(got[i], want[t + i]), (preset, "pass of", k, "frame", t + i)
             t += k
         assert np.array_equal(rt.read_tensor("state"), want_state)
-        # (640x448: the 128-filter flow blocks are launches per convolution there -- split-K, the generic kernel and the
-        # upsampling launch all have an item dimension)
+        # (split-K, the generic kernel and the upsampling launch -- the 128-filter blocks of frames larger than 640x448 --
+        # all have an item dimension too: test_models_without_... covers what has none)
         assert rt.stat("lookahead_frames") == n - 2, "the passes did not take the look-ahead path"
         assert rt.stat("fallbacks") == 0
 
