@@ -109,7 +109,7 @@ JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image
  * simply starts a new pass).
  * The flow net reads LR frames only, never the HR state, so for JU_LOC_DEVICE frames the runtime computes the flow
  * fields of up to 8 frames in ONE pass of the flow net's launches, which fill the chip where one frame's do not
- * (-30 % flow time per frame at 480x270); warp, tower and tail stay strictly frame by frame.  Frames the pass
+ * (-40 % flow time per frame at 480x270); warp, tower and tail stay strictly frame by frame.  Frames the pass
  * cannot take (host frames, GL resources, a model without the one-launch flow plan) simply run as ju_process
  * does.  For callers that can read ahead: a file transcoder, an AviSynth filter fetching child frames n .. n+3.
  * JU_LOOKAHEAD=<1..8> caps the frames per pass (1 = off). */
