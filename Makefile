@@ -9,14 +9,15 @@ OBJ        := build/obj
 CXXFLAGS   := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wall -Wextra \
               -Wno-unused-parameter
 HIPFLAGS   := --offload-arch=$(ARCH) $(CXXFLAGS)
-SRCS_CPP   := model.cpp engine.cpp c_api.cpp core_api.cpp log.cpp comm.cpp graphics.cpp
+SRCS_CPP   := model.cpp engine.cpp c_api.cpp core_api.cpp log.cpp comm.cpp graphics.cpp dev_switch.cpp
 SRCS_HIP   := conv_kernels.hip tower_kernels.hip frame_kernels.hip fp8_kernels.hip flow_kernels.hip res_block_kernels.hip splitk_kernels.hip tower8_kernels.hip
 OBJS       := $(addprefix $(OBJ)/,$(SRCS_CPP:.cpp=.o)) $(addprefix $(OBJ)/,$(SRCS_HIP:.hip=.o))
 
 # Two libraries from the same objects: the product (exactly the C ABI of include/joshupscale_amd.h + the C++ plugin
-# surface of include/JoshUpscale/core.h) and its test flavour, in which c_api.cpp and graphics.cpp are compiled with
-# -DJU_TEST_HOOKS and additionally export include/joshupscale_amd_test.h (ju_debug_*, ju_read_tensor, ju_time_steps).
-HOOK_CPP   := c_api.cpp graphics.cpp
+# surface of include/JoshUpscale/core.h) and its test flavour, in which c_api.cpp, graphics.cpp and dev_switch.cpp are
+# compiled with -DJU_TEST_HOOKS: it additionally exports include/joshupscale_amd_test.h (ju_debug_*, ju_read_tensor,
+# ju_time_steps) and reads the developer switches of csrc/dev_switch.h from the environment -- the product reads none of them.
+HOOK_CPP   := c_api.cpp graphics.cpp dev_switch.cpp
 OBJS_TEST  := $(filter-out $(addprefix $(OBJ)/,$(HOOK_CPP:.cpp=.o)),$(OBJS)) $(addprefix $(OBJ)/,$(HOOK_CPP:.cpp=_hooks.o))
 
 all: $(OUT)/libJoshUpscale.so $(OUT)/libJoshUpscale_test.so

@@ -112,8 +112,13 @@ JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image
  * (-40 % flow time per frame at 480x270); warp, tower and tail stay strictly frame by frame.  Frames the pass
  * cannot take (host frames, GL resources, a model without the one-launch flow plan) simply run as ju_process
  * does.  For callers that can read ahead: a file transcoder, an AviSynth filter fetching child frames n .. n+3.
- * JU_LOOKAHEAD=<1..8> caps the frames per pass (1 = off). */
+ * ju_set_lookahead caps the frames per pass (1 = off); its default is 8, or JU_LOOKAHEAD=<1..8> at creation. */
 JU_API int ju_process_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image *outputs, int count);
+/* Frames per look-ahead pass of ju_process_batch for THIS runtime, 1 (every frame as ju_process does) .. 8; values
+ * outside are clamped.  Passes registered with ju_prepare_batch that are longer than the new cap are forgotten.  The
+ * setter is what a host application uses; the JU_LOOKAHEAD environment variable only sets the default of runtimes
+ * created afterwards (one process, several filters: each sets its own). */
+JU_API int ju_set_lookahead(ju_runtime *runtime, int frames);
 /* What ju_prepare_frames is to ju_process: registers a tuple of 2 .. JU_LOOKAHEAD JU_LOC_DEVICE frame buffers the
  * caller is going to hand to ju_process_batch as one pass; its hipGraphs (one per binding set) are captured now,
  * nothing executes.  Unregistered tuples are captured at their second use.  *captured (optional) = graphs captured

@@ -168,6 +168,10 @@ int ju_prepare_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image
 	});
 }
 
+int ju_set_lookahead(ju_runtime *runtime, int frames) {
+	return guarded([&] { engineOf(runtime).setLookahead(frames); });
+}
+
 int ju_enqueue(ju_runtime *runtime, const ju_image *input, const ju_image *output) {
 	return guarded([&] {
 		const ju::Frame in = toFrame(input), out = toFrame(output);

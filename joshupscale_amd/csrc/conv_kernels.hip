@@ -552,7 +552,7 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 	// single-stage kernel: two co-resident workgroups hide each other's latency and
 	// the doubled LDS would cost a second round of workgroups.  (JU_CONV_DBUF=0/1
 	// forces it off/on for A/B timing.)
-	static const char *dbufEnv = std::getenv("JU_CONV_DBUF");
+	static const char *dbufEnv = devSwitch(Dev::ConvDbuf);
 	const int cus = currentDeviceCUs();
 	const long wgs = (long)((p.W + kTW - 1) / kTW) * ((p.H + 4 * p.rw - 1) / (4 * p.rw)) *
 	                 (p.cout / (32 * p.nb));

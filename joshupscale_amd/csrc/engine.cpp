@@ -10,6 +10,7 @@
 #include <sstream>
 #include <stdexcept>
 
+#include "dev_switch.h"
 #include "fp8.h"
 #include "graphics.h"
 #include "log.h"
@@ -924,7 +925,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	const int H = c.frameHeight, W = c.frameWidth;
 	const int PH = c.paddedHeight(), PW = c.paddedWidth();
 
-	const char *tailMode = std::getenv("JU_TAIL");
+	const char *tailMode = devSwitch(Dev::Tail);
 	m_FusedTail = !(tailMode && std::string(tailMode) == "split");
 	// The fused tail runs INSIDE the resident tower launch wherever that kernel is used with a
 	// ReLU generator (its last layer is in LDS: the trunk is never written or re-read, one launch
@@ -933,13 +934,13 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	// psp-fast (tools/submit_overhead.py, three A/B rounds), so it is the default now.
 	// JU_TAIL=fused: the separate tail_fused_kernel launch; JU_TAIL=split: the two-kernel tail.
 	m_TailInTower = !(tailMode && (std::string(tailMode) == "fused" || std::string(tailMode) == "split"));
-	const char *packMode = std::getenv("JU_PACK");
+	const char *packMode = devSwitch(Dev::Pack);
 	m_PackInBlock = !(packMode && std::string(packMode) == "split");  // JU_PACK=split: pack_frames_kernel as its own launch
-	const char *poolMode = std::getenv("JU_POOL");
+	const char *poolMode = devSwitch(Dev::Pool);
 	m_FusedPool = !(poolMode && std::string(poolMode) == "split");
-	const char *upMode = std::getenv("JU_UPSAMPLE");
+	const char *upMode = devSwitch(Dev::Upsample);
 	m_FusedUpsample = !(upMode && std::string(upMode) == "split");
-	const char *flowConv = std::getenv("JU_FLOW_CONV");
+	const char *flowConv = devSwitch(Dev::FlowConv);
 	m_FlowFused = !(flowConv && std::string(flowConv) == "generic") && m_FusedUpsample;
 	planFlowUnits();
 
@@ -947,15 +948,15 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 
 	// ---- resident tower: needs 64 filters and one co-resident workgroup per region ----
 	{
-		const char *mode = std::getenv("JU_TOWER");
+		const char *mode = devSwitch(Dev::Tower);
 		int cus = 0;
 		JU_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
 		bool wanted = !(mode && (std::string(mode) == "layers" || std::string(mode) == "convs"));
 		m_BlockFused = !(mode && std::string(mode) == "convs");
-		const char *calib = std::getenv("JU_CALIBRATE");
+		const char *calib = devSwitch(Dev::Calibrate);
 		m_Calibrate = calib && calib[0] == '1';
 		if (m_Calibrate) {
-			if (m_Fp8Tower) throw std::invalid_argument("JU_CALIBRATE: calibrate the fp16 / bf16 engine, not the 8-bit one");
+			if (m_Fp8Tower) throw std::invalid_argument("calibration mode: calibrate the fp16 / bf16 engine, not the 8-bit one");
 			wanted = false;
 			m_BlockFused = false;
 		}
@@ -975,7 +976,7 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		}
 		m_TowerHostW.clear();
 		m_TowerHostW.shrink_to_fit();
-		const char *flowMode = std::getenv("JU_FLOW");
+		const char *flowMode = devSwitch(Dev::Flow);
 		if (flowMode && std::string(flowMode) == "convs") m_BlockFused = false;
 		if (m_Resident && !(flowMode && (std::string(flowMode) == "layers" || std::string(flowMode) == "convs")) &&
 		    c.flowArch == 1 &&
@@ -1081,14 +1082,14 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 	m_IO.inStride = static_cast<std::ptrdiff_t>(W) * 4;
 	m_IO.out = m_OutStage.as<std::uint8_t>();
 	m_IO.outStride = static_cast<std::ptrdiff_t>(W) * 16;
-	const char *direct = std::getenv("JU_DIRECT");
+	const char *direct = devSwitch(Dev::Direct);
 	m_PreferDirect = !(direct && direct[0] == '0');
 	const char *noGraph = std::getenv("JU_NO_GRAPH");
 	const bool useGraph = !(noGraph && noGraph[0] == '1');
 	if (const char *retry = std::getenv("JU_RESIDENT_RETRY")) m_RetryBase = static_cast<unsigned>(std::atoi(retry));
-	const char *directGraph = std::getenv("JU_DIRECT_GRAPH");
+	const char *directGraph = devSwitch(Dev::DirectGraph);
 	m_DirectGraph = !(directGraph && directGraph[0] == '0');
-	if (const char *spin = std::getenv("JU_SYNC_SPIN_US")) m_SpinUs = static_cast<unsigned>(std::atoi(spin));
+	if (const char *spin = devSwitch(Dev::SyncSpinUs)) m_SpinUs = static_cast<unsigned>(std::atoi(spin));
 	// frames per look-ahead pass of processBatch (1 = frame by frame)
 	if (const char *la = std::getenv("JU_LOOKAHEAD")) m_BatchMax = std::min(std::max(std::atoi(la), 1), kFlowBatchMax);
 
@@ -1108,8 +1109,8 @@ Engine::Engine(int device, const void *blob, std::size_t size, int dtypeOverride
 		// JU_TRACE_STEPS=<file> (developer switch): every launch of this eager pass is appended to the file BEFORE it
 		// runs and waited for after -- the last line names the kernel behind a GPU memory fault, which the runtime
 		// otherwise reports asynchronously and without a name
-		const char *trace = std::getenv("JU_TRACE_STEPS");
-		const bool traceSync = !std::getenv("JU_TRACE_NOSYNC");  // (JU_TRACE_NOSYNC=1: the list only)
+		const char *trace = devSwitch(Dev::TraceSteps);
+		const bool traceSync = !devSwitch(Dev::TraceNoSync);  // (JU_TRACE_NOSYNC=1: the list only)
 		for (int s = 0; s < 2; ++s) {
 			int k = 0;
 			for (const Step &st : m_Program[s]) {
@@ -1590,6 +1591,19 @@ bool Engine::batchPlanned(int items) {
 		m_BatchCap = 0;
 		return false;
 	}
+}
+
+void Engine::setLookahead(int frames) {
+	DeviceGuard g(m_Device);
+	const int cap = std::min(std::max(frames, 1), kFlowBatchMax);
+	if (cap < m_BatchMax) {
+		// graphs of longer passes can no longer be asked for: drop them (their launches may still be in flight)
+		m_Stream.synchronize();
+		for (auto it = m_BatchGraphs.begin(); it != m_BatchGraphs.end();) {
+			it = static_cast<int>(it->first.size()) > cap ? m_BatchGraphs.erase(it) : std::next(it);
+		}
+	}
+	m_BatchMax = cap;
 }
 
 void Engine::dropBatchGraphs() {

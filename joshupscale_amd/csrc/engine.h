@@ -64,6 +64,8 @@ public:
 	// (2 .. JU_LOOKAHEAD frames): its graphs, one per binding set, are captured now -- what prepareFrames is to
 	// process.  Nothing executes.  Returns the graphs captured (0: the tuple will not go as one pass).
 	int prepareBatch(const Frame *in, const Frame *out, int count);
+	// Frames per look-ahead pass, 1 (off) .. kFlowBatchMax, clamped.  Default: kFlowBatchMax, or JU_LOOKAHEAD at creation.
+	void setLookahead(int frames);
 	// Asynchronous variant for device-resident frames: enqueue only.
 	void enqueue(const Frame &in, const Frame &out);
 	void synchronize();

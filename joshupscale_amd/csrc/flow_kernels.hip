@@ -632,7 +632,7 @@ inline long fbLaunchCost(int H, long tilesX, int TH, int numCUs, int items = 1) 
 }
 
 inline int fbForcedTile() {
-	static const int forced = [] { const char *e = std::getenv("JU_FLOW_TILE"); return e ? std::atoi(e) : 0; }();
+	static const int forced = [] { const char *e = devSwitch(Dev::FlowTile); return e ? std::atoi(e) : 0; }();
 	return forced;
 }
 
@@ -763,7 +763,7 @@ bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHea
 		// block 5 lost 9 us to the launches of their own there: profiles/r05_flow_layers_ps2.txt).  Larger frames keep the
 		// launches per convolution.  JU_FLOW_WIDE=0 keeps them everywhere, 1 fuses the encoder block only, 3 fuses whatever
 		// the tile count: A/B runs.
-		const char *wideEnv = std::getenv("JU_FLOW_WIDE");  // (read per call: only engine construction asks, and the tests switch it)
+		const char *wideEnv = devSwitch(Dev::FlowWide);  // (read per call: only engine construction asks, and the tests switch it)
 		const int wide = wideEnv ? std::atoi(wideEnv) : 2;
 		const int rows = (cin == 256 && !upsample) ? 2 : 6;  // the tallest tile of the shape
 		const bool oneRound = H <= 0 || W <= 0 || wide >= 3 ||
@@ -779,7 +779,7 @@ bool flowBlockSupported(int cin, int cmid, bool upsample, bool pool, bool outHea
 
 void launchFlowBlock(DType dt, const FlowBlockLaunch &q, hipStream_t stream) {
 	if (q.residual && q.cin == 64 && q.cmid == 64 && !q.upsample && !q.pool) {
-		static const char *mode = std::getenv("JU_RES_BLOCK");  // "tile": the non-persistent flow_block_kernel form (A/B)
+		static const char *mode = devSwitch(Dev::ResBlock);  // "tile": the non-persistent flow_block_kernel form (A/B)
 		if (!(mode && std::string(mode) == "tile")) {
 			launchResBlockPersistent(dt, q, stream);  // res_block_kernels.hip
 			return;

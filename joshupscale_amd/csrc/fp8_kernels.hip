@@ -832,7 +832,7 @@ void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
 	// round (surplus workgroups exit), down otherwise
 	if (grid > 8) grid = k.numTiles <= 2 * cus ? (grid + 7) / 8 * 8 : grid - grid % 8;
 	// JU_FP8_GRID=n (tests): any grid computes the same bytes, a race would not
-	if (const char *g = std::getenv("JU_FP8_GRID")) grid = std::atoi(g) > 0 ? std::atoi(g) : grid;
+	if (const char *g = devSwitch(Dev::Fp8Grid)) grid = std::atoi(g) > 0 ? std::atoi(g) : grid;
 	if (q.leaky) {  // `activation: lrelu` models: own instantiations, the ReLU kernels are unchanged
 		if (q.stream != nullptr) {
 			if (dt == kF16) launchFp8T<f16, true, true>(k, grid, stream);
@@ -854,7 +854,7 @@ void launchConvTowerFp8(DType dt, const Fp8TowerParams &q, hipStream_t stream) {
 
 // 0: by geometry; 1: one 8-wave workgroup per CU; 2: two 4-wave workgroups per CU (JU_FP8_BLOCK=solo / duo, tests)
 static std::atomic<int> g_Fp8BlockForm{[] {
-	const char *e = std::getenv("JU_FP8_BLOCK");
+	const char *e = devSwitch(Dev::Fp8Block);
 	return e == nullptr ? 0 : (std::string(e) == "duo" ? 2 : (std::string(e) == "solo" ? 1 : 0));
 }()};
 void setFp8BlockForm(int form) { g_Fp8BlockForm = form; }

@@ -11,6 +11,7 @@
 #include <string>
 #include <type_traits>
 
+#include "dev_switch.h"
 #include "kernels.h"
 
 namespace ju {
@@ -134,7 +135,7 @@ inline int ablationSkipBits() { return 0; }
 // res_block_fp8_kernel: the instruction is a scheduling barrier for hipcc and the kernel ran 2x slower.)
 inline int wavePriorityMode(int fallback) {
 	static const int mode = [] {
-		const char *e = std::getenv("JU_WAVE_PRIO");
+		const char *e = devSwitch(Dev::WavePrio);
 		return e ? std::atoi(e) : -1;
 	}();
 	return mode >= 0 ? mode : fallback;

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256, 1) void res_block_pipe_kernel(ResBlockParams p
 }
 
 // JU_RES_BLOCK=plain (or the tests' switch): res_block_kernel for every block
-static std::atomic<int> g_ResBlockPlain{[] { const char *e = std::getenv("JU_RES_BLOCK"); return (e != nullptr && std::string(e) == "plain") ? 1 : 0; }()};
+static std::atomic<int> g_ResBlockPlain{[] { const char *e = devSwitch(Dev::ResBlock); return (e != nullptr && std::string(e) == "plain") ? 1 : 0; }()};
 }  // namespace
 void setResBlockPlain(int on) { g_ResBlockPlain = on ? 1 : 0; }
 bool resBlockPlain() { return g_ResBlockPlain.load() != 0; }

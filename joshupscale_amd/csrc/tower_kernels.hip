@@ -1637,7 +1637,7 @@ bool residentTowerM16() { return JU_TOWER_M16 != 0; }
 void setTowerVariant(int v) { g_TowerVariant = v; }
 // the fast schedule where the geometry allows it (default); 0 (JU_TOWER_FAST=0 or the tests' switch): the
 // general schedule everywhere
-static std::atomic<int> g_TowerFast{[] { const char *e = std::getenv("JU_TOWER_FAST"); return (e != nullptr && e[0] == '0') ? 0 : 1; }()};
+static std::atomic<int> g_TowerFast{[] { const char *e = devSwitch(Dev::TowerFast); return (e != nullptr && e[0] == '0') ? 0 : 1; }()};
 void setResidentTowerFast(int on) { g_TowerFast = on ? 1 : 0; }
 bool residentTowerFast() { return g_TowerFast.load() != 0; }
 int towerVariant() { return g_TowerVariant; }

@@ -80,6 +80,7 @@ _PRODUCT_SIGS = {
     "ju_process": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage)]),
     "ju_process_batch": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), C.c_int]),
     "ju_prepare_batch": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), C.c_int, _P(C.c_int)]),
+    "ju_set_lookahead": (C.c_int, [C.c_void_p, C.c_int]),
     "ju_enqueue": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage)]),
     "ju_synchronize": (C.c_int, [C.c_void_p]),
     "ju_prepare_frames": (C.c_int, [C.c_void_p, _P(JuImage), _P(JuImage), _P(C.c_int)]),
@@ -238,6 +239,10 @@ class Runtime:
         got = C.c_int()
         _check(self._lib, self._lib.ju_prepare_batch(self._h, ins, outs, n, C.byref(got)))
         return got.value
+
+    def set_lookahead(self, frames: int) -> None:
+        """``ju_set_lookahead``: frames per look-ahead pass of ``process_batch`` (1 = frame by frame, at most 8)."""
+        _check(self._lib, self._lib.ju_set_lookahead(self._h, int(frames)))
 
     def enqueue(self, inp: JuImage, out: JuImage) -> None:
         _check(self._lib, self._lib.ju_enqueue(self._h, C.byref(inp), C.byref(out)))

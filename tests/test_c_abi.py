@@ -62,6 +62,29 @@ def test_product_library_exports_exactly_the_declared_surface(product_library):
     assert sorted(n for n in tnames if n.startswith("ju_")) == sorted(declared_functions() + hooks)
 
 
+def test_product_library_reads_only_the_documented_environment(product_library):
+    """Every developer switch (A/B paths, cross-check kernels, traces) goes through csrc/dev_switch.h and exists in the
+    test flavour only: the product library holds the NAMES of exactly the variables INTEGRATION.md documents for it."""
+    import subprocess
+
+    def ju_strings(path):
+        out = subprocess.check_output(["strings", "-n", "4", path]).decode(errors="replace")
+        return sorted({m.group(0) for line in out.splitlines() for m in [re.match(r"JU_[A-Z0-9_]+", line)] if m})
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = text[text.index("### The product library (`libJoshUpscale.so`)"):text.index("### The test flavour")]
+    documented = sorted(set(re.findall(r"^\| `(JU_[A-Z0-9_]+)", section, flags=re.M)))
+    assert documented == ["JU_LOOKAHEAD", "JU_NO_GRAPH", "JU_RESIDENT_RETRY", "JU_VERBOSE"]
+    assert ju_strings(R.library_path(False)) == documented
+    # the test flavour does carry the developer switches (the same objects + dev_switch.cpp under -DJU_TEST_HOOKS)
+    dev = ju_strings(R.library_path(True))
+    assert set(documented) < set(dev) and {"JU_TOWER", "JU_FLOW_CONV", "JU_TAIL", "JU_FP8_GRID"} <= set(dev)
+    # ... and every one of them is documented in the second table
+    tail = text[text.index("### The test flavour"):]
+    listed = set(re.findall(r"`(JU_[A-Z0-9_]+)", tail))
+    assert set(dev) - set(documented) <= listed, set(dev) - set(documented) - listed
+
+
 def subprocess_nm_strong(path):
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
