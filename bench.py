@@ -8,6 +8,17 @@ synchronise.  Frames are synthetic random BGRX and already resident in HBM when
 the timed region starts (JU_LOC_DEVICE images); weights are seeded random-init of
 the reference's default architecture ("PSP quality", see BASELINE.json).
 
+`value` is ALWAYS taken through that one-frame-per-call boundary unless `--lookahead N`
+or `--location host` is given explicitly (A/B work; the line then says so).  The same
+line carries, each timed with the same barrier / synchronise / max-over-ranks method in a
+region of its own after the contract's timed region:
+  frame_by_frame_value   ju_process over >= 200 frames whatever --steps was
+  lookahead_value        ju_process_batch, passes of 8 device frames (an extension of the
+                         boundary for callers that can read ahead; one output buffer per frame)
+  host_frames_value      ju_process on host frames (PCIe-inclusive; the reference's own timing
+                         loop, scripts/inference/tensorrt/inference.py:245-251)
+  host_frames_lookahead_value   ju_process_batch, passes of 8 host frames
+
 N GPUs = N independent streams, one process per GPU, one RCCL broadcast of the
 model container at start-up, no per-frame communication ("replicas only").
 
@@ -184,9 +195,11 @@ def main() -> int:
     ap.add_argument("--preroll", type=int, default=PREROLL_FRAMES,
                     help="untimed clock-warm frames in front of --warmup (fixed; not part of the contract's W)")
     ap.add_argument("--lookahead", type=int, default=None,
-                    help="frames per ju_process_batch pass (1 = ju_process frame by frame).  Default: 8 for device "
-                         "frames -- the frames are resident in HBM, so the boundary call can read ahead -- and 1 for "
-                         "psp-fast (BASELINE config 3 is the latency configuration) and for host frames")
+                    help="A/B only: time `value` through ju_process_batch passes of N frames (2..8) instead of the "
+                         "reference's one-frame boundary; the line's config.boundary then says so.  Default: `value` is "
+                         "ju_process frame by frame, and the look-ahead figure is reported beside it as lookahead_value")
+    ap.add_argument("--extra-frames", type=int, default=256,
+                    help="frames per secondary region (frame_by_frame_value, lookahead_value, host_frames_*); 0 = none")
     ap.add_argument("--no-prepare", action="store_true",
                     help="do not register the frame buffers (ju_prepare_frames): graphs are then captured "
                          "inside ju_process at a pair's second use, and a timed region that contains such a "
@@ -218,106 +231,128 @@ def main() -> int:
     # The frames are timed through the PRODUCT library (libJoshUpscale.so: no test hooks); the per-kernel times of
     # the roofline come afterwards from a second runtime of its test flavour (libJoshUpscale_test.so: the same
     # objects + ju_time_steps).  JU_LIBRARY (A/B of developer builds) replaces both.
-    look = args.lookahead
-    if look is None:
-        look = 1 if (args.preset == "psp-fast" or args.location != "device") else 8
-    look = max(1, min(look, 8))
-    os.environ["JU_LOOKAHEAD"] = str(look)  # (the runtimes' cap on frames per pass = what this run hands over per call)
+    look = 1 if args.lookahead is None else max(1, min(args.lookahead, 8))
     rt = R.Runtime(blob, device=local_rank, dtype=dt, hooks=False)
+    rt.set_lookahead(8)  # (the runtime's cap; what a pass really holds is what each call hands over)
 
     h, w = cfg.frame_height, cfg.frame_width
-    clip = M.synthetic_frames(16, h, w, seed=1234 + rank, kind="noise")
-    out_host = np.empty((4 * h, 4 * w, 4), np.uint8)
-    if args.location == "device":
-        d_in = torch.from_numpy(clip).to(device)
-        d_out = torch.empty((4 * h, 4 * w, 4), dtype=torch.uint8, device=device)
-        ins = [rt.device_image(d_in[i].data_ptr(), w, h) for i in range(len(clip))]
-        outs = [rt.device_image(d_out.data_ptr(), 4 * w, 4 * h)] * len(clip)
-    else:
-        ins = [R.host_image(clip[i]) for i in range(len(clip))]
-        outs = [R.host_image(out_host)] * len(clip)
+    RING = 16
+    clip = M.synthetic_frames(RING, h, w, seed=1234 + rank, kind="noise")
+    # ONE OUTPUT BUFFER PER FRAME of the ring, on both sides: a caller that reads ahead keeps every frame of a pass
+    d_in = torch.from_numpy(clip).to(device)
+    d_out = torch.empty((RING, 4 * h, 4 * w, 4), dtype=torch.uint8, device=device)
+    dev_ins = [rt.device_image(d_in[i].data_ptr(), w, h) for i in range(RING)]
+    dev_outs = [rt.device_image(d_out[i].data_ptr(), 4 * w, 4 * h) for i in range(RING)]
+    out_host = np.empty((8, 4 * h, 4 * w, 4), np.uint8)
+    host_ins = [R.host_image(clip[i]) for i in range(RING)]
+    host_outs = [R.host_image(out_host[i % 8]) for i in range(RING)]
     torch.cuda.synchronize()
-    # Set-up: register every frame-buffer pair the loop will use, so that their hipGraphs are
-    # captured HERE (the reference captures its graphs in the constructor,
-    # tensorrt_backend.cc:257-263) and the timed region only replays.
-    def passes(count: int):
-        """The boundary calls of a phase of `count` frames: (first ring position, frames) per call -- passes of `look`
-        frames from the phase's start, a shorter one at its end."""
+
+    def passes(count: int, per_call: int):
+        """The boundary calls of a phase of `count` frames: (first ring position, frames) per call -- passes of
+        `per_call` frames from the phase's start, a shorter one at its end."""
         i = 0
         while i < count:
-            n = min(look, count - i)
-            yield i % len(ins), n
+            n = min(per_call, count - i)
+            yield i % RING, n
             i += n
 
-    def register(runtime, counts) -> int:
-        """Set-up: every frame-buffer pair and every pass tuple the phases will use, so that their hipGraphs are
-        captured HERE and the timed region only replays."""
+    def register(runtime, counts, per_call: int, host_too: bool = False) -> int:
+        """Set-up: every device frame-buffer pair and every pass tuple the phases will use, so that their hipGraphs are
+        captured HERE (the reference captures its graphs in the constructor, tensorrt_backend.cc:257-263) and the
+        timed regions only replay."""
         got = 0
-        for i in range(len(ins)):
-            got += runtime.prepare_frames(ins[i], outs[i])
+        for i in range(RING):
+            got += runtime.prepare_frames(dev_ins[i], dev_outs[i])
         seen = set()
         for count in counts:
-            for pos, n in passes(count):
+            for pos, n in passes(count, per_call):
                 if n > 1 and (pos, n) not in seen:
                     seen.add((pos, n))
-                    got += runtime.prepare_batch([ins[(pos + k) % len(ins)] for k in range(n)],
-                                                 [outs[(pos + k) % len(outs)] for k in range(n)])
+                    got += runtime.prepare_batch([dev_ins[(pos + k) % RING] for k in range(n)],
+                                                 [dev_outs[(pos + k) % RING] for k in range(n)])
+                    if host_too:  # (host frames ride in the pass's own device buffers: one graph per pass length and set)
+                        got += runtime.prepare_batch(host_ins[:n], host_outs[:n])
         return got
 
-    def run_phase(runtime, count: int) -> None:
-        for pos, n in passes(count):
+    def run_phase(runtime, count: int, per_call: int, host: bool = False, lat=None) -> None:
+        ins, outs = (host_ins, host_outs) if host else (dev_ins, dev_outs)
+        for pos, n in passes(count, per_call):
+            t1 = time.perf_counter() if lat is not None else 0.0
             if n == 1:
-                runtime.process(ins[pos], outs[pos % len(outs)])
+                runtime.process(ins[pos], outs[pos])
             else:
-                runtime.process_batch([ins[(pos + k) % len(ins)] for k in range(n)],
-                                      [outs[(pos + k) % len(outs)] for k in range(n)])
-
-    phases = (args.preroll, args.warmup, args.steps)
-    prepared = 0
-    if not args.no_prepare:
-        prepared = register(rt, phases)
-
-    def step(i: int) -> None:
-        rt.process(ins[i % len(ins)], outs[i % len(outs)])
+                runtime.process_batch([ins[(pos + k) % RING] for k in range(n)], [outs[(pos + k) % RING] for k in range(n)])
+            if lat is not None:
+                lat.append((time.perf_counter() - t1) * 1e3)
 
     def counters() -> dict:
         return {"replays": rt.stat("graph_replays"), "eager": rt.stat("eager_runs"),
                 "captures": rt.stat("graph_captures")}
 
+    def timed(count: int, per_call: int, host: bool = False, lat=None):
+        """One timed region, the contract's method: barrier + synchronise on both sides, the slowest rank's time.
+        Returns (max-over-ranks seconds, this rank's seconds, what the region consisted of)."""
+        jdist.barrier()
+        torch.cuda.synchronize()
+        c0, la0 = counters(), rt.stat("lookahead_frames")
+        t0 = time.perf_counter()
+        run_phase(rt, count, per_call, host, lat)
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0
+        jdist.barrier()
+        elapsed = time.perf_counter() - t0
+        c1 = counters()
+        region = {k: int(c1[k] - c0[k]) for k in c0}
+        region["lookahead_frames"] = int(rt.stat("lookahead_frames") - la0)
+        return jdist.max_over_ranks(elapsed, device), own, region
+
+    host_main = args.location == "host"
+    extra = max(0, args.extra_frames)
+    phases = (args.preroll, args.warmup, args.steps)
+    prepared = 0
+    if not args.no_prepare:
+        prepared = register(rt, phases, look)
+        if extra:
+            prepared += register(rt, (extra,), 8, host_too=True)
+
     with SclkSampler(local_rank) as sclk:
-        run_phase(rt, args.preroll)  # clock-warm, fixed, outside the contract's warm-up
-    run_phase(rt, args.warmup)
-    jdist.barrier()
-    torch.cuda.synchronize()
-    c0 = counters()
-    la0 = rt.stat("lookahead_frames")
-    t0 = time.perf_counter()
-    run_phase(rt, args.steps)
-    torch.cuda.synchronize()
-    own_elapsed = time.perf_counter() - t0
-    jdist.barrier()
-    elapsed = time.perf_counter() - t0
-    c1 = counters()
-    timed_region = {k: int(c1[k] - c0[k]) for k in c0}
-    timed_region["lookahead_frames"] = int(rt.stat("lookahead_frames") - la0)
-    elapsed = jdist.max_over_ranks(elapsed, device)
+        run_phase(rt, args.preroll, look, host_main)  # clock-warm, fixed, outside the contract's warm-up
+    run_phase(rt, args.warmup, look, host_main)
+    # ---- the contract's timed region: EXACTLY --steps frames through the boundary -----------------------------------
+    main_lat = [] if look == 1 else None
+    elapsed, own_elapsed, timed_region = timed(args.steps, look, host_main, main_lat)
     rank_fps = jdist.gather_floats(args.steps / own_elapsed, device)
 
-    # per-frame latency of the synchronous boundary call (outside the timed region):
-    # what a caller blocked in processImage sees; SURVEY 8d config 3 asks for p50/p99
-    lat = []
-    per_frame_fps = None
-    if rank == 0:
-        for i in range(min(args.steps, 200)):
-            t1 = time.perf_counter()
-            step(i)
-            lat.append((time.perf_counter() - t1) * 1e3)
-        per_frame_fps = len(lat) / (sum(lat) * 1e-3)  # (the frame-by-frame boundary call, same runtime, same box)
+    # ---- secondary regions (same runtime, same box, same method; each after a short warm-up of its own kind) --------
+    def secondary(per_call: int, host: bool):
+        if not extra:
+            return None
+        run_phase(rt, 2 * 8 * 2, per_call, host)   # (32 frames: host passes capture their graph at a tuple's second use)
+        lat = []
+        t, _, region = timed(extra, per_call, host, lat)
         lat.sort()
+        return {"value": world * extra / t, "frames": extra, "frames_per_call": per_call, "timed_region": region,
+                "call_latency_ms": {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
+                                    "max": lat[-1], "calls": len(lat)}}
+
+    fbf = secondary(1, False)
+    la_dev = secondary(8, False)
+    host_fbf = secondary(1, True)
+    host_la = secondary(8, True)
+    # the synchronous call's latency: the frame-by-frame region's own per-call timers (the boundary `value` is taken through)
+    if fbf is not None:
+        latency = dict(fbf["call_latency_ms"], boundary="ju_process", frames=fbf["frames"])
+    elif main_lat:
+        ml = sorted(main_lat)
+        latency = {"p50": ml[len(ml) // 2], "p99": ml[min(len(ml) - 1, int(len(ml) * 0.99))], "max": ml[-1],
+                   "calls": len(ml), "boundary": "ju_process", "frames": len(ml)}
+    else:
+        latency = None
 
     result = None
     # a timed region that is not pure steady state is not a measurement of it: refuse
-    graphs_on = os.environ.get("JU_NO_GRAPH", "0") != "1" and os.environ.get("JU_DIRECT_GRAPH", "1") != "0"
+    graphs_on = os.environ.get("JU_NO_GRAPH", "0") != "1"
     # (a resident-tower fallback -- CUs held by another process -- re-captures its graphs: that run is
     # reported as it went, with config.tower saying "per-layer launches", not refused)
     fell_back = rt.stat("fallbacks") > 0
@@ -350,10 +385,11 @@ def main() -> int:
         # on live recurrent data.  (Measured, round 5: a pre-roll of ju_time_steps frames instead -- a constant, zero
         # input frame, the state decays -- read 325 us in-frame for a kernel that takes ~350 in the timed frames: MFMAs
         # on degenerate data draw less power and the chip clocks higher, tools/probes/two_runtimes2.py.)
-        if args.location == "device" and not args.no_prepare:
-            register(rt, phases)
+        rt.set_lookahead(8)
+        if not args.no_prepare:
+            register(rt, phases, look)
         for count in phases:
-            run_phase(rt, count)
+            run_phase(rt, count, look, host_main)
         # (timed inside whole frames: the kernel in the clock / cache context of the workload --
         # what `rocprofv3 --kernel-trace --stats` of this command averages; the back-to-back
         # figure of the launches alone is reported beside it)
@@ -363,6 +399,12 @@ def main() -> int:
         ctx = "@pass" if in_passes else "@frame"
         ms, launches, flops = rt.time_steps("tower" + ctx, args.roofline_iters)
         ms_alone = rt.time_steps("tower", args.roofline_iters)[0]
+        tower_in_pass_ms = None
+        if not in_passes and la_dev is not None and la_dev["timed_region"]["lookahead_frames"] > 0:
+            try:  # (beside the headline's figure: the same kernel inside look-ahead passes -- another power state)
+                tower_in_pass_ms = rt.time_steps("tower@pass", max(2, args.roofline_iters // 4))[0]
+            except R.JoshUpscaleError:
+                tower_in_pass_ms = None
         flops_per_launch = flops / max(launches, 1)
         achieved = flops_per_launch / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_MFMA_TFLOPS
@@ -451,9 +493,16 @@ def main() -> int:
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "preroll": args.preroll, "untimed_frames": args.preroll + args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            # the same runtime through the frame-by-frame boundary call (ju_process), measured right after the timed
-            # region: `value` is taken through ju_process_batch passes unless --lookahead 1 / psp-fast / host frames
-            "frame_by_frame_value": per_frame_fps,
+            # Secondary figures: the same runtime, the same box, each in a timed region of its own right after the
+            # contract's (same barrier / synchronise / max-over-ranks method, `extra_frames` frames each, one output
+            # buffer per frame).  In reading order: the drop-in boundary over a longer sample than --steps; the look-ahead
+            # extension of the boundary (callers that can hand over 8 consecutive frames); host frames (PCIe-inclusive:
+            # the reference's own timing loop, scripts/inference/tensorrt/inference.py:245-251) both ways.
+            "frame_by_frame_value": fbf and fbf["value"],
+            "lookahead_value": la_dev and la_dev["value"],
+            "host_frames_value": host_fbf and host_fbf["value"],
+            "host_frames_lookahead_value": host_la and host_la["value"],
+            "extra_frames": extra,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {
@@ -467,11 +516,15 @@ def main() -> int:
                 "affinity": AFFINITY,
                 "boundary": ("ju_process_batch (synchronous; passes of %d consecutive frames: the flow fields of a pass in one "
                              "sweep of the flow net's launches, warp / tower / tail frame by frame; bytes equal "
-                             "ju_process)" % look) if in_passes else "ju_process (synchronous processImage)",
-                "lookahead": {"frames_per_pass": look if in_passes else 1,
-                              "frame_by_frame_value": per_frame_fps,
-                              "frame_by_frame_how": "ju_process on the same runtime after the timed region, %d frames "
-                                                    "(the latency loop)" % len(lat)},
+                             "ju_process) -- NOT the reference's boundary: an explicit --lookahead run" % look) if in_passes
+                            else "ju_process (synchronous processImage, one frame per call: core.h:68-69)",
+                "secondary": {
+                    "how": "each figure: its own timed region after the contract's (barrier + synchronise on both sides, slowest "
+                           "rank), %d frames after 32 warm-up frames of its kind, a ring of %d inputs and one output buffer per "
+                           "frame" % (extra, RING),
+                    "frame_by_frame": fbf, "lookahead": la_dev, "host_frames": host_fbf, "host_frames_lookahead": host_la,
+                    "tower_launch_ms_inside_passes": tower_in_pass_ms,
+                },
                 "library": {"timed": product["library"], "kernel_times": os.path.basename(R.library_path(True))},
                 "timed_region": timed_region,
                 "resident_fallbacks": product["fallbacks"],
@@ -485,8 +538,7 @@ def main() -> int:
                                       "captured in set-up by ju_prepare_frames / ju_prepare_batch (unregistered tuples: at "
                                       "their second use), replayed afterwards"},
                 "tower": "resident (one launch)" if product["resident_tower"] else "per-layer launches",
-                "latency_ms": {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
-                               "max": lat[-1], "frames": len(lat)},
+                "latency_ms": latency,
                 "gflop_per_frame": total_flops / 1e9,
                 "whole_frame_tflops": total_flops * fps / world / 1e12,
             },

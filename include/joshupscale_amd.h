@@ -106,7 +106,7 @@ JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image
  * outputs[i] receives exactly the bytes ju_process(inputs[i], outputs[i]) called in order would have written,
  * and the recurrent state afterwards is the same -- but ALL inputs must hold their pixels when the call is made
  * (an input that overlaps the OUTPUT of an earlier frame of the call -- to be read after that write, frame by frame --
- * simply starts a new pass).
+ * simply starts a new pass, and so does an output that overlaps an earlier frame's INPUT).
  * The flow net reads LR frames only, never the HR state, so for JU_LOC_DEVICE frames the runtime computes the flow
  * fields of up to 8 frames in ONE pass of the flow net's launches, which fill the chip where one frame's do not
  * (-40 % flow time per frame at 480x270); warp, tower and tail stay strictly frame by frame.  Frames the pass

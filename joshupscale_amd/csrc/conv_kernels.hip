@@ -554,8 +554,9 @@ void launchConvT(const ConvParams &p, hipStream_t stream) {
 	// forces it off/on for A/B timing.)
 	static const char *dbufEnv = devSwitch(Dev::ConvDbuf);
 	const int cus = currentDeviceCUs();
+	// (a look-ahead launch covers `items` frames: that many times the workgroups, as fbLaunchCost and the split-K rule count)
 	const long wgs = (long)((p.W + kTW - 1) / kTW) * ((p.H + 4 * p.rw - 1) / (4 * p.rw)) *
-	                 (p.cout / (32 * p.nb));
+	                 (p.cout / (32 * p.nb)) * (p.items > 1 ? p.items : 1);
 	// several 64-channel chunks: the loads of chunk c+1 travel behind the MFMAs of chunk
 	// c (register prefetch).  Two LDS stages when the launch has at most one workgroup
 	// per CU anyway, one stage (and a second barrier) when two can be co-resident.

@@ -1642,30 +1642,140 @@ void Engine::runBatch(int set, int n, const std::function<void(const Step &, boo
 		for (const Step &st : m_Program[set]) {
 			if (st.tag != "flow" && st.tag != "pack") run(st);
 		}
+		// (a host frame: its bytes are complete in m_PassOut[i] -- tell the thread that copies them out)
+		if (m_BatchHost[i].hostOut) launchSignalHost(m_PassSignal.device(), m_Stream);
 	}
 }
 
+// A frame may go into a pass when each of its two images is either a device-resident one the kernels can read / write in
+// place (directEligible's conditions) or a host image of the right size (staged through the pass's own device buffers).
+bool Engine::passEligible(const Frame &in, const Frame &out) const {
+	const FrameSize fs = frameSize();
+	const auto inRow = static_cast<std::ptrdiff_t>(fs.inputWidth * 4);
+	const auto outRow = static_cast<std::ptrdiff_t>(fs.outputWidth * 4);
+	auto sized = [](const Frame &f, std::size_t w, std::size_t h, std::ptrdiff_t row) {
+		return f.ptr != nullptr && f.width == w && f.height == h && (f.stride >= row || -f.stride >= row);
+	};
+	if (!sized(in, fs.inputWidth, fs.inputHeight, inRow) || !sized(out, fs.outputWidth, fs.outputHeight, outRow)) return false;
+	auto side = [&](const Frame &f, unsigned align) {
+		if (f.location == Location::Host) return true;
+		return f.location == Location::Device && m_PreferDirect && reinterpret_cast<std::uintptr_t>(f.ptr) % align == 0 &&
+		       f.stride % static_cast<std::ptrdiff_t>(align) == 0;
+	};
+	return side(in, 4) && side(out, 8);
+}
+
+// Binds the n frames of a pass: m_BatchIO[i] = what frame i's kernels read and write -- the caller's device memory, or
+// for a host image the pass's device buffer i, addressed with the SIGN of the caller's stride (a bottom-up host frame is
+// uploaded / downloaded in memory order and read / written bottom-up by the kernels: no flip pass).  The key of the
+// pass's graph is made of those bindings, so all-host passes of one length and orientation share one graph.
 std::vector<Engine::DirectKey> Engine::bindBatch(const Frame *in, const Frame *out, int n, int set) {
+	const FrameSize fs = frameSize();
+	const auto inRow = static_cast<std::ptrdiff_t>(fs.inputWidth * 4);
+	const auto outRow = static_cast<std::ptrdiff_t>(fs.outputWidth * 4);
 	std::vector<DirectKey> key(static_cast<std::size_t>(n));
 	for (int i = 0; i < n; ++i) {
-		m_BatchIO[i].in = static_cast<const std::uint8_t *>(in[i].ptr);
-		m_BatchIO[i].inStride = in[i].stride;
-		m_BatchIO[i].out = static_cast<std::uint8_t *>(out[i].ptr);
-		m_BatchIO[i].outStride = out[i].stride;
-		key[i] = DirectKey{in[i].ptr, in[i].stride, out[i].ptr, out[i].stride, set};
+		FrameIO &io = m_BatchIO[i];
+		m_BatchHost[i].hostIn = in[i].location == Location::Host;
+		m_BatchHost[i].hostOut = out[i].location == Location::Host;
+		if (m_BatchHost[i].hostIn) {
+			if (!m_PassIn[i].get()) m_PassIn[i] = DeviceBuffer(fs.inputHeight * static_cast<std::size_t>(inRow));
+			auto *base = m_PassIn[i].as<std::uint8_t>();
+			io.in = in[i].stride >= 0 ? base : base + static_cast<std::ptrdiff_t>(fs.inputHeight - 1) * inRow;
+			io.inStride = in[i].stride >= 0 ? inRow : -inRow;
+		} else {
+			io.in = static_cast<const std::uint8_t *>(in[i].ptr);
+			io.inStride = in[i].stride;
+		}
+		if (m_BatchHost[i].hostOut) {
+			if (!m_PassOut[i].get()) m_PassOut[i] = DeviceBuffer(fs.outputHeight * static_cast<std::size_t>(outRow));
+			if (!m_PassSignal.host()) m_PassSignal = PinnedWords(64);
+			if (!m_CopyStream) m_CopyStream = std::make_unique<Stream>();
+			auto *base = m_PassOut[i].as<std::uint8_t>();
+			io.out = out[i].stride >= 0 ? base : base + static_cast<std::ptrdiff_t>(fs.outputHeight - 1) * outRow;
+			io.outStride = out[i].stride >= 0 ? outRow : -outRow;
+		} else {
+			io.out = static_cast<std::uint8_t *>(out[i].ptr);
+			io.outStride = out[i].stride;
+		}
+		key[i] = DirectKey{io.in, io.inStride, io.out, io.outStride, set};
 	}
 	return key;
+}
+
+// Every host input of the pass into its device buffer, rows in MEMORY order (the binding carries the orientation), on the
+// engine's stream in front of the pass's launches.  Pageable memory: the runtime stages or page-locks per call, as in
+// stageIn; 0.52 MB per frame.
+void Engine::uploadPassInputs(const Frame *in, int n) {
+	const FrameSize fs = frameSize();
+	const std::size_t rowBytes = fs.inputWidth * 4, rows = fs.inputHeight;
+	for (int i = 0; i < n; ++i) {
+		if (!m_BatchHost[i].hostIn) continue;
+		const auto *p0 = static_cast<const std::uint8_t *>(in[i].ptr);
+		const std::uint8_t *lowest = in[i].stride >= 0 ? p0 : p0 + static_cast<std::ptrdiff_t>(rows - 1) * in[i].stride;
+		const std::size_t pitch = static_cast<std::size_t>(in[i].stride >= 0 ? in[i].stride : -in[i].stride);
+		if (pitch == rowBytes) {
+			JU_HIP(hipMemcpyAsync(m_PassIn[i].get(), lowest, rowBytes * rows, hipMemcpyHostToDevice, m_Stream));
+		} else {
+			JU_HIP(hipMemcpy2DAsync(m_PassIn[i].get(), rowBytes, lowest, pitch, rowBytes, rows, hipMemcpyHostToDevice, m_Stream));
+		}
+	}
+}
+
+// The thread blocked in processBatch: wait for frame i's completion count, copy frame i out on the copy stream while the
+// GPU runs frame i + 1, in order.  The wait is bounded by the pass itself: once the engine's stream has drained, a count
+// that has not arrived never will.
+void Engine::drainPassOutputs(const Frame *out, int n) {
+	const FrameSize fs = frameSize();
+	const std::size_t rowBytes = fs.outputWidth * 4, rows = fs.outputHeight;
+	volatile unsigned *word = m_PassSignal.host();
+	unsigned due = 0;
+	bool any = false;
+	for (int i = 0; i < n; ++i) {
+		if (!m_BatchHost[i].hostOut) continue;
+		++due;
+		auto arrived = [&] { return static_cast<int>(*word - m_PassSignalBase) >= static_cast<int>(due); };
+		for (unsigned spins = 1; !arrived(); ++spins) {
+			if ((spins & 255u) == 0) {
+				const hipError_t st = hipStreamQuery(m_Stream);
+				if (st == hipSuccess) {
+					if (arrived()) break;
+					throw std::runtime_error("look-ahead pass: the completion count of a host frame did not arrive");
+				}
+				if (st != hipErrorNotReady) JU_HIP(st);
+			} else {
+				__builtin_ia32_pause();
+			}
+		}
+		auto *p0 = static_cast<std::uint8_t *>(out[i].ptr);
+		std::uint8_t *lowest = out[i].stride >= 0 ? p0 : p0 + static_cast<std::ptrdiff_t>(rows - 1) * out[i].stride;
+		const std::size_t pitch = static_cast<std::size_t>(out[i].stride >= 0 ? out[i].stride : -out[i].stride);
+		if (pitch == rowBytes) {
+			JU_HIP(hipMemcpyAsync(lowest, m_PassOut[i].get(), rowBytes * rows, hipMemcpyDeviceToHost, *m_CopyStream));
+		} else {
+			JU_HIP(hipMemcpy2DAsync(lowest, pitch, m_PassOut[i].get(), rowBytes, rowBytes, rows, hipMemcpyDeviceToHost, *m_CopyStream));
+		}
+		any = true;
+	}
+	if (any) JU_HIP(hipStreamSynchronize(*m_CopyStream));
 }
 
 Engine::DirectEntry &Engine::batchEntry(const std::vector<DirectKey> &key) {
 	auto it = m_BatchGraphs.find(key);
 	if (it == m_BatchGraphs.end()) {
-		if (m_BatchGraphs.size() >= kMaxBatchGraphs) {  // least recently used out
-			auto victim = m_BatchGraphs.begin();
+		// least recently used out -- among the tuples nobody registered: a tuple handed to prepareBatch keeps its graphs
+		// (the header promises that process calls on it never capture), as registered pairs do; only a caller that keeps
+		// registering new tuples (more than kMaxRegisteredBatches) loses the registered one it used least recently
+		std::size_t registered = 0;
+		for (const auto &kv : m_BatchGraphs) registered += kv.second.registered ? 1 : 0;
+		if (m_BatchGraphs.size() - registered >= kMaxBatchGraphs || registered >= kMaxRegisteredBatches) {
+			const bool fromRegistered = m_BatchGraphs.size() - registered < kMaxBatchGraphs;
+			auto victim = m_BatchGraphs.end();
 			for (auto j = m_BatchGraphs.begin(); j != m_BatchGraphs.end(); ++j) {
-				if (j->second.lastUse < victim->second.lastUse) victim = j;
+				if (j->second.registered != fromRegistered) continue;
+				if (victim == m_BatchGraphs.end() || j->second.lastUse < victim->second.lastUse) victim = j;
 			}
-			m_BatchGraphs.erase(victim);
+			if (victim != m_BatchGraphs.end()) m_BatchGraphs.erase(victim);
 		}
 		it = m_BatchGraphs.emplace(key, DirectEntry{}).first;
 	}
@@ -1681,13 +1791,14 @@ int Engine::prepareBatch(const Frame *in, const Frame *out, int n) {
 	DeviceGuard g(m_Device);
 	if (n < 2 || n > m_BatchMax || !m_UseGraph || !m_DirectGraph) return 0;
 	for (int i = 0; i < n; ++i) {
-		if (!directEligible(in[i], out[i])) return 0;
+		if (!passEligible(in[i], out[i])) return 0;
 	}
 	if (!batchPlanned(n)) return 0;
 	std::unique_lock<std::mutex> chain = chainBegin();  // (no capture while another engine's constructor drains the device)
 	int captured = 0;
 	for (int set = 0; set < 2; ++set) {
 		DirectEntry &e = batchEntry(bindBatch(in, out, n, set));
+		e.registered = true;
 		if (e.graph.valid()) continue;
 		{
 			DryLaunchScope dry;  // the attributes of the tile heights this pass's launch sizes choose
@@ -1705,6 +1816,9 @@ int Engine::prepareBatch(const Frame *in, const Frame *out, int n) {
 void Engine::submitBatch(const Frame *in, const Frame *out, int n) {
 	const int set = m_Idx;
 	const std::vector<DirectKey> key = bindBatch(in, out, n, set);
+	uploadPassInputs(in, n);  // (outside the chain lock: a pageable upload blocks its caller)
+	m_PassSignalBase = m_PassSignal.host() ? *m_PassSignal.host() : 0u;
+	for (int i = 0; i < n; ++i) m_BatchHostFrames += (m_BatchHost[i].hostIn || m_BatchHost[i].hostOut) ? 1 : 0;
 	{
 		std::unique_lock<std::mutex> chain = chainBegin();
 		bool replayed = false;
@@ -1747,13 +1861,20 @@ void Engine::processBatch(const Frame *in, const Frame *out, int count) {
 			const std::size_t bytes = static_cast<std::size_t>(rows - 1) * static_cast<std::size_t>(f.stride >= 0 ? f.stride : -f.stride) + f.width * 4;
 			return std::make_pair(lo, lo + bytes);
 		};
+		// ... nor WRITING what an earlier frame of the pass reads: on the normal path that write comes after the read
+		// (frame k's tail after frame j's, j < k), but a pass whose resident tower timed out is run again frame by frame
+		// from its inputs, which must then still be what they were (advisor, round 5)
+		auto overlap = [](const std::pair<const std::uint8_t *, const std::uint8_t *> &a,
+		                  const std::pair<const std::uint8_t *, const std::uint8_t *> &b) {
+			return a.first < b.second && b.first < a.second;
+		};
 		int n = 0;
-		while (i + n < count && n < m_BatchMax && directEligible(in[i + n], out[i + n])) {
-			const auto r = range(in[i + n]);
+		while (i + n < count && n < m_BatchMax && passEligible(in[i + n], out[i + n])) {
+			const auto r = range(in[i + n]), w = range(out[i + n]);
 			bool clash = false;
-			for (int k = 0; k < n && !clash; ++k) {
-				const auto w = range(out[i + k]);
-				clash = r.first < w.second && w.first < r.second;
+			for (int k = 0; k < n && !clash; ++k) {  // (host and device addresses are different spaces)
+				clash = (in[i + n].location == out[i + k].location && overlap(r, range(out[i + k]))) ||
+				        (out[i + n].location == in[i + k].location && overlap(w, range(in[i + k])));
 			}
 			if (clash) break;
 			++n;
@@ -1765,12 +1886,14 @@ void Engine::processBatch(const Frame *in, const Frame *out, int count) {
 		}
 		const int set = m_Idx;
 		submitBatch(in + i, out + i, n);
+		drainPassOutputs(out + i, n);  // host frames: each copied out while the next one runs
 		m_Stream.synchronizeSpin(m_SpinUs);
 		if (const unsigned code = takeResidentError()) {
-			// nothing the pass wrote was one of its inputs (see above): the same frames again, one by one, on the
-			// per-block kernels
+			// nothing the pass wrote was one of its inputs -- neither the state (see above) nor a frame buffer (the pass
+			// splitter): the same frames again, one by one, on the per-block kernels
 			m_Idx = set;
 			m_BatchFrames -= static_cast<std::uint64_t>(n);
+			for (int k = 0; k < n; ++k) m_BatchHostFrames -= (m_BatchHost[k].hostIn || m_BatchHost[k].hostOut) ? 1 : 0;
 			fallbackToLayers(code);
 			for (int k = 0; k < n; ++k) {
 				submit(in[i + k], out[i + k]);
@@ -2008,7 +2131,10 @@ double Engine::timeSteps(const std::string &tagSpecIn, int iters, int *launches)
 	std::unique_lock<std::mutex> chain = chainBegin();  // (the timed launches may be resident towers)
 	if (inPass) {
 		const int n = m_BatchMax, set = m_Idx;
-		for (int i = 0; i < n; ++i) m_BatchIO[i] = m_IO;  // (every frame of the pass on the staging buffers)
+		for (int i = 0; i < n; ++i) {  // (every frame of the pass on the staging buffers)
+			m_BatchIO[i] = m_IO;
+			m_BatchHost[i] = PassFrame{};
+		}
 		std::vector<std::unique_ptr<Event>> ev;
 		const std::function<void(const Step &, bool)> around = [&](const Step &s, bool) {
 			if (std::find(steps.begin(), steps.end(), &s) == steps.end()) return;
@@ -2087,6 +2213,7 @@ double Engine::stat(const std::string &key) const {
 	}
 	if (key == "fallbacks") return static_cast<double>(m_Fallbacks);
 	if (key == "lookahead_frames") return static_cast<double>(m_BatchFrames);  // frames that went through look-ahead passes
+	if (key == "lookahead_host_frames") return static_cast<double>(m_BatchHostFrames);  // ... of them with a host image
 	if (key == "lookahead_max") return static_cast<double>(m_BatchMax);
 	if (key == "launches_per_frame") return static_cast<double>(m_Program[0].size());
 	if (key == "tower_variant") return static_cast<double>(towerVariant());  // (developer switch, tests)

@@ -290,6 +290,7 @@ private:
 		GraphExec graph;
 		unsigned seen = 0;
 		std::uint64_t lastUse = 0;
+		bool registered = false;  // a look-ahead tuple handed to prepareBatch: exempt from the LRU eviction
 	};
 	std::map<DirectKey, DirectEntry> m_DirectGraphs;
 	// pairs registered through prepareFrames (idx = 0 in the key): captured at their FIRST
@@ -308,7 +309,29 @@ private:
 	bool m_BatchUnsupported = false;
 	std::map<std::pair<int, int>, std::vector<Step>> m_BatchFlow;
 	std::map<std::vector<DirectKey>, DirectEntry> m_BatchGraphs;
-	static constexpr std::size_t kMaxBatchGraphs = 64;
+	// Host frames inside look-ahead passes (round 6; the AviSynth caller's frames, avisynth_plugin/src/main.cc:113-144, and
+	// the only path the reference's own timer measures, scripts/inference/tensorrt/inference.py:245-251).  Frame by frame
+	// the 8.3 MB of an output cross the PCIe link while the GPU idles -- the frame's rows all appear in its last
+	// microseconds and the next frame needs this one's state.  Inside a pass that is no longer so: every input of the
+	// pass is uploaded up front into the pass's own device buffers (m_PassIn), frame i's kernels write m_PassOut[i], a
+	// one-thread kernel behind frame i's last launch counts it done in host-mapped memory (m_PassSignal), and the thread
+	// blocked in processBatch copies frame i out on a second stream (SDMA, no CU) while frame i + 1 runs: only the last
+	// frame's copy is exposed.  The copies go from / to the caller's pageable rows through the HIP runtime as in
+	// stageIn / stageOut (cuda_convert.cc.cu:360-459); nothing of the caller's is page-locked (section 7 of DESIGN.md).
+	struct PassFrame {
+		bool hostIn = false, hostOut = false;
+	};
+	PassFrame m_BatchHost[kFlowBatchMax];
+	DeviceBuffer m_PassIn[kFlowBatchMax], m_PassOut[kFlowBatchMax];
+	std::unique_ptr<Stream> m_CopyStream;
+	PinnedWords m_PassSignal;
+	unsigned m_PassSignalBase = 0;
+	std::uint64_t m_BatchHostFrames = 0;
+	bool passEligible(const Frame &in, const Frame &out) const;
+	void uploadPassInputs(const Frame *in, int n);
+	void drainPassOutputs(const Frame *out, int n);
+	static constexpr std::size_t kMaxBatchGraphs = 64;          // unregistered tuples (LRU)
+	static constexpr std::size_t kMaxRegisteredBatches = 256;   // tuples registered through prepareBatch
 	std::uint64_t m_BatchFrames = 0;
 	bool batchPlanned(int items);
 	void submitBatch(const Frame *in, const Frame *out, int n);

@@ -574,6 +574,14 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const std::uint8_t *__re
 	*reinterpret_cast<unsigned *>(dst + static_cast<std::ptrdiff_t>(r) * dstStride + c * 4) = v;
 }
 
+// One more frame of a look-ahead pass is complete: a count in host-mapped memory the thread blocked in
+// Engine::processBatch polls, so that it can copy that frame out while the next one runs (host frames inside passes).
+// The kernel boundary in front of it has released the frame's bytes to memory; the increment itself is a system-scope
+// release so that the host sees it at once.
+__global__ void signal_host_kernel(unsigned *word) {
+	__hip_atomic_fetch_add(word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void to_float_kernel(
     const T *__restrict__ in, float *__restrict__ out, size_t n) {
@@ -766,6 +774,11 @@ void launchCopyRows(const std::uint8_t *src, std::ptrdiff_t srcStride, std::uint
 	hipLaunchKernelGGL(copy_rows_kernel, dim3(blocksFor((size_t)words * rows)), dim3(256), 0,
 	    stream, src, srcStride, dst, dstStride, words, static_cast<unsigned>(rows));
 	hipCheckLaunch("copy_rows");
+}
+
+void launchSignalHost(unsigned *word, hipStream_t stream) {
+	hipLaunchKernelGGL(signal_host_kernel, dim3(1), dim3(1), 0, stream, word);
+	hipCheckLaunch("signal_host");
 }
 
 void launchToFloat(DType dt, const void *in, float *out, std::size_t n, hipStream_t stream) {

@@ -54,8 +54,8 @@ struct ConvParams {
 	// weights must be packed for the same nb), rows per wave rw (tile = 4*rw rows).
 	int nb, rw;
 	// Frame look-ahead (Engine::processBatch): the same layer of `items` consecutive frames in one launch, item i at
-	// in + i * inItemBytes / out + i * outItemBytes.  0 or 1 = one frame.  Honoured by launchConvSplitK only (the
-	// other launchers refuse items > 1).
+	// in + i * inItemBytes / out + i * outItemBytes.  0 or 1 = one frame.  Honoured by launchConv (grid.z; no residual
+	// operand then) and launchConvSplitK; the flow block launcher has its own item fields (FlowBlockLaunch).
 	int items;
 	long inItemBytes, outItemBytes;
 };
@@ -278,7 +278,7 @@ inline std::size_t residentCounterBytes(int GX, int GY) {
 void launchResidentTower(DType dt, const ResidentTowerParams &p, hipStream_t stream);
 
 // Timing-only ablation switch of the tower kernel (0 = product kernel).
-// the resident tower's K loops run v_mfma_f32_16x16x32 (weights packed by packTowerWeights(..., true)) or 32x32x16
+// the resident tower's K loops run v_mfma_f32_16x16x32 (weights packed by packTowerWeightsM16, model.cpp) or 32x32x16
 bool residentTowerM16();
 void setTowerVariant(int variant);
 int towerVariant();
@@ -401,6 +401,10 @@ void launchTailFused(DType dt, const TailFusedLaunch &p, hipStream_t stream);
 // Row-wise device copy with signed strides (bottom-up frames).
 void launchCopyRows(const std::uint8_t *src, std::ptrdiff_t srcStride, std::uint8_t *dst,
     std::ptrdiff_t dstStride, std::size_t rowBytes, std::size_t rows, hipStream_t stream);
+
+// *word += 1 (system scope) once everything enqueued before it on `stream` has completed: `word` is the device address of
+// host-mapped memory (PinnedWords) that the host polls.  Host frames inside look-ahead passes (Engine::processBatch).
+void launchSignalHost(unsigned *word, hipStream_t stream);
 
 // max |x| over n 16-bit elements, atomically folded into *out as the bit pattern of a
 // non-negative float (the caller zeroes it per frame).  Calibration mode only.

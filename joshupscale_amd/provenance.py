@@ -27,8 +27,8 @@ KERNEL_SOURCES = {
     "tail_fused_kernel": "frame_kernels.hip",
     "warp_pack_kernel": "frame_kernels.hip",
     "pack_frames_kernel": "frame_kernels.hip",
-    "upsample2_kernel": "conv_kernels.hip",
-    "maxpool2_kernel": "conv_kernels.hip",
+    "upsample2_kernel": "frame_kernels.hip",
+    "maxpool2_kernel": "frame_kernels.hip",
 }
 
 

@@ -13,6 +13,13 @@ restatement) on the u8 output (B,G,R bytes; X must be 0):
            full size 0.0231 % (psp-quality) / 0.0223 % (ps2-quality), profiles/r02_quality_*.json;
            the bound is 1.4 x the worst measured, like every other one here
 
+Large flows have a bound of their own (TOL_LARGE_FLOW; test_large_flows_reach_across_and_beyond_the_frame: flow heads
+scaled to 14 and 68 HR pixels on small frames).  The f16 flow head resolves 2^-6 / 2^-5 px at |flow| in [16, 32) / [32, 64),
+and a sample fetched that far away is an unrelated pixel, so the head's storage rounding becomes interpolation-weight
+error on EVERY output pixel instead of on the few that move: fp16 PSNR >= 59 dB, bf16 >= 52 dB, max <= 3 LSB, <= 0.08 %
+of bytes off by more than 1 (measured, profiles/r05_parity_stats.json: fp16 62.9-73.5 dB, bf16 55.5-64.4 dB, 2 LSB,
+0.055 % -- the suite's worst frac_gt1, which round 5 left unstated; the bound is 1.4 x it).
+
 and on internal tensors (max abs error): flow head 0.003 / 0.02 HR pixels (the head is
 stored as f16: up to 2^-9 px of storage rounding at |flow| in [2, 4)), output_raw and the
 generator input 0.001 / 0.007 (fp16 / bf16).
@@ -39,6 +46,11 @@ from joshupscale_amd import runtime as R
 TOL = {
     R.DTYPE_F16: dict(psnr=61.0, max=1, frac=0.0, flow=0.003, raw=0.001),
     R.DTYPE_BF16: dict(psnr=53.0, max=3, frac=0.0001, frac_noise=0.00035, flow=0.02, raw=0.007),
+}
+# flows of tens of HR pixels (see the header): the only case with a looser u8 bound than TOL
+TOL_LARGE_FLOW = {
+    R.DTYPE_F16: dict(psnr=59.0, max=3, frac=0.0008),
+    R.DTYPE_BF16: dict(psnr=52.0, max=3, frac=0.0008),
 }
 GOLD = os.path.join(ROOT, "tests", "golden")
 

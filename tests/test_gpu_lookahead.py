@@ -109,8 +109,9 @@ def test_look_ahead_replays_graphs_and_takes_long_and_ragged_calls():
 
 
 def test_look_ahead_mixes_with_host_frames_and_respects_the_cap(monkeypatch):
-    """Frames a pass cannot take -- host frames here -- run as ju_process does, in order, inside the same call; and
-    JU_LOOKAHEAD=1 turns the passes off altogether.  Same bytes every way."""
+    """A host frame between device frames rides in the same pass (round 6: staged through the pass's own device
+    buffers, its output copied out while the next frame runs); the cap -- ju_set_lookahead, or JU_LOOKAHEAD as the
+    default of new runtimes -- turns the passes off altogether.  Same bytes every way."""
     import torch
     cfg = M.PRESETS["psp-fast"]
     h, w = cfg.frame_height, cfg.frame_width
@@ -127,7 +128,24 @@ def test_look_ahead_mixes_with_host_frames_and_respects_the_cap(monkeypatch):
         got = d_out.cpu().numpy()
         for t in range(7):
             assert np.array_equal(host_out if t == 3 else got[t], want[t]), t
-        assert rt.stat("lookahead_frames") == 6
+        assert rt.stat("lookahead_frames") == 7 and rt.stat("lookahead_host_frames") == 1
+        # the setter: passes of at most 3 from now on (7 frames = 3 + 3 + 1), then off
+        rt.reset()
+        rt.set_lookahead(3)
+        assert rt.stat("lookahead_max") == 3
+        rt.process_batch(ins, outs)
+        got = d_out.cpu().numpy()
+        for t in range(7):
+            assert np.array_equal(host_out if t == 3 else got[t], want[t]), t
+        assert rt.stat("lookahead_frames") == 7 + 6
+        rt.reset()
+        rt.set_lookahead(0)                                                 # clamped to 1 = frame by frame
+        assert rt.stat("lookahead_max") == 1
+        rt.process_batch(ins, outs)
+        assert rt.stat("lookahead_frames") == 7 + 6
+        assert all(np.array_equal(host_out if t == 3 else d_out[t].cpu().numpy(), want[t]) for t in range(7))
+        rt.set_lookahead(99)
+        assert rt.stat("lookahead_max") == 8
     monkeypatch.setenv("JU_LOOKAHEAD", "1")
     with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
         assert rt.stat("lookahead_max") == 1
@@ -135,6 +153,116 @@ def test_look_ahead_mixes_with_host_frames_and_respects_the_cap(monkeypatch):
                          [rt.device_image(d_out[t].data_ptr(), 4 * w, 4 * h) for t in range(7)])
         got = d_out.cpu().numpy()
         assert all(np.array_equal(got[t], want[t]) for t in range(7)) and rt.stat("lookahead_frames") == 0
+
+
+@pytest.mark.parametrize("preset,dtype", [("psp-quality", R.DTYPE_BF16), ("psp-fast", R.DTYPE_F16), ("ps2-quality", R.DTYPE_FP8)])
+def test_all_host_passes_give_the_frame_by_frame_bytes(preset, dtype):
+    """The AviSynth caller's frames (host memory, bottom-up: avisynth_plugin/src/main.cc:113-144) through look-ahead
+    passes: every input uploaded up front, every output copied out behind its frame while the next one runs.  Plain,
+    padded-stride and bottom-up (negative stride) frames, in and out independently, passes of 8, 5, 2 and 3 -- every
+    frame equals ju_process on the same host frames, and so does the recurrent state."""
+    cfg = M.PRESETS[preset]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    n = 18
+    frames = M.synthetic_frames(n, h, w, seed=97, kind="noise")
+    with R.Runtime(blob, 0, dtype) as rt:
+        want = [rt.process_image(frames[t]).copy() for t in range(n)]
+        want_state = rt.read_tensor("state").copy()
+
+    def host_views(kind, count, rows, cols):
+        """`count` frame buffers of one stride kind: (array to index as [row, col, 4] logically, JuImage)."""
+        views = []
+        for _ in range(count):
+            if kind == "plain":
+                a = np.zeros((rows, cols, 4), np.uint8)
+            elif kind == "padded":
+                a = np.zeros((rows, cols + 24, 4), np.uint8)[:, :cols]
+            else:  # bottom-up: the first logical row is the LAST row in memory
+                a = np.zeros((rows, cols + 8, 4), np.uint8)[::-1, :cols]
+            views.append(a)
+        return views
+
+    for in_kind, out_kind in (("plain", "plain"), ("bottom-up", "bottom-up"), ("padded", "bottom-up"), ("bottom-up", "padded")):
+        ins = host_views(in_kind, n, h, w)
+        outs = host_views(out_kind, 8, 4 * h, 4 * w)
+        for t in range(n):
+            ins[t][...] = frames[t]
+        with R.Runtime(blob, 0, dtype) as rt:
+            t = 0
+            for k in (8, 5, 2, 3):
+                rt.process_batch([R.host_image(ins[t + i]) for i in range(k)], [R.host_image(outs[i]) for i in range(k)])
+                for i in range(k):
+                    assert np.array_equal(outs[i], want[t + i]), (preset, in_kind, out_kind, "pass of", k, "frame", t + i)
+                t += k
+            assert np.array_equal(rt.read_tensor("state"), want_state)
+            assert rt.stat("lookahead_frames") == n and rt.stat("lookahead_host_frames") == n and rt.stat("fallbacks") == 0
+            # one graph per (pass length, binding set, orientation) whatever the caller's addresses: the second pass of a
+            # length replays.  8, 5, 2, 3 again on fresh host arrays: four captures at most, then replays only
+            captures = rt.stat("graph_captures")
+            ins2 = host_views(in_kind, n, h, w)
+            for t2 in range(n):
+                ins2[t2][...] = frames[t2]
+            rt.reset()
+            t = 0
+            for k in (8, 5, 2, 3):
+                rt.process_batch([R.host_image(ins2[t + i]) for i in range(k)], [R.host_image(outs[i]) for i in range(k)])
+                t += k
+            assert np.array_equal(outs[2], want[n - 1])
+            rt.reset()
+            before = rt.stat("graph_replays")
+            rt.process_batch([R.host_image(ins2[i]) for i in range(8)], [R.host_image(outs[i]) for i in range(8)])
+            assert rt.stat("graph_replays") == before + 1 and rt.stat("graph_captures") <= captures + 4
+            assert all(np.array_equal(outs[i], want[i]) for i in range(8))
+
+
+def test_host_frames_in_a_pass_whose_tower_times_out_are_run_again_and_an_overwritten_input_splits_the_pass():
+    """(1) The fallback inside an all-host pass: the frames are run again one by one through the staging path and the
+    caller's buffers end up with the per-block tower's bytes.  (2) advisor, round 5: an OUTPUT that overlaps an EARLIER
+    frame's input would be harmless on the normal path (written after that input was read) but not for the re-run,
+    which reads the inputs again -- such a frame starts a new pass."""
+    import torch
+    cfg = M.PRESETS["psp-fast"]
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames = M.synthetic_frames(6, h, w, seed=59, kind="noise")
+    lib = R.load_library()
+    outs = [np.zeros((4 * h, 4 * w, 4), np.uint8) for _ in range(6)]
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:   # reference: the same fault frame by frame
+        want = []
+        for t in range(6):
+            if t == 2:
+                lib.ju_debug_set(b"resident_fault", 1)
+            try:
+                want.append(rt.process_image(frames[t]).copy())
+            finally:
+                lib.ju_debug_set(b"resident_fault", 0)
+        want_state = rt.read_tensor("state").copy()
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        rt.process_batch([R.host_image(frames[t]) for t in range(2)], [R.host_image(outs[t]) for t in range(2)])
+        lib.ju_debug_set(b"resident_fault", 1)
+        try:
+            rt.process_batch([R.host_image(frames[t]) for t in range(2, 6)], [R.host_image(outs[t]) for t in range(2, 6)])
+        finally:
+            lib.ju_debug_set(b"resident_fault", 0)
+        assert rt.stat("fallbacks") == 1 and rt.stat("lookahead_frames") == 2
+        assert all(np.array_equal(outs[t], want[t]) for t in range(6))
+        assert np.array_equal(rt.read_tensor("state"), want_state)
+    # (2) device frames: frame 1's output lies over frame 0's input
+    dev = torch.device("cuda", 0)
+    arena = torch.zeros((4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+    d_in = torch.from_numpy(frames).to(dev)
+    d_out = torch.zeros((4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+    arena.view(-1)[: h * w * 4] = d_in[0].view(-1)
+    torch.cuda.synchronize()
+    with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
+        ins = [rt.device_image(arena.data_ptr(), w, h), rt.device_image(d_in[1].data_ptr(), w, h),
+               rt.device_image(d_in[2].data_ptr(), w, h)]
+        outs_d = [rt.device_image(d_out.data_ptr(), 4 * w, 4 * h), rt.device_image(arena.data_ptr(), 4 * w, 4 * h),
+                  rt.device_image(d_out.data_ptr(), 4 * w, 4 * h)]
+        rt.process_batch(ins, outs_d)
+        # frame 0 alone (a "pass" of one frame is a plain call), then frames 1-2 as a pass
+        assert rt.stat("lookahead_frames") == 2
 
 
 @pytest.mark.parametrize("variant", ["generic-flow", "brightness", "flow-resnet", "temporal"])
@@ -227,7 +355,7 @@ def test_prepare_batch_captures_in_setup_and_the_passes_only_replay():
     """ju_prepare_batch is to ju_process_batch what ju_prepare_frames is to ju_process: the graphs of a registered
     tuple (one per binding set) exist before its first pass, which therefore replays -- no eager first sighting, no
     capture inside the call -- and writes the bytes of an unregistered runtime.  Tuples that cannot run as one pass
-    (a single frame, host frames, more frames than JU_LOOKAHEAD) register nothing."""
+    (a single frame, a wrong size, more frames than the cap) register nothing."""
     cfg = M.PRESETS["psp-fast"]
     h, w = cfg.frame_height, cfg.frame_width
     blob = M.serialize(cfg, M.make_seeded_weights(cfg))
@@ -240,7 +368,7 @@ def test_prepare_batch_captures_in_setup_and_the_passes_only_replay():
         assert rt.prepare_batch(ins[:4], outs) == 0                         # registered already
         assert rt.prepare_batch(ins[:1], outs[:1]) == 0
         assert rt.prepare_batch(ins + ins[:1], outs + outs + outs[:1]) == 0  # nine frames: not one pass
-        assert rt.prepare_batch([R.host_image(frames[0]), ins[1]], outs[:2]) == 0
+        assert rt.prepare_batch([rt.device_image(d_in[0].data_ptr(), w - 1, h), ins[1]], outs[:2]) == 0   # a wrong size
         assert rt.stat("prepared_captures") == 4 and rt.stat("eager_runs") == 0
         for p in range(2):
             rt.process_batch(ins[4 * p:4 * p + 4], outs)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from gpu_common import GOLD, TOL, check_u8, make, record
+from gpu_common import GOLD, TOL, TOL_LARGE_FLOW, check_u8, make, record
 from helpers import (M, O, ROOT, err, gen_in_to_reference, oracle_config, small_config,
                      tail_y_to_reference, u8_stats)
 from joshupscale_amd import runtime as R
@@ -157,8 +157,9 @@ def test_large_flows_reach_across_and_beyond_the_frame(scale, dtype):
         assert err(flow, trace["flow"])["rel_to_max"] <= (0.004 if dtype == R.DTYPE_F16 else 0.02)
         st = u8_stats(out, ref)
         record(("large-flow", scale, t), dtype, st)
-        # (measured: fp16 62.9-73.5 dB, bf16 55.5-64.4 dB, at most 2 LSB)
-        assert st["psnr"] >= (59.0 if dtype == R.DTYPE_F16 else 52.0) and st["max"] <= 3 and not out[..., 3].any(), (scale, t, st)
+        # (the large-flow bound stated in gpu_common.py; measured: fp16 62.9-73.5 dB, bf16 55.5-64.4 dB, at most 2 LSB, 0.055 %)
+        tol = TOL_LARGE_FLOW[dtype]
+        assert st["psnr"] >= tol["psnr"] and st["max"] <= tol["max"] and st["frac_gt1"] <= tol["frac"] and not out[..., 3].any(), (scale, t, st)
     assert far >= scale                # (HR pixels: 14 and 68 -- the frames really were sampled far away)
     rt.close()
 
