@@ -228,15 +228,23 @@ def test_host_frames_in_a_pass_whose_tower_times_out_are_run_again_and_an_overwr
     frames = M.synthetic_frames(6, h, w, seed=59, kind="noise")
     lib = R.load_library()
     outs = [np.zeros((4 * h, 4 * w, 4), np.uint8) for _ in range(6)]
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(frames).to(dev)
+    d_out = torch.zeros((4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:   # reference: the same fault frame by frame
+        # (device frames, a fresh input pointer per call: eager launches -- the test hook acts at LAUNCH time, a replayed
+        # graph of host staging would never see it; host and device frames give the same bytes)
         want = []
         for t in range(6):
             if t == 2:
                 lib.ju_debug_set(b"resident_fault", 1)
             try:
-                want.append(rt.process_image(frames[t]).copy())
+                rt.process(rt.device_image(d_in[t].data_ptr(), w, h), rt.device_image(d_out.data_ptr(), 4 * w, 4 * h))
+                want.append(d_out.cpu().numpy())
             finally:
                 lib.ju_debug_set(b"resident_fault", 0)
+        assert rt.stat("fallbacks") == 1
         want_state = rt.read_tensor("state").copy()
     with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
         rt.process_batch([R.host_image(frames[t]) for t in range(2)], [R.host_image(outs[t]) for t in range(2)])
@@ -249,10 +257,7 @@ def test_host_frames_in_a_pass_whose_tower_times_out_are_run_again_and_an_overwr
         assert all(np.array_equal(outs[t], want[t]) for t in range(6))
         assert np.array_equal(rt.read_tensor("state"), want_state)
     # (2) device frames: frame 1's output lies over frame 0's input
-    dev = torch.device("cuda", 0)
     arena = torch.zeros((4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
-    d_in = torch.from_numpy(frames).to(dev)
-    d_out = torch.zeros((4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
     arena.view(-1)[: h * w * 4] = d_in[0].view(-1)
     torch.cuda.synchronize()
     with R.Runtime(blob, 0, R.DTYPE_BF16) as rt:
