@@ -401,9 +401,12 @@ constexpr int kResMaxRH = 16;                                       // 8 row pai
 constexpr int kResPitch = kResRW + 2;                               // LDS row: 32 px + halo column each side
 constexpr int kResRowBytes = kResPitch * 128;                       // 4352
 constexpr int kResBufBytes = (kResMaxRH + 2) * kResRowBytes;       // 78336
+// 16 spare bytes BEHIND each buffer, at the same offset from its base (kResDummyOff): where the branch-free sweep of
+// the fast schedule sends the lanes that have no halo cell to fill, whichever buffer the layer writes
+constexpr int kResDummyOff = kResBufBytes;
 constexpr int kResOffA = 0;
-constexpr int kResOffB = kResBufBytes;
-constexpr int kResOffMisc = kResOffB + kResBufBytes;
+constexpr int kResOffB = kResBufBytes + 16;
+constexpr int kResOffMisc = kResOffB + kResBufBytes + 16;
 static_assert(kResRowBytes == 4352, "the ds_read immediates in tower_resident_kernel assume a 4352-byte row");
 constexpr int kResLds = kResOffMisc + 64 + 512;                     // flag, 2 bias slots
 constexpr int kResMailSlots = 4 * 32 * 8;                           // 16-byte slots per region per parity
@@ -1054,7 +1057,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			}
 		}
 		const u64 tu1 = stamp();
+#ifdef JU_DEV_WAITNOW
+		if constexpr (KIND == 0) { }
+#else
 		if constexpr (KIND == 0) prof[7] += tu1 - tu0;
+#endif
 #ifdef JU_TOWER_SEGPROF  // developer builds: the finish segments one by one (slots 3..6 carry them instead of their usual sums)
 		else if constexpr (KIND == 1 && !DEF) prof[3] += tu1 - tu0;
 		else if constexpr (KIND == 1 && DEF) prof[4] += tu1 - tu0;
@@ -1125,7 +1132,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		if constexpr (LO <= 2 && 2 < HI) slot(accPre2, 2);
 	};
 	// the rest of the layer: the pre-run units' remaining steps, then the other units whole
-	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const bool streamW) __attribute__((always_inline)) {
+	// seg1Done (JU_EARLYFIN_DEV timing builds): the first finish segment of this layer already ran inside the previous
+	// layer's halo fill
+	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const bool streamW, const bool seg1Done = false) __attribute__((always_inline)) {
 		const int afterPre = firstWhole >= 0 ? firstWhole : (mySingle ? np2 : -1);
 		if constexpr (kDefer) {
 			// The fast schedule's shape (two pre-run pairs, then one or two whole pairs: every wave of a
@@ -1140,7 +1149,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				using N = std::false_type;
 				const int ua = firstWhole, ub = nextWhole(firstWhole);
 				int lastUnit = ua;
+#ifdef JU_EARLYFIN_DEV
+				if (!seg1Done) unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre0, layer, preFirst, false, -1, true, N{}, N{}, accPre0, 0, N{});
+#else
 				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre0, layer, preFirst, false, preFirst + 2, true, N{}, N{}, accPre0, 0, N{});
+#endif
 				if (kPreRun == 3 && nPre == 3) {
 					// (16-row regions: three pre-run pairs, one whole pair)
 					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, true, preFirst + 4, true, N{}, Y{}, accPre0, preFirst, N{});
@@ -1148,7 +1161,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, Y{}, Y{}, accPre2, preFirst + 4, N{});
 					else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, N{}, Y{}, accPre2, preFirst + 4, N{});
 				} else {
+#ifdef JU_EARLYFIN_DEV
+					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, false, ua, false, N{}, Y{}, accPre0, preFirst, N{});
+#else
 					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, true, ua, false, N{}, Y{}, accPre0, preFirst, N{});
+#endif
 					if (ub >= 0) {
 						// (the third set takes the first whole pair, so that the last one finds accPre0 free)
 						unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre2, layer, ua, true, ub, false, N{}, Y{}, accPre1, preFirst + 2, N{});
@@ -1234,17 +1251,37 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// dword = value16 | epoch16 << 16 with epoch = (writes to this slot so far) & 0xffff --
 	// every dword still validates itself, the mailbox holds twice the slots (16 per pixel
 	// record instead of 8) and publish / sweep move 8-byte half chunks on the LDS side.
+	// The fast schedule's exchange is branch-free (round 6).  Measured with stamps inside the fill (profiles/r06_tower_fill.txt):
+	// the sweep's loads have a raw latency of ~730 cycles and are back before the pre-run unit behind them ends -- what
+	// was called "exposed exchange" was the CODE that checks them: per slot four v_cmp -> s_and chains, a saveexec and a
+	// branch, ~180 cycles each at one wave per SIMD, 900-1050 cycles per layer, and as many again where a second pass is
+	// checked.  Now: one OR of the four (dword ^ expected epoch) per slot into a per-lane accumulator, ONE vote per pass;
+	// every lane writes its slot's payload every pass (a slot holds the previous write or the expected one, never a newer
+	// one, so a rewrite can only repeat the bytes; lanes without a halo cell write the 16 spare bytes behind the buffer
+	// and read their OWN region's slot, which carries the same epoch); the publish stores unconditionally (an entry
+	// beyond the region's rows lands in its own slot, which no consumer reads).
+	constexpr bool kFastXchg = FAST && !LEAKY;
 	constexpr int kSlots = LEAKY ? 2 * kResMailSlots : kResMailSlots;  // per region and parity
 	constexpr int CPP = LEAKY ? 16 : 8;      // slots per pixel record
 	constexpr int CSH = LEAKY ? 4 : 3;
-	constexpr int NP = kSlots / 256;         // publish: 4 strips x 32 entries x CPP slots
+	// (the fast exchange: a region is at most 16 rows high, so the two column strips have 16 entries each and share ONE
+	// slot per thread -- threads 0..127 the left column, 128..255 the right one: 3 publish stores and 4 sweep loads per
+	// thread instead of 4 and 5, every lane of every instruction at work; the mailbox's slot numbering is unchanged)
+	constexpr int NP = kFastXchg ? 3 : kSlots / 256;  // publish: 4 strips x 32 entries x CPP slots
 	constexpr int NS = NP + 1;               // sweep: 4 sides x 32 entries x CPP slots, + the 4 corners
 	unsigned pubLds[NP];                     // LDS byte offset inside a buffer of the (half) chunk to publish
+	unsigned pubOff[kFastXchg ? NP : 1];     // fast exchange: the slot's byte offset in the mailbox, parity 0 (else pubBase + it * 4096)
 	unsigned pubValid = 0;
 #pragma unroll
 	for (int it = 0; it < NP; ++it) {
 		const int idx = it * 256 + tid;
-		const int strip = idx >> (5 + CSH), e = (idx >> CSH) & 31, cs = idx & (CPP - 1);
+		int strip = idx >> (5 + CSH), e = (idx >> CSH) & 31;
+		const int cs = idx & (CPP - 1);
+		if (kFastXchg && it == 2) {
+			strip = 2 + (tid >> 7);
+			e = (tid >> 3) & 15;
+		}
+		if constexpr (kFastXchg) pubOff[it] = (unsigned)((region * 2) * kSlots + (strip * 32 + e) * CPP + cs) * 16u;
 		const int c = LEAKY ? cs >> 1 : cs, half = LEAKY ? (cs & 1) * 8 : 0;
 		int rr, cc;
 		bool valid;
@@ -1254,6 +1291,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		else { rr = e + 1; cc = rwv; valid = e < rhv; }
 		pubLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4) + half);
 		if (valid) pubValid |= 1u << it;
+		// (fast schedule, ReLU: the publish is branch-free -- an entry beyond the region's rows reads a harmless place and
+		// stores into its own, unused, slot)
+		if (kFastXchg && !valid) pubLds[it] = 0u;
 	}
 	const unsigned pubBase = (unsigned)(region * 2 * kSlots) * 16u + (unsigned)tid * 16u;
 	unsigned sweepSrc[NS];  // mailbox byte offset of the neighbour's slot, parity 0
@@ -1267,7 +1307,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			const int idx = it * 256 + tid;
 			const int hp = idx >> CSH;
 			cs = idx & (CPP - 1);
-			const int side = hp >> 5, e = hp & 31;
+			int side = hp >> 5, e = hp & 31;
+			if (kFastXchg && it == 2) {  // (both columns in one slot per thread, 16 entries each)
+				side = 2 + (tid >> 7);
+				e = (tid >> 3) & 15;
+			}
 			// side 0: row above, 1: row below, 2: column left, 3: column right
 			if (side < 2) {
 				ny += side == 0 ? -1 : 1;
@@ -1304,6 +1348,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		sweepSrc[it] = (unsigned)((nreg * 2) * kSlots + (strip * 32 + se) * CPP + cs) * 16u;
 		sweepLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4) + half);
 		if (valid) sweepValid |= 1u << it;
+		if (kFastXchg && !valid) {
+			// this lane has no neighbour slot to fetch: it reads a slot of its own region (published for the same layer into
+			// the same parity: the epoch the check expects) and parks the bytes behind the buffer
+			sweepSrc[it] = (unsigned)((region * 2) * kSlots + tid) * 16u;  // (slot `tid`: its own first publish store)
+			sweepLds[it] = (unsigned)kResDummyOff;
+		}
 	}
 	constexpr unsigned kParityBytes = kSlots * 16u;
 	// `layer`: the layer whose output (in buffer `off`) is published
@@ -1334,7 +1384,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4 *>(smem + off + pubLds[it]);
 #pragma unroll
 			for (int it = 0; it < NP; ++it) {
-				if (pubValid >> it & 1u) {
+				if constexpr (kFastXchg) {
+					// (post-ReLU values: the sign bits are clear already)
+					__builtin_amdgcn_raw_buffer_store_b128(v[it] | tm, mailRsrc, pubOff[it], soff, kSc1);
+				} else if (pubValid >> it & 1u) {
 					__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7fff7fffu) | tm, mailRsrc,
 					    pubBase + it * 4096, soff, kSc1);
 				}
@@ -1347,6 +1400,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		// tag-checked by its consumer; the two wait states cost nothing and keep the store's data
 		// registers untouched for as long as the probe's worst case needed.
 		asm volatile("s_nop 1" ::: "memory");
+#ifdef JU_DEV_PUBWAIT  // developer timing build: how long do the write-through stores take to be acknowledged?
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 	};
 	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
 	// returns false on timeout (uniform across the workgroup)
@@ -1392,27 +1448,71 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		// The first pass is straight-line code (not the loop's first iteration): what the caller
 		// runs behind its loads -- a pre-run unit, 32 accumulator registers -- is then defined on
 		// one path only and needs no copies where the paths would join.
+		// the fast exchange's check: every lane writes, one accumulator, one vote (see kFastXchg)
+		auto checkPassFast = [&](const u32x4(&hv)[NS]) __attribute__((always_inline)) {
+			unsigned bad = 0;
+#pragma unroll
+			for (int it = 0; it < NS; ++it) {
+				// the expected write XOR the expected epoch IS the payload (post-ReLU values: sign bits clear); anything
+				// else leaves epoch bits standing, is written all the same and overwritten by the pass that succeeds
+				const u32x4 x = hv[it] ^ tm;
+				bad |= x[0] | x[1] | x[2] | x[3];
+				*reinterpret_cast<u32x4 *>(smem + off + sweepLds[it]) = x;
+			}
+			pending = bad & 0x80008000u;  // != 0: some slot of this lane still holds the previous write
+		};
 		auto loadPass = [&]() __attribute__((always_inline)) { loadPassTo(hvFirst); };
-		auto checkPass = [&]() __attribute__((always_inline)) { checkPassOf(hvFirst); };
+		auto checkPass = [&]() __attribute__((always_inline)) {
+			if constexpr (kFastXchg) checkPassFast(hvFirst);
+			else checkPassOf(hvFirst);
+		};
 		loadPass();
 		__builtin_amdgcn_sched_barrier(0);
+#ifdef JU_DEV_WAITNOW  // developer diagnostic: the raw latency of the sweep's loads, nothing else running (profile slot 7 instead of the pre-run)
+		{
+			const u64 w0 = stamp();
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			prof[7] += stamp() - w0;
+		}
+#endif
+#ifdef JU_DEV_SLEEPCOVER  // developer diagnostic: ~2.5k idle cycles between the loads and their check (is it the K loops that hold the returns up?)
+		for (int z = 0; z < 20; ++z) __builtin_amdgcn_s_sleep(2);
+#endif
 		behindFirstPass();  // (work the caller wants done while the loads travel; vmcnt is in-order)
 		__builtin_amdgcn_sched_barrier(0);
+#ifdef JU_TOWER_FILLPROF  // developer diagnostic (variant 4): where inside the fill the time goes -- slots 1, 3, 4 of the profile
+		const u64 fp0 = stamp();
+#endif
+#ifdef JU_DEV_NOSECOND
+		if constexpr (false) {
+#else
 		if constexpr (FAST) {
+#endif
 			// A second pass in flight before the first is checked: when the first came too early for a slot
 			// (0.3 times per layer), its data is one pre-run unit behind instead of a whole round trip
 			// (-1 % per tower; twice the sweep's read traffic, 5 MB more per layer over the chip).
 			u32x4 hvSecond[NS];
 			loadPassTo(hvSecond);
 			__builtin_amdgcn_sched_barrier(0);
-			checkPassOf(hvFirst);
-			if (__any(pending != 0)) {
-				checkPassOf(hvSecond);
-				if constexpr (VARIANT == 4) extraPasses += 1;
+			if constexpr (kFastXchg) {
+				checkPassFast(hvFirst);
+				if (__any(pending != 0)) {
+					checkPassFast(hvSecond);
+					if constexpr (VARIANT == 4) extraPasses += 1;
+				}
+			} else {
+				checkPassOf(hvFirst);
+				if (__any(pending != 0)) {
+					checkPassOf(hvSecond);
+					if constexpr (VARIANT == 4) extraPasses += 1;
+				}
 			}
 		} else {
 			checkPass();
 		}
+#ifdef JU_TOWER_FILLPROF
+		const u64 fp1 = stamp();
+#endif
 		while (__any(pending != 0)) {
 			const u64 now = __builtin_amdgcn_s_memrealtime();
 			if (t0 == 0) t0 = now;
@@ -1429,7 +1529,16 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			checkPass();
 			if constexpr (VARIANT == 4) extraPasses += 1;
 		}
+#ifdef JU_TOWER_FILLPROF
+		const u64 fp2 = stamp();
+#endif
 		__syncthreads();
+#ifdef JU_TOWER_FILLPROF
+		const u64 fp3 = stamp();
+		prof[1] += fp1 - fp0;  // the first check (waits for the first pass's loads)
+		prof[3] += fp2 - fp1;  // the retry loop
+		prof[4] += fp3 - fp2;  // the barrier behind the fill
+#endif
 		return *failFlag == 0;
 	};
 
@@ -1442,13 +1551,17 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int L = p.nLayers;
 	// RES / PAR are compile-time: a runtime `if (residual)` around the epilogue's LDS
 	// read makes hipcc branch and wait per element (+1 us per layer, measured).
-	auto layerStep = [&](auto resTag, auto parTag, const int i) __attribute__((always_inline)) -> bool {
+	auto layerStep = [&](auto resTag, auto parTag, const int i, [[maybe_unused]] auto nextResTag) __attribute__((always_inline)) -> bool {
 		constexpr int PAR = decltype(parTag)::value;
 		using InT = std::integral_constant<int, PAR ? kResOffB : kResOffA>;
 		using OutT = std::integral_constant<int, PAR ? kResOffA : kResOffB>;
 		const bool more = i + 1 < L;
 		const u64 t0 = stamp();
+#ifdef JU_EARLYFIN_DEV
+		finishLayer(resTag, InT{}, OutT{}, i, more && streamsInUnit, FAST && i > 0);
+#else
 		finishLayer(resTag, InT{}, OutT{}, i, more && streamsInUnit);
+#endif
 		if constexpr (VARIANT == 5) {
 			// per-layer maximum over the frame -> debug[i] (non-negative floats order like
 			// their bit patterns, so an integer atomic max does it)
@@ -1494,6 +1607,14 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			preRun(OutT{}, InT{}, Z{}, Split{}, i + 1, primePre);
 			const bool okFill = fillHalo(OutT{}, i, [&]() __attribute__((always_inline)) {
 				preRun(OutT{}, InT{}, Split{}, N{}, i + 1, primePre);
+#ifdef JU_EARLYFIN_DEV
+				// TIMING BUILD (wrong frames: the halo columns it reads are the previous layer's): the next layer's first
+				// finish segment between the sweep's loads and its check -- what a mid-layer publish of the early units'
+				// edge columns would allow
+				if constexpr (FAST) {
+					unitSeg(R2{}, KFin{}, nextResTag, OutT{}, InT{}, accPre0, i + 1, preFirst, false, -1, true, std::false_type{}, std::false_type{}, accPre0, 0, std::false_type{});
+				}
+#endif
 			});
 			if (!okFill) return false;
 		} else {
@@ -1502,10 +1623,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		}
 		const u64 t5 = stamp();
 		prof[0] += t5 - t4;
+#ifndef JU_TOWER_FILLPROF
 		prof[1] += (VARIANT == 4 && FAST) ? extraPasses * 1000 : t4 - t3;  // (fast schedule: sweep passes beyond the first, x 1000)
+#endif
 		extraPasses = 0;
 		prof[2] += t1 - t0;
-#ifndef JU_TOWER_SEGPROF
+#if !defined(JU_TOWER_SEGPROF) && !defined(JU_TOWER_FILLPROF)
 		prof[3] += t2 - t1;
 		prof[4] += t3 - t2;
 #endif
@@ -1517,16 +1640,17 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	using P1 = std::integral_constant<int, 1>;
 	preRun(std::integral_constant<int, kResOffA>{}, std::integral_constant<int, kResOffB>{}, std::integral_constant<int, 0>{},
 	    std::integral_constant<int, kPreRun>{}, 0, false);
+	// (the last argument: does the NEXT layer add a residual -- its first segments may run inside this layer's exchange)
 	if (HEAD) {  // conv_1, then (conv1, conv2+skip) pairs: L is odd
-		if (!layerStep(No{}, P0{}, 0)) return;
+		if (!layerStep(No{}, P0{}, 0, No{})) return;
 		for (int i = 1; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P1{}, i)) return;
-			if (!layerStep(Yes{}, P0{}, i + 1)) return;
+			if (!layerStep(No{}, P1{}, i, Yes{})) return;
+			if (!layerStep(Yes{}, P0{}, i + 1, No{})) return;
 		}
 	} else {  // (conv1, conv2+skip) pairs: L is even
 		for (int i = 0; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P0{}, i)) return;
-			if (!layerStep(Yes{}, P1{}, i + 1)) return;
+			if (!layerStep(No{}, P0{}, i, Yes{})) return;
+			if (!layerStep(Yes{}, P1{}, i + 1, No{})) return;
 		}
 	}
 	const int finalOff = (L & 1) ? kResOffB : kResOffA;

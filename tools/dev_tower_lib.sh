@@ -11,5 +11,5 @@ mkdir -p build/ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -Ijoshupscale_amd/csrc \
   -Wno-unused-parameter -mllvm -amdgpu-mfma-vgpr-form -DJU_TOWER_DEV "$@" -c $SRC -o build/ab/tower_$n.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/ab/lib_$n.so \
-  $(ls build/obj/*.o | grep -v -e tower_kernels.o -e /c_api.o -e /graphics.o) build/ab/tower_$n.o -Wl,--exclude-libs,ALL -ldl
+  $(ls build/obj/*.o | grep -v -e tower_kernels.o -e /c_api.o -e /graphics.o -e /dev_switch.o) build/ab/tower_$n.o -Wl,--exclude-libs,ALL -ldl
 echo built build/ab/lib_$n.so
