@@ -41,8 +41,11 @@ constexpr int kT8SRow = kT8Pitch * 128;                 // stream row, bytes
 constexpr int kT8QRow = kT8Pitch * 64;                  // e4m3 row, bytes
 constexpr int kT8OffS = 0;
 constexpr int kT8OffX = (kT8MaxRH + 2) * kT8SRow;       // 78336
-constexpr int kT8OffT = kT8OffX + (kT8MaxRH + 2) * kT8QRow;
-constexpr int kT8OffMisc = kT8OffT + (kT8MaxRH + 2) * kT8QRow;  // 156672
+// (16 spare bytes behind each e4m3 buffer, at the same offset from its base: where the branch-free sweep parks the
+// lanes that have no halo cell to fill -- tower_kernels.hip, kLean)
+constexpr int kT8DummyOff = (kT8MaxRH + 2) * kT8QRow;
+constexpr int kT8OffT = kT8OffX + (kT8MaxRH + 2) * kT8QRow + 16;
+constexpr int kT8OffMisc = kT8OffT + (kT8MaxRH + 2) * kT8QRow + 16;  // 156704
 // misc: fail flag (64 B), per-layer bias x 2 slots (512 B), per-layer weight scale codes x 2 slots (512 B)
 constexpr int kT8Lds = kT8OffMisc + 64 + 512 + 512;
 constexpr int kT8MailSlots = 4 * 32 * 4;                // 16-byte slots per region per parity
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		else if (strip == 1) { rr = rhv; cc = e + 1; valid = e < rwv; }
 		else if (strip == 2) { rr = e + 1; cc = 1; valid = e < rhv; }
 		else { rr = e + 1; cc = rwv; valid = e < rhv; }
-		pubLds[it] = chunkOff(rr, cc, c);
+		pubLds[it] = valid ? chunkOff(rr, cc, c) : 0u;  // (branch-free publish: an entry beyond the region reads a harmless place)
 		if (valid) pubValid |= 1u << it;
 	}
 	const unsigned pubBase = (unsigned)(region * 2 * kSlots) * 16u + (unsigned)tid * 16u;
@@ -521,7 +524,16 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		sweepSrc[it] = (unsigned)((nreg * 2) * kSlots + (strip * 32 + se) * CPP + c) * 16u;
 		sweepLds[it] = chunkOff(rr, cc, c);
 		if (valid) sweepValid |= 1u << it;
+		if (!valid) {
+			// (round 6, as in tower_kernels.hip: the check is branch-free -- a lane without a neighbour slot reads entry 0 of
+			// its own region's top row strip, published for the same layer into the same parity, and parks the bytes in the
+			// 16 spare bytes behind the buffer)
+			sweepSrc[it] = (unsigned)((region * 2) * kSlots + (tid & (CPP - 1))) * 16u;
+			sweepLds[it] = (unsigned)kT8DummyOff;
+		}
 	}
+	(void)pubValid;
+	(void)sweepValid;
 	constexpr unsigned kParityBytes = kSlots * 16u;
 	auto publish = [&](auto offTag, int layer) {
 		constexpr int off = decltype(offTag)::value;
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x2w *>(smem + off + pubLds[it]);
 #pragma unroll
 			for (int it = 0; it < NP; ++it) {
-				if (pubValid >> it & 1u) {
+				{  // (unconditional: an entry beyond the region lands in its own slot, which no consumer reads)
 					const u32x4w d = {(v[it][0] & 0xffffu) | tg, (v[it][0] >> 16) | tg, (v[it][1] & 0xffffu) | tg,
 					    (v[it][1] >> 16) | tg};
 					__builtin_amdgcn_raw_buffer_store_b128(d, mailRsrc, pubBase + it * 4096, soff, kSc1);
@@ -549,9 +561,9 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4w *>(smem + off + pubLds[it]);
 #pragma unroll
 			for (int it = 0; it < NP; ++it) {
-				if (pubValid >> it & 1u) {
-					__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7f7f7f7fu) | tm, mailRsrc, pubBase + it * 4096, soff, kSc1);
-				}
+				// (unconditional.  The mask stays: an e4m3 -0 byte, which the conversion may produce, must not pass for an
+				// epoch bit -- one v_and_or per dword either way)
+				__builtin_amdgcn_raw_buffer_store_b128((v[it] & 0x7f7f7f7fu) | tm, mailRsrc, pubBase + it * 4096, soff, kSc1);
 			}
 		}
 		asm volatile("s_nop 1" ::: "memory");  // (store-data hazard of soffset-SGPR buffer stores: tower_kernels.hip, publish)
@@ -562,31 +574,31 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		const int par = (layer + 1) & 1;
 		const unsigned tm = LEAKY ? (pubCount[par] & 0xffffu) : epochMask(par);
 		const unsigned soff = par ? kParityBytes : 0u;
-		unsigned pending = sweepValid;
+		// Branch-free check (round 6; tower_kernels.hip measured the per-slot compare / branch form at ~180 cycles a slot
+		// on one wave per SIMD): the expected write XOR the expected epoch IS the payload -- post-ReLU e4m3 bytes have
+		// clear sign bits, LeakyReLU slots carry the epoch in their dwords' upper halves --, every lane writes every pass
+		// (a slot holds the previous write or the expected one, never a newer one: a rewrite repeats the bytes), one
+		// accumulator of the bits left standing, one vote per pass.
+		unsigned pending = 1u;
 		while (__any(pending != 0)) {
 			u32x4w hv[NS];
 #pragma unroll
 			for (int it = 0; it < NS; ++it) hv[it] = __builtin_amdgcn_raw_buffer_load_b128(mailRsrc, sweepSrc[it], soff, kSc1);
+			unsigned bad = 0;
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
 				if constexpr (LEAKY) {
 					typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
-					const u32x4w tg = hv[it] >> 16;
-					const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
-					if ((pending >> it & 1u) && ok) {
-						*reinterpret_cast<u32x2w *>(smem + off + sweepLds[it]) =
-						    u32x2w{(hv[it][0] & 0xffffu) | (hv[it][1] << 16), (hv[it][2] & 0xffffu) | (hv[it][3] << 16)};
-						pending &= ~(1u << it);
-					}
+					const u32x4w x = hv[it] ^ (tm << 16);
+					bad |= x[0] | x[1] | x[2] | x[3];
+					*reinterpret_cast<u32x2w *>(smem + off + sweepLds[it]) = u32x2w{(x[0] & 0xffffu) | (x[1] << 16), (x[2] & 0xffffu) | (x[3] << 16)};
 				} else {
-					const u32x4w tg = hv[it] & 0x80808080u;
-					const bool ok = tg[0] == tm && tg[1] == tm && tg[2] == tm && tg[3] == tm;
-					if ((pending >> it & 1u) && ok) {
-						*reinterpret_cast<u32x4w *>(smem + off + sweepLds[it]) = hv[it] & 0x7f7f7f7fu;
-						pending &= ~(1u << it);
-					}
+					const u32x4w x = hv[it] ^ tm;
+					bad |= x[0] | x[1] | x[2] | x[3];
+					*reinterpret_cast<u32x4w *>(smem + off + sweepLds[it]) = x;
 				}
 			}
+			pending = bad & (LEAKY ? 0xffff0000u : 0x80808080u);
 			if (pending != 0) {
 				const u64 now = __builtin_amdgcn_s_memrealtime();
 				if (t0 == 0) t0 = now;

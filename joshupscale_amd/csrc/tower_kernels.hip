@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// dword = value16 | epoch16 << 16 with epoch = (writes to this slot so far) & 0xffff --
 	// every dword still validates itself, the mailbox holds twice the slots (16 per pixel
 	// record instead of 8) and publish / sweep move 8-byte half chunks on the LDS side.
-	// The fast schedule's exchange is branch-free (round 6).  Measured with stamps inside the fill (profiles/r06_tower_fill.txt):
+	// The exchange is branch-free (round 6).  Measured with stamps inside the fill (profiles/r06_tower_fill.txt):
 	// the sweep's loads have a raw latency of ~730 cycles and are back before the pre-run unit behind them ends -- what
 	// was called "exposed exchange" was the CODE that checks them: per slot four v_cmp -> s_and chains, a saveexec and a
 	// branch, ~180 cycles each at one wave per SIMD, 900-1050 cycles per layer, and as many again where a second pass is
@@ -1260,28 +1260,32 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// one, so a rewrite can only repeat the bytes; lanes without a halo cell write the 16 spare bytes behind the buffer
 	// and read their OWN region's slot, which carries the same epoch); the publish stores unconditionally (an entry
 	// beyond the region's rows lands in its own slot, which no consumer reads).
-	constexpr bool kFastXchg = FAST && !LEAKY;
+	// Every instantiation but the plain schedule (VARIANT 8: the tests' cross-check keeps the per-slot form, on the same
+	// mailbox -- the slots both forms read are written by both) exchanges this way; kCompact: the ReLU slot format, whose
+	// publish and sweep also pack both columns into one slot per thread (below).
+	constexpr bool kLean = VARIANT != 8;
+	constexpr bool kCompact = kLean && !LEAKY;
 	constexpr int kSlots = LEAKY ? 2 * kResMailSlots : kResMailSlots;  // per region and parity
 	constexpr int CPP = LEAKY ? 16 : 8;      // slots per pixel record
 	constexpr int CSH = LEAKY ? 4 : 3;
-	// (the fast exchange: a region is at most 16 rows high, so the two column strips have 16 entries each and share ONE
+	// (kCompact: a region is at most 16 rows high, so the two column strips have 16 entries each and share ONE
 	// slot per thread -- threads 0..127 the left column, 128..255 the right one: 3 publish stores and 4 sweep loads per
 	// thread instead of 4 and 5, every lane of every instruction at work; the mailbox's slot numbering is unchanged)
-	constexpr int NP = kFastXchg ? 3 : kSlots / 256;  // publish: 4 strips x 32 entries x CPP slots
+	constexpr int NP = kCompact ? 3 : kSlots / 256;  // publish: 4 strips x 32 entries x CPP slots
 	constexpr int NS = NP + 1;               // sweep: 4 sides x 32 entries x CPP slots, + the 4 corners
 	unsigned pubLds[NP];                     // LDS byte offset inside a buffer of the (half) chunk to publish
-	unsigned pubOff[kFastXchg ? NP : 1];     // fast exchange: the slot's byte offset in the mailbox, parity 0 (else pubBase + it * 4096)
+	unsigned pubOff[kCompact ? NP : 1];      // kCompact: the slot's byte offset in the mailbox, parity 0 (else pubBase + it * 4096)
 	unsigned pubValid = 0;
 #pragma unroll
 	for (int it = 0; it < NP; ++it) {
 		const int idx = it * 256 + tid;
 		int strip = idx >> (5 + CSH), e = (idx >> CSH) & 31;
 		const int cs = idx & (CPP - 1);
-		if (kFastXchg && it == 2) {
+		if (kCompact && it == 2) {
 			strip = 2 + (tid >> 7);
 			e = (tid >> 3) & 15;
 		}
-		if constexpr (kFastXchg) pubOff[it] = (unsigned)((region * 2) * kSlots + (strip * 32 + e) * CPP + cs) * 16u;
+		if constexpr (kCompact) pubOff[it] = (unsigned)((region * 2) * kSlots + (strip * 32 + e) * CPP + cs) * 16u;
 		const int c = LEAKY ? cs >> 1 : cs, half = LEAKY ? (cs & 1) * 8 : 0;
 		int rr, cc;
 		bool valid;
@@ -1291,9 +1295,9 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		else { rr = e + 1; cc = rwv; valid = e < rhv; }
 		pubLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4) + half);
 		if (valid) pubValid |= 1u << it;
-		// (fast schedule, ReLU: the publish is branch-free -- an entry beyond the region's rows reads a harmless place and
-		// stores into its own, unused, slot)
-		if (kFastXchg && !valid) pubLds[it] = 0u;
+		// (the publish is branch-free: an entry beyond the region's rows or columns reads a harmless place and stores into
+		// its own slot, which no consumer reads)
+		if (kLean && !valid) pubLds[it] = 0u;
 	}
 	const unsigned pubBase = (unsigned)(region * 2 * kSlots) * 16u + (unsigned)tid * 16u;
 	unsigned sweepSrc[NS];  // mailbox byte offset of the neighbour's slot, parity 0
@@ -1308,7 +1312,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			const int hp = idx >> CSH;
 			cs = idx & (CPP - 1);
 			int side = hp >> 5, e = hp & 31;
-			if (kFastXchg && it == 2) {  // (both columns in one slot per thread, 16 entries each)
+			if (kCompact && it == 2) {  // (both columns in one slot per thread, 16 entries each)
 				side = 2 + (tid >> 7);
 				e = (tid >> 3) & 15;
 			}
@@ -1348,10 +1352,11 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		sweepSrc[it] = (unsigned)((nreg * 2) * kSlots + (strip * 32 + se) * CPP + cs) * 16u;
 		sweepLds[it] = (unsigned)(rr * kResRowBytes + cc * 128 + ((c ^ ((cc >> 1) & 7)) << 4) + half);
 		if (valid) sweepValid |= 1u << it;
-		if (kFastXchg && !valid) {
+		if (kLean && !valid) {
 			// this lane has no neighbour slot to fetch: it reads a slot of its own region (published for the same layer into
-			// the same parity: the epoch the check expects) and parks the bytes behind the buffer
-			sweepSrc[it] = (unsigned)((region * 2) * kSlots + tid) * 16u;  // (slot `tid`: its own first publish store)
+			// the same parity: the epoch the check expects) and parks the bytes behind the buffer.  Entry 0 of the top
+			// row strip: written in every geometry and by the plain schedule's publish too
+			sweepSrc[it] = (unsigned)((region * 2) * kSlots + (tid & (CPP - 1))) * 16u;
 			sweepLds[it] = (unsigned)kResDummyOff;
 		}
 	}
@@ -1371,7 +1376,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x2 *>(smem + off + pubLds[it]);
 #pragma unroll
 			for (int it = 0; it < NP; ++it) {
-				if (pubValid >> it & 1u) {
+				if (kLean || (pubValid >> it & 1u)) {
 					const u32x4 d = {(v[it][0] & 0xffffu) | tg, (v[it][0] >> 16) | tg, (v[it][1] & 0xffffu) | tg,
 					    (v[it][1] >> 16) | tg};
 					__builtin_amdgcn_raw_buffer_store_b128(d, mailRsrc, pubBase + it * 4096, soff, kSc1);
@@ -1384,7 +1389,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			for (int it = 0; it < NP; ++it) v[it] = *reinterpret_cast<const u32x4 *>(smem + off + pubLds[it]);
 #pragma unroll
 			for (int it = 0; it < NP; ++it) {
-				if constexpr (kFastXchg) {
+				if constexpr (kCompact) {
 					// (post-ReLU values: the sign bits are clear already)
 					__builtin_amdgcn_raw_buffer_store_b128(v[it] | tm, mailRsrc, pubOff[it], soff, kSc1);
 				} else if (pubValid >> it & 1u) {
@@ -1448,22 +1453,30 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		// The first pass is straight-line code (not the loop's first iteration): what the caller
 		// runs behind its loads -- a pre-run unit, 32 accumulator registers -- is then defined on
 		// one path only and needs no copies where the paths would join.
-		// the fast exchange's check: every lane writes, one accumulator, one vote (see kFastXchg)
+		// the branch-free check: every lane writes, one accumulator, one vote (see kLean)
 		auto checkPassFast = [&](const u32x4(&hv)[NS]) __attribute__((always_inline)) {
 			unsigned bad = 0;
 #pragma unroll
 			for (int it = 0; it < NS; ++it) {
-				// the expected write XOR the expected epoch IS the payload (post-ReLU values: sign bits clear); anything
-				// else leaves epoch bits standing, is written all the same and overwritten by the pass that succeeds
-				const u32x4 x = hv[it] ^ tm;
-				bad |= x[0] | x[1] | x[2] | x[3];
-				*reinterpret_cast<u32x4 *>(smem + off + sweepLds[it]) = x;
+				if constexpr (LEAKY) {
+					// dword = value16 | epoch16 << 16: XOR with the expected epoch clears the upper half of the expected write
+					typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+					const u32x4 x = hv[it] ^ (tm << 16);
+					bad |= x[0] | x[1] | x[2] | x[3];
+					*reinterpret_cast<u32x2 *>(smem + off + sweepLds[it]) = u32x2{(x[0] & 0xffffu) | (x[1] << 16), (x[2] & 0xffffu) | (x[3] << 16)};
+				} else {
+					// the expected write XOR the expected epoch IS the payload (post-ReLU values: sign bits clear); anything
+					// else leaves epoch bits standing, is written all the same and overwritten by the pass that succeeds
+					const u32x4 x = hv[it] ^ tm;
+					bad |= x[0] | x[1] | x[2] | x[3];
+					*reinterpret_cast<u32x4 *>(smem + off + sweepLds[it]) = x;
+				}
 			}
-			pending = bad & 0x80008000u;  // != 0: some slot of this lane still holds the previous write
+			pending = bad & (LEAKY ? 0xffff0000u : 0x80008000u);  // != 0: some slot of this lane still holds the previous write
 		};
 		auto loadPass = [&]() __attribute__((always_inline)) { loadPassTo(hvFirst); };
 		auto checkPass = [&]() __attribute__((always_inline)) {
-			if constexpr (kFastXchg) checkPassFast(hvFirst);
+			if constexpr (kLean) checkPassFast(hvFirst);
 			else checkPassOf(hvFirst);
 		};
 		loadPass();
@@ -1494,7 +1507,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			u32x4 hvSecond[NS];
 			loadPassTo(hvSecond);
 			__builtin_amdgcn_sched_barrier(0);
-			if constexpr (kFastXchg) {
+			if constexpr (kLean) {
 				checkPassFast(hvFirst);
 				if (__any(pending != 0)) {
 					checkPassFast(hvSecond);
