@@ -104,7 +104,7 @@ PREROLL_FRAMES = 256
 # bench.py cannot run rocprofv3 around itself, so `roofline.traffic` quotes the committed figure of the SAME kernel
 # -- only while the summary was collected on the kernel source that is being measured (joshupscale_amd/provenance.py:
 # the collector stores a digest of the kernel's .hip + headers; a figure with another digest, or none, is dropped)
-PMC_PROFILE = "r05_pmc_per_kernel_{preset}_{dtype}.json"
+PMC_PROFILE = "r06_pmc_per_kernel_{preset}_{dtype}.json"
 
 
 class SclkSampler:

@@ -13,7 +13,7 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pa$i
-  timeout 250 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pa$i -- python3 $R/bench.py $EXTRA --lookahead 1 --steps 8 --warmup 2 --no-cpu-baseline --roofline-iters 1 > $R/gpurun_out/pa$i.log 2>&1
+  timeout 250 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pa$i -- python3 $R/bench.py $EXTRA --extra-frames 0 --steps 8 --warmup 2 --no-cpu-baseline --roofline-iters 1 > $R/gpurun_out/pa$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, os, collections, json, re
