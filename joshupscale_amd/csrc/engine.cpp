@@ -697,6 +697,7 @@ void Engine::buildProgram(int set) {
 		rp.nLayers = 2 * c.genBlocks;
 		rp.leaky = c.genActivation == 1 ? 1 : 0;
 		rp.slope = c.genNegativeSlope;
+		rp.debug = m_Tensors.at("tower_profile").buf.get();
 		prog.push_back({"tower", 2.0 * H * W * 9.0 * 64.0 * 64 * 2 * c.genBlocks,
 		    [=](hipStream_t s) { launchResidentTower8(dt, rp, s); }});
 		a = 1;

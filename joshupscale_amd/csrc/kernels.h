@@ -309,6 +309,7 @@ struct ResidentTower8Params {
 	int nLayers;
 	int leaky;           // `activation: lrelu` models; the mailbox is then residentMailboxBytes8(GX, GY, true)
 	float slope;
+	void *debug;         // developer builds (-DJU_T8_PROF, tools/tower8_phases.py): [regions][4 waves][8] cycle sums; unused otherwise
 };
 std::size_t residentMailboxBytes8(int GX, int GY, bool leaky = false);
 void launchResidentTower8(DType dt, const ResidentTower8Params &p, hipStream_t stream);

@@ -103,6 +103,7 @@ struct Tower8Params {
 	int GX, GY, RH;
 	int nLayers;               // 2 x blocks
 	float slope;               // LEAKY instantiations: LeakyReLU negative slope
+	unsigned long long *debug; // JU_T8_PROF developer builds: [regions][4][8] cycle sums
 	int fault;                 // test hook: workgroups launched short (they never publish)
 	int skip;                  // timing ablation (JU_FB_SKIP, developer only): 1 exchange, 2 K loop, 4 epilogue
 };
@@ -201,6 +202,21 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	}
 	__syncthreads();
 
+	// JU_T8_PROF (developer builds: tools/dev_kernel_lib.sh tower8_kernels.hip x -DJU_T8_PROF, tools/tower8_phases.py): s_memtime
+	// sums per wave -- 0 sweep, 1 weight issue, 2 the layer's units, 3 barrier, 4 bias + publish, 5 K loops, 6 writes between
+	// the units + the exposed epilogue, 7 unused
+	unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long {
+#ifdef JU_T8_PROF
+		__builtin_amdgcn_sched_barrier(0);
+		unsigned long long t;
+		asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+		__builtin_amdgcn_sched_barrier(0);
+		return t;
+#else
+		return 0;
+#endif
+	};
 	// B fragments of one horizontal tap of a row pair: 4 input rows x 32 bytes per lane
 	auto loadFrags = [&](int off, int unit, int dx, i32x8(&fb)[4]) {
 		const int x = px + dx;
@@ -411,18 +427,29 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		if (u >= np2) return;
 		f32x16 A[2], B[2];
 		Vec4<T> rvA[2][4], rvB[2][4];
+		unsigned long long ts = stamp();
+		auto lap = [&](int slot) __attribute__((always_inline)) {
+			const unsigned long long t = stamp();
+			prof[slot] += t - ts;
+			ts = t;
+		};
 		kloop(u, A, rvA, std::false_type{}, nothing);
+		lap(5);
 		bool lastInB = false;
 		for (u += 2; u < np2;) {
 			kloop(u, B, rvB, std::true_type{}, [&](int k) __attribute__((always_inline)) { epiHalf(A, rvA, o8, o16, k); });
+			lap(5);
 			epiStores(u - 2, o8, o16);
+			lap(6);
 			u += 2;
 			if (u >= np2) {
 				lastInB = true;
 				break;
 			}
 			kloop(u, A, rvA, std::true_type{}, [&](int k) __attribute__((always_inline)) { epiHalf(B, rvB, o8, o16, k); });
+			lap(5);
 			epiStores(u - 2, o8, o16);
+			lap(6);
 			u += 2;
 		}
 		// the layer's last unit: its epilogue is exposed.  ONE code path, the set selected by value (two
@@ -439,6 +466,7 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			}
 			epiValues(L, rvL, o8, o16, std::false_type{});
 			epiStores(u - 2, o8, o16);
+			lap(6);
 		}
 	};
 
@@ -621,8 +649,11 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 	auto layerStep = [&](auto secondTag, const int i, i32x8(&wc)[9]) -> bool {
 		constexpr bool SECOND = decltype(secondTag)::value;
 		const bool more = i + 1 < L;
+		const unsigned long long t0 = stamp();
 		computeLayer(secondTag, i, wc);
+		const unsigned long long t1 = stamp();
 		__syncthreads();
+		const unsigned long long t2 = stamp();
 		// operands of layer i+1 (fetched one step ago) into the slots layer i-1 used; the
 		// sweep's closing barrier orders them before the next layer's reads
 		if (i >= 1 && more && wave == 0) {
@@ -630,21 +661,32 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 			ldsScale[((i + 1) & 1) * 64 + lane] = scaleNext;
 		}
 		if (more && !(JU_SKIP(p) & 1)) publish(std::integral_constant<int, SECOND ? kT8OffX : kT8OffT>{}, i);
+		const unsigned long long t3 = stamp();
 		// this layer's weight registers are free: refill them for layer i+2 while the
 		// neighbours' stores travel, THEN sweep (tower_kernels.hip, same order)
 		if (i + 2 < L) {
+			// (Round 6, tools/tower8_phases.py: these 18 loads of four waves are 1.1 k exposed cycles per layer here -- and the
+			// cheapest cover there is for the flight of the publish's stores: streamed from inside the next layer's first unit
+			// instead, the sweep's first pass comes too early and the layer is 5 us slower, profiles/r06_t8_wstream_ab.txt)
 			loadWeights(i + 2, wc);
 			if (wave == 0) {
 				biasNext = p.bias[(i + 2) * 64 + lane];
 				scaleNext = p.scaleA[(i + 2) * 64 + lane];
 			}
 		}
+		const unsigned long long t4 = stamp();
 		// the halo of the next layer's INPUT: this layer's output ring
 		if (more && !(JU_SKIP(p) & 1)) {
 			if (!fillHalo(std::integral_constant<int, SECOND ? kT8OffX : kT8OffT>{}, i)) return false;
 		} else {
 			__syncthreads();
 		}
+		const unsigned long long t5 = stamp();
+		prof[0] += t5 - t4;
+		prof[1] += t4 - t3;
+		prof[2] += t1 - t0;
+		prof[3] += t2 - t1;
+		prof[4] += t3 - t2;
 		return true;
 	};
 	using First = std::false_type;
@@ -657,6 +699,11 @@ __global__ __launch_bounds__(256, 1) void tower8_resident_kernel(Tower8Params p)
 		p.count[region * 2] = pubCount[0];
 		p.count[region * 2 + 1] = pubCount[1];
 	}
+#ifdef JU_T8_PROF
+	if (lane == 0 && p.debug != nullptr) {
+		for (int k = 0; k < 8; ++k) p.debug[(region * 4 + wave) * 8 + k] = prof[k];
+	}
+#endif
 	// ---- the stream's interior -> global tower-layout tensor ----
 	{
 		T *out = static_cast<T *>(p.out);
@@ -710,6 +757,7 @@ void launchResidentTower8(DType dt, const ResidentTower8Params &q, hipStream_t s
 	p.RH = q.RH;
 	p.nLayers = q.nLayers;
 	p.slope = q.slope;
+	p.debug = static_cast<unsigned long long *>(q.debug);
 	p.fault = residentFaultForTests();
 	p.skip = ablationSkipBits();
 	if (p.nLayers < 2 || (p.nLayers & 1)) throw std::invalid_argument("fp8 resident tower: layer count must be 2 x blocks");
