@@ -439,3 +439,44 @@ def test_passes_without_graphs_launch_eagerly_and_give_the_same_bytes(switch, mo
             assert all(np.array_equal(got[t], want[t]) for t in range(6)), rnd
         assert np.array_equal(rt.read_tensor("state"), want_state)
         assert rt.stat("lookahead_frames") == 12 and rt.stat("graph_captures") == 0
+
+
+def test_registered_tuples_keep_their_graphs_under_pressure_and_host_tuples_register_too():
+    """(advisor, round 5) A tuple handed to ju_prepare_batch is exempt from the LRU of unregistered tuples: after 70 other
+    tuples have come and gone (64 cached at most) its pass still replays -- no eager run, no capture inside the call.
+    Host tuples register as well (their frames ride in the pass's own device buffers: one graph per pass length and
+    binding set whatever the caller's addresses)."""
+    import torch
+    cfg = small_config()
+    h, w = cfg.frame_height, cfg.frame_width
+    blob = M.serialize(cfg, M.make_seeded_weights(cfg))
+    frames, d_in, _ = _device_clip(cfg, 2, seed=7)
+    dev = torch.device("cuda", 0)
+    outs = torch.zeros((72, 2, 4 * h, 4 * w, 4), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    with R.Runtime(blob, 0, R.DTYPE_F16) as rt:
+        ins = [rt.device_image(d_in[t].data_ptr(), w, h) for t in range(2)]
+        tup = lambda k: [rt.device_image(outs[k][t].data_ptr(), 4 * w, 4 * h) for t in range(2)]
+        assert rt.prepare_batch(ins, tup(0)) == 2
+        rt.process_batch(ins, tup(0))
+        want = outs[0].cpu().numpy().copy()
+        for k in range(1, 71):                       # 70 unregistered tuples, each seen twice: eager, then captured
+            for _ in range(2):
+                rt.reset()
+                rt.process_batch(ins, tup(k))
+        assert np.array_equal(outs[70].cpu().numpy(), want)
+        rt.reset()
+        c0, e0, r0 = rt.stat("graph_captures"), rt.stat("eager_runs"), rt.stat("graph_replays")
+        outs[0].zero_()
+        rt.process_batch(ins, tup(0))                # the registered tuple: still a replay
+        assert (rt.stat("graph_captures"), rt.stat("eager_runs"), rt.stat("graph_replays")) == (c0, e0, r0 + 1)
+        assert np.array_equal(outs[0].cpu().numpy(), want)
+        # host tuples
+        h_out = [np.zeros((4 * h, 4 * w, 4), np.uint8) for _ in range(2)]
+        assert rt.prepare_batch([R.host_image(frames[t]) for t in range(2)], [R.host_image(o) for o in h_out]) == 2
+        rt.reset()
+        c0, e0 = rt.stat("graph_captures"), rt.stat("eager_runs")
+        copies = [frames[t].copy() for t in range(2)]           # (other addresses than the registered ones)
+        rt.process_batch([R.host_image(c) for c in copies], [R.host_image(o) for o in h_out])
+        assert (rt.stat("graph_captures"), rt.stat("eager_runs")) == (c0, e0)
+        assert np.array_equal(np.stack(h_out), want) and rt.stat("lookahead_host_frames") == 2
