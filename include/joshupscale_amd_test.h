@@ -23,7 +23,9 @@ JU_API void ju_debug_fake_gl_counters(int *registered, int *mapped, int *maps, i
 /* Copies a named internal tensor to host memory as float32.  *count receives the
  * element count; dst may be NULL to query it.  Names: "state" (last output_raw,
  * f16 [4H][4W][4]), "flow" (f16 [PH][PW][32], the flow head before depth-to-space), "flow_in", "gen_in", "trunk",
- * "tail_y", and the per-layer flow activations. */
+ * "tail_y", and the per-layer flow activations.  "flow" and the flow activations are the PER-FRAME tensors: a look-ahead pass
+ * (ju_process_batch) computes its flow fields in tensors of its own and does not update them; "state", "flow_in" and "gen_in"
+ * are what the last frame of a pass left, as after ju_process. */
 JU_API int ju_read_tensor(ju_runtime *runtime, const char *name, float *dst, size_t capacity,
     size_t *count);
 
