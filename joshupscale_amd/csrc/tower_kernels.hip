@@ -1057,11 +1057,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			}
 		}
 		const u64 tu1 = stamp();
-#ifdef JU_DEV_WAITNOW
-		if constexpr (KIND == 0) { }
-#else
 		if constexpr (KIND == 0) prof[7] += tu1 - tu0;
-#endif
 #ifdef JU_TOWER_SEGPROF  // developer builds: the finish segments one by one (slots 3..6 carry them instead of their usual sums)
 		else if constexpr (KIND == 1 && !DEF) prof[3] += tu1 - tu0;
 		else if constexpr (KIND == 1 && DEF) prof[4] += tu1 - tu0;
@@ -1132,9 +1128,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		if constexpr (LO <= 2 && 2 < HI) slot(accPre2, 2);
 	};
 	// the rest of the layer: the pre-run units' remaining steps, then the other units whole
-	// seg1Done (JU_EARLYFIN_DEV timing builds): the first finish segment of this layer already ran inside the previous
-	// layer's halo fill
-	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const bool streamW, const bool seg1Done = false) __attribute__((always_inline)) {
+	auto finishLayer = [&](auto resTag, auto inTag, auto outTag, const int layer, const bool streamW) __attribute__((always_inline)) {
 		const int afterPre = firstWhole >= 0 ? firstWhole : (mySingle ? np2 : -1);
 		if constexpr (kDefer) {
 			// The fast schedule's shape (two pre-run pairs, then one or two whole pairs: every wave of a
@@ -1149,11 +1143,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				using N = std::false_type;
 				const int ua = firstWhole, ub = nextWhole(firstWhole);
 				int lastUnit = ua;
-#ifdef JU_EARLYFIN_DEV
-				if (!seg1Done) unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre0, layer, preFirst, false, -1, true, N{}, N{}, accPre0, 0, N{});
-#else
 				unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre0, layer, preFirst, false, preFirst + 2, true, N{}, N{}, accPre0, 0, N{});
-#endif
 				if (kPreRun == 3 && nPre == 3) {
 					// (16-row regions: three pre-run pairs, one whole pair)
 					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, true, preFirst + 4, true, N{}, Y{}, accPre0, preFirst, N{});
@@ -1161,11 +1151,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 					if (streamW) unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, Y{}, Y{}, accPre2, preFirst + 4, N{});
 					else unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre0, layer, ua, true, -1, false, N{}, Y{}, accPre2, preFirst + 4, N{});
 				} else {
-#ifdef JU_EARLYFIN_DEV
-					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, false, ua, false, N{}, Y{}, accPre0, preFirst, N{});
-#else
 					unitSeg(R2{}, KFin{}, resTag, inTag, outTag, accPre1, layer, preFirst + 2, true, ua, false, N{}, Y{}, accPre0, preFirst, N{});
-#endif
 					if (ub >= 0) {
 						// (the third set takes the first whole pair, so that the last one finds accPre0 free)
 						unitSeg(R2{}, KWhole{}, resTag, inTag, outTag, accPre2, layer, ua, true, ub, false, N{}, Y{}, accPre1, preFirst + 2, N{});
@@ -1261,17 +1247,19 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	// and read their OWN region's slot, which carries the same epoch); the publish stores unconditionally (an entry
 	// beyond the region's rows lands in its own slot, which no consumer reads).
 	// Every instantiation but the plain schedule (VARIANT 8: the tests' cross-check keeps the per-slot form, on the same
-	// mailbox -- the slots both forms read are written by both) exchanges this way; kCompact: the ReLU slot format, whose
-	// publish and sweep also pack both columns into one slot per thread (below).
+	// mailbox -- the slots both forms read are written by both) exchanges this way.
 	constexpr bool kLean = VARIANT != 8;
-	constexpr bool kCompact = kLean && !LEAKY;
+	constexpr bool kCompact = kLean;  // (the column strips packed: below)
 	constexpr int kSlots = LEAKY ? 2 * kResMailSlots : kResMailSlots;  // per region and parity
 	constexpr int CPP = LEAKY ? 16 : 8;      // slots per pixel record
 	constexpr int CSH = LEAKY ? 4 : 3;
-	// (kCompact: a region is at most 16 rows high, so the two column strips have 16 entries each and share ONE
-	// slot per thread -- threads 0..127 the left column, 128..255 the right one: 3 publish stores and 4 sweep loads per
-	// thread instead of 4 and 5, every lane of every instruction at work; the mailbox's slot numbering is unchanged)
-	constexpr int NP = kCompact ? 3 : kSlots / 256;  // publish: 4 strips x 32 entries x CPP slots
+	// (kCompact: a region is at most 16 rows high, so a column strip has 16 entries, not 32 -- ReLU: both columns share ONE
+	// slot per thread (threads 0..127 the left column, 128..255 the right one): 3 publish stores and 4 sweep loads per
+	// thread instead of 4 and 5; LeakyReLU (twice the slots per pixel): one slot per thread and column, 6 and 7 instead of
+	// 8 and 9 -- every lane of every instruction at work; the mailbox's slot numbering is unchanged)
+	constexpr int ROWITS = 2 * CPP / 8;      // slots per thread of the two row strips
+	constexpr int COLPT = 16 * CPP;          // threads (= slots) of one packed column strip
+	constexpr int NP = kCompact ? ROWITS + 2 * COLPT / 256 : kSlots / 256;  // publish: 4 strips x 32 entries x CPP slots
 	constexpr int NS = NP + 1;               // sweep: 4 sides x 32 entries x CPP slots, + the 4 corners
 	unsigned pubLds[NP];                     // LDS byte offset inside a buffer of the (half) chunk to publish
 	unsigned pubOff[kCompact ? NP : 1];      // kCompact: the slot's byte offset in the mailbox, parity 0 (else pubBase + it * 4096)
@@ -1281,9 +1269,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		const int idx = it * 256 + tid;
 		int strip = idx >> (5 + CSH), e = (idx >> CSH) & 31;
 		const int cs = idx & (CPP - 1);
-		if (kCompact && it == 2) {
-			strip = 2 + (tid >> 7);
-			e = (tid >> 3) & 15;
+		if (kCompact && it >= ROWITS) {
+			const int j = (it - ROWITS) * 256 + tid;
+			strip = 2 + j / COLPT;
+			e = (j / CPP) & 15;
 		}
 		if constexpr (kCompact) pubOff[it] = (unsigned)((region * 2) * kSlots + (strip * 32 + e) * CPP + cs) * 16u;
 		const int c = LEAKY ? cs >> 1 : cs, half = LEAKY ? (cs & 1) * 8 : 0;
@@ -1312,9 +1301,10 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			const int hp = idx >> CSH;
 			cs = idx & (CPP - 1);
 			int side = hp >> 5, e = hp & 31;
-			if (kCompact && it == 2) {  // (both columns in one slot per thread, 16 entries each)
-				side = 2 + (tid >> 7);
-				e = (tid >> 3) & 15;
+			if (kCompact && it >= ROWITS) {  // (the packed column strips, 16 entries each)
+				const int j = (it - ROWITS) * 256 + tid;
+				side = 2 + j / COLPT;
+				e = (j / CPP) & 15;
 			}
 			// side 0: row above, 1: row below, 2: column left, 3: column right
 			if (side < 2) {
@@ -1379,7 +1369,7 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 				if (kLean || (pubValid >> it & 1u)) {
 					const u32x4 d = {(v[it][0] & 0xffffu) | tg, (v[it][0] >> 16) | tg, (v[it][1] & 0xffffu) | tg,
 					    (v[it][1] >> 16) | tg};
-					__builtin_amdgcn_raw_buffer_store_b128(d, mailRsrc, pubBase + it * 4096, soff, kSc1);
+					__builtin_amdgcn_raw_buffer_store_b128(d, mailRsrc, kCompact ? pubOff[it] : pubBase + it * 4096, soff, kSc1);
 				}
 			}
 		} else {
@@ -1405,9 +1395,6 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		// tag-checked by its consumer; the two wait states cost nothing and keep the store's data
 		// registers untouched for as long as the probe's worst case needed.
 		asm volatile("s_nop 1" ::: "memory");
-#ifdef JU_DEV_PUBWAIT  // developer timing build: how long do the write-through stores take to be acknowledged?
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 	};
 	// fills the halo ring of buffer `off` with the neighbours' output of layer `layer`;
 	// returns false on timeout (uniform across the workgroup)
@@ -1481,26 +1468,12 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 		};
 		loadPass();
 		__builtin_amdgcn_sched_barrier(0);
-#ifdef JU_DEV_WAITNOW  // developer diagnostic: the raw latency of the sweep's loads, nothing else running (profile slot 7 instead of the pre-run)
-		{
-			const u64 w0 = stamp();
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			prof[7] += stamp() - w0;
-		}
-#endif
-#ifdef JU_DEV_SLEEPCOVER  // developer diagnostic: ~2.5k idle cycles between the loads and their check (is it the K loops that hold the returns up?)
-		for (int z = 0; z < 20; ++z) __builtin_amdgcn_s_sleep(2);
-#endif
 		behindFirstPass();  // (work the caller wants done while the loads travel; vmcnt is in-order)
 		__builtin_amdgcn_sched_barrier(0);
 #ifdef JU_TOWER_FILLPROF  // developer diagnostic (variant 4): where inside the fill the time goes -- slots 1, 3, 4 of the profile
 		const u64 fp0 = stamp();
 #endif
-#ifdef JU_DEV_NOSECOND
-		if constexpr (false) {
-#else
 		if constexpr (FAST) {
-#endif
 			// A second pass in flight before the first is checked: when the first came too early for a slot
 			// (0.3 times per layer), its data is one pre-run unit behind instead of a whole round trip
 			// (-1 % per tower; twice the sweep's read traffic, 5 MB more per layer over the chip).
@@ -1564,17 +1537,13 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	const int L = p.nLayers;
 	// RES / PAR are compile-time: a runtime `if (residual)` around the epilogue's LDS
 	// read makes hipcc branch and wait per element (+1 us per layer, measured).
-	auto layerStep = [&](auto resTag, auto parTag, const int i, [[maybe_unused]] auto nextResTag) __attribute__((always_inline)) -> bool {
+	auto layerStep = [&](auto resTag, auto parTag, const int i) __attribute__((always_inline)) -> bool {
 		constexpr int PAR = decltype(parTag)::value;
 		using InT = std::integral_constant<int, PAR ? kResOffB : kResOffA>;
 		using OutT = std::integral_constant<int, PAR ? kResOffA : kResOffB>;
 		const bool more = i + 1 < L;
 		const u64 t0 = stamp();
-#ifdef JU_EARLYFIN_DEV
-		finishLayer(resTag, InT{}, OutT{}, i, more && streamsInUnit, FAST && i > 0);
-#else
 		finishLayer(resTag, InT{}, OutT{}, i, more && streamsInUnit);
-#endif
 		if constexpr (VARIANT == 5) {
 			// per-layer maximum over the frame -> debug[i] (non-negative floats order like
 			// their bit patterns, so an integer atomic max does it)
@@ -1620,14 +1589,6 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 			preRun(OutT{}, InT{}, Z{}, Split{}, i + 1, primePre);
 			const bool okFill = fillHalo(OutT{}, i, [&]() __attribute__((always_inline)) {
 				preRun(OutT{}, InT{}, Split{}, N{}, i + 1, primePre);
-#ifdef JU_EARLYFIN_DEV
-				// TIMING BUILD (wrong frames: the halo columns it reads are the previous layer's): the next layer's first
-				// finish segment between the sweep's loads and its check -- what a mid-layer publish of the early units'
-				// edge columns would allow
-				if constexpr (FAST) {
-					unitSeg(R2{}, KFin{}, nextResTag, OutT{}, InT{}, accPre0, i + 1, preFirst, false, -1, true, std::false_type{}, std::false_type{}, accPre0, 0, std::false_type{});
-				}
-#endif
 			});
 			if (!okFill) return false;
 		} else {
@@ -1653,17 +1614,16 @@ __global__ __launch_bounds__(256, 1) void tower_resident_kernel(ResidentParams p
 	using P1 = std::integral_constant<int, 1>;
 	preRun(std::integral_constant<int, kResOffA>{}, std::integral_constant<int, kResOffB>{}, std::integral_constant<int, 0>{},
 	    std::integral_constant<int, kPreRun>{}, 0, false);
-	// (the last argument: does the NEXT layer add a residual -- its first segments may run inside this layer's exchange)
 	if (HEAD) {  // conv_1, then (conv1, conv2+skip) pairs: L is odd
-		if (!layerStep(No{}, P0{}, 0, No{})) return;
+		if (!layerStep(No{}, P0{}, 0)) return;
 		for (int i = 1; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P1{}, i, Yes{})) return;
-			if (!layerStep(Yes{}, P0{}, i + 1, No{})) return;
+			if (!layerStep(No{}, P1{}, i)) return;
+			if (!layerStep(Yes{}, P0{}, i + 1)) return;
 		}
 	} else {  // (conv1, conv2+skip) pairs: L is even
 		for (int i = 0; i + 1 < L; i += 2) {
-			if (!layerStep(No{}, P0{}, i, Yes{})) return;
-			if (!layerStep(Yes{}, P1{}, i + 1, No{})) return;
+			if (!layerStep(No{}, P0{}, i)) return;
+			if (!layerStep(Yes{}, P1{}, i + 1)) return;
 		}
 	}
 	const int finalOff = (L & 1) ? kResOffB : kResOffA;
