@@ -312,7 +312,7 @@ def main() -> int:
     phases = (args.preroll, args.warmup, args.steps)
     prepared = 0
     if not args.no_prepare:
-        prepared = register(rt, phases, look)
+        prepared = register(rt, phases, look, host_too=host_main)
         if extra:
             prepared += register(rt, (extra,), 8, host_too=True)
 
@@ -341,9 +341,9 @@ def main() -> int:
     host_fbf = secondary(1, True)
     host_la = secondary(8, True)
     # the synchronous call's latency: the frame-by-frame region's own per-call timers (the boundary `value` is taken through)
-    if fbf is not None:
+    if fbf is not None and not host_main:
         latency = dict(fbf["call_latency_ms"], boundary="ju_process", frames=fbf["frames"])
-    elif main_lat:
+    elif main_lat:  # (host frames in `value`: the latency of THOSE calls)
         ml = sorted(main_lat)
         latency = {"p50": ml[len(ml) // 2], "p99": ml[min(len(ml) - 1, int(len(ml) * 0.99))], "max": ml[-1],
                    "calls": len(ml), "boundary": "ju_process", "frames": len(ml)}

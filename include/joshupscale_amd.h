@@ -115,7 +115,9 @@ JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image
  * ju_set_lookahead caps the frames per pass (1 = off); its default is 8, or JU_LOOKAHEAD=<1..8> at creation. */
 JU_API int ju_process_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image *outputs, int count);
 /* Frames per look-ahead pass of ju_process_batch for THIS runtime, 1 (every frame as ju_process does) .. 8; values
- * outside are clamped.  Passes registered with ju_prepare_batch that are longer than the new cap are forgotten.  The
+ * outside are clamped.  Passes registered with ju_prepare_batch that are longer than the new cap are forgotten; RAISING
+ * the cap after passes have run or been registered re-allocates the passes' tensors, and every pass graph is then
+ * captured again at its next use (set the cap once, before ju_prepare_batch).  The
  * setter is what a host application uses; the JU_LOOKAHEAD environment variable only sets the default of runtimes
  * created afterwards (one process, several filters: each sets its own). */
 JU_API int ju_set_lookahead(ju_runtime *runtime, int frames);

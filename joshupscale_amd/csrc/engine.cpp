@@ -1559,7 +1559,9 @@ bool Engine::batchPlanned(int items) {
 			m_BatchGraphs.clear();
 			m_BatchFlow.clear();
 			m_BatchTensors.clear();
-			const int cap = std::max(items, std::min(4, kFlowBatchMax));
+			// (the whole cap at once: growing later reallocates the tensors every captured pass is bound to -- also the
+			// registered ones -- and round 6's bench lost a registered short pass that way.  ~210 MB at 480x270 for 8 frames.)
+			const int cap = std::max(items, m_BatchMax);
 			for (const auto &kv : m_Tensors) {
 				const bool flowTensor = kv.first == "flow" || kv.first.rfind("flow/", 0) == 0;
 				if (!flowTensor) continue;
