@@ -275,8 +275,21 @@ def main() -> int:
                         got += runtime.prepare_batch(host_ins[:n], host_outs[:n])
         return got
 
+    import ctypes as C
+    refs = {id(lst): [C.byref(x) for x in lst] for lst in (dev_ins, dev_outs, host_ins, host_outs)}
+
     def run_phase(runtime, count: int, per_call: int, host: bool = False, lat=None) -> None:
         ins, outs = (host_ins, host_outs) if host else (dev_ins, dev_outs)
+        if per_call == 1 and lat is None:
+            # the frame-by-frame loop as a C caller would write it: the descriptors' addresses taken once, the entry point
+            # looked up once (the Python binding's per-call work -- two byref objects, a method dispatch, the generator above
+            # -- is ~1.5 us of a 264 us psp-fast frame, and none of it is the product's)
+            proc, hnd, rin, rout = runtime._lib.ju_process, runtime._h, refs[id(ins)], refs[id(outs)]
+            for i in range(count):
+                pos = i % RING
+                if proc(hnd, rin[pos], rout[pos]):
+                    runtime.process(ins[pos], outs[pos])   # (raises with the runtime's message)
+            return
         for pos, n in passes(count, per_call):
             t1 = time.perf_counter() if lat is not None else 0.0
             if n == 1:
@@ -320,8 +333,7 @@ def main() -> int:
         run_phase(rt, args.preroll, look, host_main)  # clock-warm, fixed, outside the contract's warm-up
     run_phase(rt, args.warmup, look, host_main)
     # ---- the contract's timed region: EXACTLY --steps frames through the boundary -----------------------------------
-    main_lat = [] if look == 1 else None
-    elapsed, own_elapsed, timed_region = timed(args.steps, look, host_main, main_lat)
+    elapsed, own_elapsed, timed_region = timed(args.steps, look, host_main)
     rank_fps = jdist.gather_floats(args.steps / own_elapsed, device)
 
     # ---- secondary regions (same runtime, same box, same method; each after a short warm-up of its own kind) --------
@@ -341,14 +353,9 @@ def main() -> int:
     host_fbf = secondary(1, True)
     host_la = secondary(8, True)
     # the synchronous call's latency: the frame-by-frame region's own per-call timers (the boundary `value` is taken through)
-    if fbf is not None and not host_main:
-        latency = dict(fbf["call_latency_ms"], boundary="ju_process", frames=fbf["frames"])
-    elif main_lat:  # (host frames in `value`: the latency of THOSE calls)
-        ml = sorted(main_lat)
-        latency = {"p50": ml[len(ml) // 2], "p99": ml[min(len(ml) - 1, int(len(ml) * 0.99))], "max": ml[-1],
-                   "calls": len(ml), "boundary": "ju_process", "frames": len(ml)}
-    else:
-        latency = None
+    # (per-call timers run in the secondary regions only; with --location host the latency is that of host-frame calls)
+    src = host_fbf if host_main else fbf
+    latency = dict(src["call_latency_ms"], boundary="ju_process", frames=src["frames"]) if src is not None else None
 
     result = None
     # a timed region that is not pure steady state is not a measurement of it: refuse
