@@ -107,11 +107,13 @@ JU_API int ju_process(ju_runtime *runtime, const ju_image *input, const ju_image
  * and the recurrent state afterwards is the same -- but ALL inputs must hold their pixels when the call is made
  * (an input that overlaps the OUTPUT of an earlier frame of the call -- to be read after that write, frame by frame --
  * simply starts a new pass, and so does an output that overlaps an earlier frame's INPUT).
- * The flow net reads LR frames only, never the HR state, so for JU_LOC_DEVICE frames the runtime computes the flow
- * fields of up to 8 frames in ONE pass of the flow net's launches, which fill the chip where one frame's do not
- * (-40 % flow time per frame at 480x270); warp, tower and tail stay strictly frame by frame.  Frames the pass
- * cannot take (host frames, GL resources, a model without the one-launch flow plan) simply run as ju_process
- * does.  For callers that can read ahead: a file transcoder, an AviSynth filter fetching child frames n .. n+3.
+ * The flow net reads LR frames only, never the HR state, so the runtime computes the flow fields of up to 8 frames in
+ * ONE pass of the flow net's launches, which fill the chip where one frame's do not (-40 % flow time per frame at
+ * 480x270); warp, tower and tail stay strictly frame by frame.  JU_LOC_DEVICE frames are read and written in place;
+ * host frames (JU_LOC_CPU) ride in the same passes -- every input uploaded up front, each output copied out while the
+ * next frame's kernels run (pageable memory; nothing of the caller's is page-locked).  Frames a pass cannot take (GL
+ * resources, a model without the one-launch flow plan) simply run as ju_process does.  For callers that can read
+ * ahead: a file transcoder, an AviSynth filter fetching child frames n .. n+7.
  * ju_set_lookahead caps the frames per pass (1 = off); its default is 8, or JU_LOOKAHEAD=<1..8> at creation. */
 JU_API int ju_process_batch(ju_runtime *runtime, const ju_image *inputs, const ju_image *outputs, int count);
 /* Frames per look-ahead pass of ju_process_batch for THIS runtime, 1 (every frame as ju_process does) .. 8; values
@@ -121,7 +123,7 @@ JU_API int ju_process_batch(ju_runtime *runtime, const ju_image *inputs, const j
  * setter is what a host application uses; the JU_LOOKAHEAD environment variable only sets the default of runtimes
  * created afterwards (one process, several filters: each sets its own). */
 JU_API int ju_set_lookahead(ju_runtime *runtime, int frames);
-/* What ju_prepare_frames is to ju_process: registers a tuple of 2 .. JU_LOOKAHEAD JU_LOC_DEVICE frame buffers the
+/* What ju_prepare_frames is to ju_process: registers a tuple of 2 .. cap (ju_set_lookahead) frame buffers -- device or host -- the
  * caller is going to hand to ju_process_batch as one pass; its hipGraphs (one per binding set) are captured now,
  * nothing executes.  Unregistered tuples are captured at their second use.  *captured (optional) = graphs captured
  * by this call; 0 for a tuple that will not run as one pass. */
